@@ -1,0 +1,240 @@
+/*
+ * se_amd.h -- C ABI of the MI355X (gfx950) speech-enhancement hot path.
+ *
+ * Drop-in boundary for the per-utterance path of leo19941227/Speech-Enhancement-by-S3PRL
+ * (STFT -> features -> [TERA/Mockingjay encoder] -> mask / spectrogram head -> mask (.) |X|^2 ->
+ * iSTFT -> level normalisation, plus the masked log-L1 objective).  The reference has no native code
+ * and no FFI: its interface for this path is the Python duck-typed surface of SURVEY.md section 8(b)
+ * (S3PRL's OnlinePreprocessor / TRANSFORMER / TransformerSpecPredictionHead and the reference's
+ * model.py / objective.py / utils.py / runner.py call sites).  Each entry point below cites the
+ * reference call it replaces; the Python host (the .py files of speech-enhancement-by-s3prl_amd) mirrors those
+ * classes and binds these symbols through ctypes (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - plain C: pointers + sizes only, no C++ / torch types.  Every data pointer is DEVICE memory
+ *     owned by the caller (torch.Tensor.data_ptr() of a contiguous tensor), fp32 unless stated.
+ *   - every launch takes `stream` = a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
+ *     calls are asynchronous and never synchronise.  No allocation happens inside launch calls;
+ *     workspaces are caller-owned and sized by the *_workspace_bytes() queries.
+ *   - return 0 on success, negative se_status on error; se_last_error() gives a thread-local message.
+ *     Allocation failures carry the substring "CUDA out of memory" so the reference's skip-batch
+ *     handler (runner.py:505,606) keeps working.
+ *   - plans / encoders are immutable after creation and may be shared across streams.
+ *     HIP is initialised lazily (first plan creation / launch), never at library load, so a spawned
+ *     child may set HIP_VISIBLE_DEVICES first (sampler.py:145-153).
+ */
+#ifndef SE_AMD_H_
+#define SE_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum se_status {
+  SE_OK = 0,
+  SE_ERR_INVALID = -1,      /* bad argument / shape */
+  SE_ERR_UNSUPPORTED = -2,  /* geometry the gfx950 kernels are not specialised for */
+  SE_ERR_HIP = -3,          /* a HIP runtime call failed */
+  SE_ERR_OOM = -4,          /* device allocation failed ("CUDA out of memory ...") */
+  SE_ERR_NO_DEVICE = -5
+} se_status;
+
+/* activation ids shared by the head kernels (model.py:12,24: nn.<activation>()) */
+typedef enum se_act { SE_ACT_IDENTITY = 0, SE_ACT_RELU = 1, SE_ACT_SIGMOID = 2, SE_ACT_GELU = 3, SE_ACT_EXP = 4 } se_act;
+
+const char* se_last_error(void);
+const char* se_version(void);
+/* 1 if a gfx950 device is visible, 0 otherwise (never throws; initialises HIP). */
+int se_device_available(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Preprocessor plan: STFT geometry + device tables (Hann window, twiddles, sparse HTK mel bank).
+ * Replaces OnlinePreprocessor.__init__ (S3PRL utility/preprocessor.py; constructed at
+ * run_downstream.py:159 from config/pretrain_sample.yaml:39-48).
+ * The kernels are specialised for n_fft = 400 (n_freq = 201), hop = 160, win <= 400; anything else
+ * returns SE_ERR_UNSUPPORTED.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct se_plan se_plan;
+
+typedef struct se_geometry {
+  int sample_rate; /* 16000 */
+  int win;         /* 400 samples (win_ms 25) */
+  int hop;         /* 160 samples (hop_ms 10) */
+  int n_freq;      /* 201 */
+  int n_mels;      /* 40 (<= 64) */
+} se_geometry;
+
+int se_plan_create(const se_geometry* geom, se_plan** out);
+void se_plan_destroy(se_plan* plan);
+/* copies the plan's host-side tables out (for tests): window[n_fft = 400] (win centred), mel_fb[n_freq*n_mels] row-major (k, m). */
+int se_plan_tables(const se_plan* plan, float* window, float* mel_fb);
+
+/* Number of STFT frames of a T-sample signal: T / hop + 1 (runner.py:455). */
+int se_num_frames(const se_plan* plan, int n_samples);
+
+/*
+ * se_stft_f32 -- rows A1 + A2 (+ A3): OnlinePreprocessor.forward's `_stft` + `_magphase` (+ `_melscale`)
+ * for ONE channel of wavs (runner.py:433,558; sampler.py:60,226-228).
+ *   wavs     (B, C, T) fp32, contiguous
+ *   power    (B, F, K) fp32 time-major  re^2+im^2            (may be NULL)
+ *   phase    (B, F, K) fp32 time-major  atan2(im, re)        (may be NULL)
+ *   complx   (B, F, K, 2) fp32 time-major (re, im)           (may be NULL)
+ *   mel      (B, n_mels, F) fp32 FEATURE-major raw mel power (may be NULL) -- input of se_features_f32
+ * F = T/hop + 1, K = n_freq.  reflect padding of n_fft/2 on both sides, periodic Hann, one-sided.
+ */
+int se_stft_f32(const se_plan* plan, const float* wavs, int B, int C, int T, int channel,
+                float* power, float* phase, float* complx, float* mel, void* stream);
+
+/*
+ * se_features_f32 -- row A4: OnlinePreprocessor.forward's select_feat: log(x+eps), `delta` stacked
+ * compute_deltas passes (5-tap, replicate), CMVN over time (unbiased std, +eps), transposed to
+ * time-major.
+ *   raw       feature-major (B, D, F) if raw_time_major == 0, else time-major (B, F, D)
+ *   out       (B, F, D*(1+delta)) fp32 time-major
+ *   workspace >= se_features_workspace_bytes(B, D, F, delta) bytes of device memory
+ */
+size_t se_features_workspace_bytes(int B, int D, int F, int delta);
+int se_features_f32(const float* raw, int raw_time_major, int B, int D, int F,
+                    int apply_log, int delta, int cmvn, float eps,
+                    float* out, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * se_istft_f32 -- row A6: OnlinePreprocessor.istft(linears, phases) (runner.py:267): mag = power^(1/linear_power),
+ * (mag cos phi, mag sin phi) -> inverse 400-pt real DFT -> x Hann -> overlap-add -> / sum(w^2) -> trim n_fft/2.
+ *   power, phase (B, F, K) time-major;   wav_out (B, wav_stride) with the first hop*(F-1) samples written and
+ *   samples [hop*(F-1), wav_stride) zero-filled (the right-pad of runner.py:268).
+ *   sumsq_out (B) optional: sum over n < lengths[b] of wav^2 (feeds se_dbnorm_f32); zeroed inside this call
+ *   (a memset on `stream`).
+ *   lengths   (B) int64 device pointer, required iff sumsq_out != NULL.
+ */
+int se_istft_f32(const se_plan* plan, const float* power, const float* phase, int B, int F,
+                 float linear_power, float* wav_out, int wav_stride,
+                 const int64_t* lengths, float* sumsq_out, void* stream);
+
+/*
+ * se_masked_sumsq_f32 -- utils.py:26-29 numerator: sums[b] = sum_{n < lengths[b]} x[b,n]^2  (sums zeroed inside).
+ */
+int se_masked_sumsq_f32(const float* x, int B, int T, int x_stride, const int64_t* lengths, float* sums, void* stream);
+
+/*
+ * se_dbnorm_f32 -- row D2: masked_normalize_decibel (utils.py:31-46) given the masked square sums:
+ *   scale[b] = sqrt( 10^(target_db[b]/10) / (wav_sumsq[b]/(len[b]+eps) + eps) ),  wav *= scale   (in place)
+ *   target: if ref_sumsq != NULL: target_db[b] = 10 log10( ref_sumsq[b] / (len[b]+eps) )   (reference-audio form)
+ *           else: fixed_db (e.g. -25)
+ */
+int se_dbnorm_f32(float* wav, int B, int T, int wav_stride, const int64_t* lengths,
+                  const float* wav_sumsq, const float* ref_sumsq, float fixed_db, float eps, void* stream);
+
+/*
+ * se_length_masks_i64 -- row D1: Runner._get_length_masks (runner.py:216-220): masks[b,t] = t < lengths[b] (int64).
+ */
+int se_length_masks_i64(const int64_t* lengths, int B, int max_len, int64_t* masks, void* stream);
+
+/*
+ * se_head_linear_f32 -- rows C1 / C2: LinearResidual.forward (model.py:28-34) and Linear.forward (model.py:14-17).
+ *   feats (B, F, D) time-major; W (N, D) row-major (nn.Linear.weight); bias (N)
+ *   cmvn != 0: features are normalised over time (dim=1), unbiased std, `+eps` outside the sqrt, first.
+ *   offset    (B, F, N) = act(feats W^T + bias)                      (may be NULL)
+ *   predicted (B, F, N) = linears * offset  if linears != NULL (C1)  else = offset (C2)
+ *   workspace >= se_head_workspace_bytes(B, F, D, N)
+ *   Exact fp32 arithmetic (f32-input MFMA, k-ordered fmaf chain).
+ */
+size_t se_head_workspace_bytes(int B, int F, int D, int N);
+int se_head_linear_f32(const float* feats, const float* W, const float* bias, const float* linears,
+                       int B, int F, int D, int N, int act, int cmvn, float eps,
+                       float* predicted, float* offset, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * se_head_linear_bwd_f32 -- autograd of C1/C2 wrt the head parameters (runner.py:459 loss.backward()):
+ *   given d_offset-pre-activation gradient inputs:  grad_predicted (B,F,N), linears (or NULL), offset (B,F,N)
+ *   computes gW (N, D) and gb (N) (accumulated over all frames of all utterances; zeroed inside).
+ *   Needs the same feats / cmvn / eps as the forward (the normalised features are recomputed).
+ */
+int se_head_linear_bwd_f32(const float* feats, const float* linears, const float* offset, const float* grad_predicted,
+                           int B, int F, int D, int N, int act, int cmvn, float eps,
+                           float* gW, float* gb, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * se_l1_masked_f32 -- row E1: L1.forward (objective.py:103-117) in un-normalised form:
+ *   sums[0] = sum over valid frames (f < frame_lengths[b]) and bins of |log_pred - log(linear_tar + eps)|
+ *   sums[1] = number of such elements.        loss = sums[0] / sums[1]  (global mean over the batch;
+ *   under data parallelism both are all-reduced first).  sums is a DEVICE double[2], zeroed inside.
+ *   grad (optional, may be NULL): sign(log_pred - log(tar+eps)) on valid elements, 0 elsewhere -- the caller
+ *   scales by 1/sums[1] (global count).
+ */
+int se_l1_masked_f32(const float* log_pred, const float* linear_tar, const int64_t* frame_lengths,
+                     int B, int F, int K, float eps, double* sums, float* grad, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Encoder: S3PRL TRANSFORMER (rows B1-B3) + TransformerSpecPredictionHead (row B4), bf16 MFMA.
+ * Replaces TRANSFORMER.forward (model.py:164; runner.py:275,282) and
+ * TransformerSpecPredictionHead.forward (model.py:120,165).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct se_encoder se_encoder;
+
+typedef struct se_encoder_config {
+  int input_dim;     /* D: 80 for mel/log/delta1 (pretrain_sample.yaml:54-59) */
+  int hidden;        /* 768  */
+  int layers;        /* 6 (sample config) / 3 (base) */
+  int heads;         /* 12, head dim must be 64 */
+  int intermediate;  /* 3072 */
+  float ln_eps;      /* 1e-12 */
+  int spec_out;      /* 0 = no spec head; else output dim of the head (201) */
+} se_encoder_config;
+
+/* HOST pointers to fp32 weights, nn.Linear layout (out, in); arrays of `layers` pointers per-layer. */
+typedef struct se_encoder_weights {
+  const float *in_w, *in_b, *in_ln_w, *in_ln_b;
+  const float* const *q_w, * const *q_b, * const *k_w, * const *k_b, * const *v_w, * const *v_b;
+  const float* const *ao_w, * const *ao_b, * const *aln_w, * const *aln_b;
+  const float* const *ff1_w, * const *ff1_b, * const *ff2_w, * const *ff2_b, * const *oln_w, * const *oln_b;
+  const float *sh_dense_w, *sh_dense_b, *sh_ln_w, *sh_ln_b, *sh_out_w, *sh_out_b; /* spec head (may be NULL) */
+} se_encoder_weights;
+
+int se_encoder_create(const se_encoder_config* cfg, const se_encoder_weights* w, se_encoder** out);
+void se_encoder_destroy(se_encoder* enc);
+size_t se_encoder_workspace_bytes(const se_encoder* enc, int B, int T);
+
+/*
+ * se_encoder_fwd_bf16 -- feats (B, T, D) fp32 -> hidden (B, T, H) fp32 (last layer, select_layer -1, eval mode).
+ *   lengths (B) int32 device pointer: valid frames per utterance (keys >= length are masked, the
+ *   (1-mask)*-10000 additive mask of S3PRL); NULL = all T valid.
+ *   GEMM operands bf16, fp32 accumulate, fp32 residual stream, fp32 LayerNorm / softmax.
+ */
+int se_encoder_fwd_bf16(const se_encoder* enc, const float* feats, const int32_t* lengths, int B, int T,
+                        float* hidden, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * se_spechead_fwd_bf16 -- rows B4 + C3: dense -> gelu -> LayerNorm -> output linear, then SpecHead.forward's
+ * epilogue (model.py:119-126):  log_target != 0: predicted = act(exp(p)), log_predicted = p
+ *                               else:            predicted = act(p), log_predicted = log(p + eps)
+ *   hidden (B, T, H) fp32;  predicted, log_predicted (B, T, spec_out) fp32 (either may be NULL);
+ *   raw (B, T, spec_out) optional: the un-activated linear output p.
+ */
+int se_spechead_fwd_bf16(const se_encoder* enc, const float* hidden, int B, int T, int log_target, int act, float eps,
+                         float* predicted, float* log_predicted, float* raw,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* frame validity: lengths[b] = #frames whose feature sum != 0 (S3PRL process_input_data). feats (B,T,D). */
+int se_valid_lengths_i32(const float* feats, int B, int T, int D, int32_t* lengths, void* stream);
+
+/* Building blocks, exported for tests / roofline measurement. All bf16 = uint16_t device arrays. */
+/* C[M,N] = epilogue(A[M,K] . W[N,K]^T + bias);  A, W bf16 row-major (K contiguous); lda/ldw/ldc in elements.
+ *   out_bf16 / out_f32 (either may be NULL); residual_f32 (M,N) optional, added before the store; act in se_act. */
+int se_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias,
+                 const float* residual_f32, int M, int N, int K, int act,
+                 uint16_t* out_bf16, float* out_f32, int ldc, void* stream);
+/* qkv (B*T, 3H) bf16 = [Q | K | V] per row, heads of 64 columns; ctx (B*T, H) bf16. */
+int se_mhsa_fwd_bf16(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, void* stream);
+/* y = LN(x) * w + b over the last dim H (TF style, eps inside sqrt); x fp32 (M,H); outputs fp32 and/or bf16. */
+int se_layernorm_f32(const float* x, const float* w, const float* b, int M, int H, float eps,
+                     float* out_f32, uint16_t* out_bf16, void* stream);
+int se_cast_f32_bf16(const float* x, size_t n, uint16_t* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SE_AMD_H_ */

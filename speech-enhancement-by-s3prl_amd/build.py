@@ -1,0 +1,93 @@
+"""Builds libse_amd.so (all HIP kernels + the C ABI of include/se_amd.h) for gfx950 with hipcc.
+
+In-tree build: the .so lands next to this file, travels to the GPU box with the snapshot and is
+git-ignored.  No torch / pybind involvement: the library is plain C ABI, bound via ctypes (_lib.py).
+
+    python speech-enhancement-by-s3prl_amd/build.py [--force] [--jobs N]
+"""
+import argparse
+import concurrent.futures
+import hashlib
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+OBJ = os.path.join(HERE, 'build')
+LIB = os.path.join(HERE, 'libse_amd.so')
+ARCH = 'gfx950'
+FLAGS = ['-O3', '-std=c++17', '-fPIC', f'--offload-arch={ARCH}', '-fno-gpu-rdc', '-Wall', '-Wno-unused-function',
+         '-Wno-comment', '-I' + os.path.join(HERE, '..', 'include')]
+
+
+def _hipcc():
+    for cand in (os.environ.get('HIPCC'), '/opt/rocm/bin/hipcc', 'hipcc'):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    raise RuntimeError('hipcc not found')
+
+
+def _digest(paths):
+    h = hashlib.sha256()
+    for p in sorted(paths):
+        h.update(p.encode())
+        with open(p, 'rb') as f:
+            h.update(f.read())
+    h.update(' '.join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.hip'))
+
+
+def build(force=False, jobs=None, verbose=True):
+    srcs = sources()
+    hdrs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h'))
+    hdrs.append(os.path.join(HERE, '..', 'include', 'se_amd.h'))
+    stamp = os.path.join(OBJ, 'stamp')
+    dig = _digest(srcs + hdrs)
+    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == dig:
+        if verbose:
+            print('[build] libse_amd.so up to date')
+        return LIB
+    os.makedirs(OBJ, exist_ok=True)
+    cc = _hipcc()
+
+    def compile_one(src):
+        obj = os.path.join(OBJ, os.path.basename(src)[:-4] + '.o')
+        cmd = [cc] + FLAGS + ['-c', src, '-o', obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError('hipcc failed: ' + ' '.join(cmd) + '\n' + r.stdout + r.stderr)
+        return obj, r.stderr
+
+    jobs = jobs or min(len(srcs), os.cpu_count() or 4)
+    with concurrent.futures.ThreadPoolExecutor(jobs) as ex:
+        results = list(ex.map(compile_one, srcs))
+    for obj, err in results:
+        if verbose and err.strip():
+            print(err.strip())
+    objs = [o for o, _ in results]
+    cmd = [cc, '-shared', '-fPIC', f'--offload-arch={ARCH}', '-o', LIB] + objs
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError('link failed: ' + ' '.join(cmd) + '\n' + r.stdout + r.stderr)
+    with open(stamp, 'w') as f:
+        f.write(dig)
+    if verbose:
+        print(f'[build] built {LIB} from {len(srcs)} sources')
+    return LIB
+
+
+if __name__ == '__main__':
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--force', action='store_true')
+    ap.add_argument('--jobs', type=int, default=None)
+    a = ap.parse_args()
+    try:
+        build(force=a.force, jobs=a.jobs)
+    except RuntimeError as e:
+        print(e, file=sys.stderr)
+        sys.exit(1)

@@ -1,0 +1,125 @@
+// features.hip -- row A4: select_feat of S3PRL OnlinePreprocessor.forward: log(x+eps), stacked deltas
+// (5-tap [-2,-1,0,1,2]/10, replicate padding, delta-of-delta for delta=2), CMVN over time
+// (mean, UNBIASED std, +eps outside the sqrt), transposed to time-major (B, F, D*(1+delta)).
+//
+// Two HBM-bound passes:
+//   rows : one workgroup per (utterance, raw feature dim): the whole time row lives in LDS; log + deltas +
+//          exact two-pass mean / variance; derived rows written feature-major (coalesced along time)
+//   emit : one workgroup per (utterance, 32-frame tile): normalise + LDS transpose -> contiguous time-major rows
+#include "common.h"
+
+namespace se {
+
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void feat_rows_kernel(const float* __restrict__ raw, int raw_time_major, int D, int F,
+                                                        int apply_log, int delta, int cmvn, float eps,
+                                                        float* __restrict__ derived, float* __restrict__ stats) {
+  extern __shared__ __attribute__((aligned(16))) float rows[];   // (1+delta) x F
+  __shared__ float red[4];
+  const int b = blockIdx.y, d = blockIdx.x, tid = threadIdx.x;
+  const int Dout = D * (1 + delta);
+  for (int t = tid; t < F; t += 256) {
+    float v = raw_time_major ? raw[((size_t)b * F + t) * D + d] : raw[((size_t)b * D + d) * F + t];
+    if (apply_log) v = logf(v + eps);
+    rows[t] = v;
+  }
+  __syncthreads();
+  for (int j = 1; j <= delta; ++j) {
+    const float* src = rows + (size_t)(j - 1) * F;
+    float* dst = rows + (size_t)j * F;
+    for (int t = tid; t < F; t += 256) {
+      const float m2 = src[max(t - 2, 0)], m1 = src[max(t - 1, 0)], p1 = src[min(t + 1, F - 1)], p2 = src[min(t + 2, F - 1)];
+      // conv1d order of torchaudio compute_deltas: sum_k kernel[k] * x[t-2+k], kernel = [-2,-1,0,1,2], then / 10
+      dst[t] = (-2.f * m2 - m1 + p1 + 2.f * p2) / 10.f;
+    }
+    __syncthreads();
+  }
+  for (int j = 0; j <= delta; ++j) {
+    const float* src = rows + (size_t)j * F;
+    const int dd = j * D + d;
+    float* out = derived + ((size_t)b * Dout + dd) * F;
+    for (int t = tid; t < F; t += 256) out[t] = src[t];
+    if (cmvn) {
+      float s = 0.f;
+      for (int t = tid; t < F; t += 256) s += src[t];
+      const float mean = block_sum_256(s, red) / (float)F;
+      float q = 0.f;
+      for (int t = tid; t < F; t += 256) {
+        const float c = src[t] - mean;
+        q = fmaf(c, c, q);
+      }
+      const float var = block_sum_256(q, red) / (float)(F - 1);
+      if (tid == 0) {
+        stats[((size_t)b * Dout + dd) * 2 + 0] = mean;
+        stats[((size_t)b * Dout + dd) * 2 + 1] = sqrtf(var) + eps;
+      }
+    }
+  }
+}
+
+constexpr int kEmitT = 32;
+
+__global__ __launch_bounds__(256) void feat_emit_kernel(const float* __restrict__ derived, const float* __restrict__ stats,
+                                                        int Dout, int F, int cmvn, float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float tile[];   // kEmitT x (Dout+1)
+  const int b = blockIdx.y, t0 = blockIdx.x * kEmitT, tid = threadIdx.x;
+  const int nt = min(kEmitT, F - t0);
+  const int ld = Dout + 1;
+  for (int it = tid; it < Dout * kEmitT; it += 256) {
+    const int dd = it / kEmitT, tl = it - dd * kEmitT;
+    if (tl < nt) {
+      float v = derived[((size_t)b * Dout + dd) * F + t0 + tl];
+      if (cmvn) {
+        const float mean = stats[((size_t)b * Dout + dd) * 2], den = stats[((size_t)b * Dout + dd) * 2 + 1];
+        v = (v - mean) / den;
+      }
+      tile[tl * ld + dd] = v;
+    }
+  }
+  __syncthreads();
+  float* o = out + ((size_t)b * F + t0) * Dout;
+  for (int it = tid; it < nt * Dout; it += 256) {
+    const int tl = it / Dout, dd = it - tl * Dout;
+    o[it] = tile[tl * ld + dd];
+  }
+}
+
+}  // namespace se
+
+extern "C" size_t se_features_workspace_bytes(int B, int D, int F, int delta) {
+  const size_t Dout = (size_t)D * (1 + delta);
+  return ((size_t)B * Dout * F + (size_t)B * Dout * 2) * sizeof(float) + 256;
+}
+
+extern "C" int se_features_f32(const float* raw, int raw_time_major, int B, int D, int F,
+                               int apply_log, int delta, int cmvn, float eps,
+                               float* out, void* workspace, size_t workspace_bytes, void* stream) {
+  SE_REQUIRE(raw && out && workspace, "se_features_f32: null argument");
+  SE_REQUIRE(B > 0 && B <= 65535 && D > 0 && D <= 65535 && F >= 2 && delta >= 0 && delta <= 3, "se_features_f32: bad shape B=%d D=%d F=%d delta=%d", B, D, F, delta);
+  SE_REQUIRE(workspace_bytes >= se_features_workspace_bytes(B, D, F, delta), "se_features_f32: workspace too small");
+  const size_t rows_lds = (size_t)(1 + delta) * F * sizeof(float);
+  const int Dout = D * (1 + delta);
+  const size_t tile_lds = (size_t)se::kEmitT * (Dout + 1) * sizeof(float);
+  SE_REQUIRE(rows_lds <= 64 * 1024, "se_features_f32: F=%d too long for the LDS row buffer", F);
+  SE_REQUIRE(tile_lds <= 120 * 1024, "se_features_f32: D*(1+delta)=%d too wide for the LDS transpose tile", Dout);
+  float* derived = reinterpret_cast<float*>(workspace);
+  float* stats = derived + (size_t)B * Dout * F;
+  hipStream_t st = se::as_stream(stream);
+  hipLaunchKernelGGL(se::feat_rows_kernel, dim3(D, B), dim3(256), rows_lds, st, raw, raw_time_major, D, F, apply_log, delta,
+                     cmvn, eps, derived, stats);
+  SE_LAUNCH_CHECK();
+  if (tile_lds > 64 * 1024)
+    SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::feat_emit_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds));
+  hipLaunchKernelGGL(se::feat_emit_kernel, dim3((F + se::kEmitT - 1) / se::kEmitT, B), dim3(256), tile_lds, st, derived, stats,
+                     Dout, F, cmvn, out);
+  SE_LAUNCH_CHECK();
+  return SE_OK;
+}

@@ -1,0 +1,212 @@
+"""``OnlinePreprocessor`` -- drop-in for S3PRL ``utility.preprocessor.OnlinePreprocessor`` backed by the
+gfx950 kernels of libse_amd.so (rows A1-A6 of SURVEY.md section 8a).
+
+Surface kept (cited uses in the reference):
+  ctor(**config['online'], feat_list=None) tolerating extra keys   run_downstream.py:159, model.py:145
+  get_feat_config(feat_type, channel, log, delta, cmvn)            run_downstream.py:153-156, runner.py:50
+  __call__(wavs=None, feat_list=None) -> [ (B, T', D) ... ]        runner.py:433,558; sampler.py:60; model.py:146
+  istft(linears, phases) -> (B, T)                                 runner.py:267
+  _win_args['hop_length'], _sample_rate, _window                   runner.py:48,455; sampler.py:226
+  _stft(wav2d, window=) / _magphase(complx)                        sampler.py:226-228
+  .to() / .cpu() / deepcopy / pickle (spawned sampler child)       runner.py:65,70,232
+
+The compute path is HIP only: calling it with CPU tensors raises (no CPU fallback); construction and
+pickling work without a device, plans are created lazily on first use so a spawned child can pick its GPU
+first (sampler.py:145-153).
+"""
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+N_SAMPLED_PSEUDO_WAV = 2
+
+
+class OnlinePreprocessor(nn.Module):
+    _FEAT_TYPES = ('complx', 'linear', 'phase', 'mel', 'mfcc')
+
+    def __init__(self, sample_rate=16000, win_ms=25, hop_ms=10, n_freq=201, n_mels=40, n_mfcc=13, feat_list=None,
+                 eps=1e-10, **kwargs):
+        super().__init__()
+        self._sample_rate = sample_rate
+        self._win_ms, self._hop_ms = win_ms, hop_ms
+        self._n_freq, self._n_mels, self._n_mfcc = n_freq, n_mels, n_mfcc
+        win = round(win_ms * sample_rate / 1000)
+        hop = round(hop_ms * sample_rate / 1000)
+        n_fft = (n_freq - 1) * 2
+        self._win_args = {'n_fft': n_fft, 'hop_length': hop, 'win_length': win}
+        self.register_buffer('_window', torch.hann_window(win))
+        self.feat_list = feat_list
+        g = torch.Generator().manual_seed(0)
+        self.register_buffer('_pseudo_wavs', torch.randn(N_SAMPLED_PSEUDO_WAV, sample_rate, generator=g))
+        self.eps = eps
+        self._plans = {}          # device index -> se_plan* (not pickled / deep-copied)
+
+    # ---- plan management -------------------------------------------------------------------------
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state['_plans'] = {}
+        return state
+
+    def __deepcopy__(self, memo):
+        import copy
+        cls = self.__class__
+        new = cls.__new__(cls)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            new.__dict__[k] = {} if k == '_plans' else copy.deepcopy(v, memo)
+        return new
+
+    def __del__(self):
+        try:
+            lib = _lib._lib
+            if lib is not None:
+                for p in self._plans.values():
+                    lib.se_plan_destroy(p)
+        except Exception:
+            pass
+
+    def _plan(self, device):
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        plan = self._plans.get(idx)
+        if plan is None:
+            lib = _lib.load()
+            geom = _lib.Geometry(self._sample_rate, self._win_args['win_length'], self._win_args['hop_length'],
+                                 self._n_freq, self._n_mels)
+            out = _lib.c_void_p()
+            with torch.cuda.device(idx):
+                _lib.check(lib.se_plan_create(geom, out), 'se_plan_create')
+            plan = self._plans[idx] = out.value
+        return plan
+
+    # ---- S3PRL surface ---------------------------------------------------------------------------
+    @classmethod
+    def get_feat_config(cls, feat_type, channel=0, log=False, delta=0, cmvn=False):
+        assert feat_type in cls._FEAT_TYPES
+        assert type(channel) is int and type(log) is bool and type(delta) is int and type(cmvn) is bool
+        return {'feat_type': feat_type, 'channel': channel, 'log': log, 'delta': delta, 'cmvn': cmvn}
+
+    def _check_list(self, feat_list):
+        feat_list = self.feat_list if feat_list is None else feat_list
+        assert type(feat_list) is list
+        return feat_list
+
+    def _require_device(self, t):
+        if not t.is_cuda:
+            raise _lib.SEError('OnlinePreprocessor runs on MI355X only: move the module and its inputs to the GPU '
+                               '(.to("cuda")); the HIP path has no CPU fallback')
+
+    def _stft_channel(self, wavs, channel, need):
+        """One se_stft_f32 launch for `channel`; `need` is a set of {'linear','phase','complx','mel'}."""
+        lib = _lib.load()
+        B, C, T = wavs.shape
+        F = T // self._win_args['hop_length'] + 1
+        K = self._n_freq
+        dev = wavs.device
+        out = {}
+        if 'linear' in need:
+            out['linear'] = torch.empty(B, F, K, device=dev, dtype=torch.float32)
+        if 'phase' in need:
+            out['phase'] = torch.empty(B, F, K, device=dev, dtype=torch.float32)
+        if 'complx' in need:
+            out['complx'] = torch.empty(B, F, 2 * K, device=dev, dtype=torch.float32)
+        if 'mel' in need:
+            out['mel'] = torch.empty(B, self._n_mels, F, device=dev, dtype=torch.float32)
+        _lib.check(lib.se_stft_f32(self._plan(dev), _lib.ptr(wavs), B, C, T, channel, _lib.ptr(out.get('linear')),
+                                   _lib.ptr(out.get('phase')), _lib.ptr(out.get('complx')), _lib.ptr(out.get('mel')),
+                                   _lib.stream()), 'se_stft_f32')
+        return out
+
+    def _select(self, raw, raw_time_major, log, delta, cmvn):
+        """se_features_f32: raw (B, D, F) feature-major or (B, F, D) time-major -> (B, F, D*(1+delta))."""
+        lib = _lib.load()
+        if raw_time_major:
+            B, F, D = raw.shape
+        else:
+            B, D, F = raw.shape
+        out = torch.empty(B, F, D * (1 + delta), device=raw.device, dtype=torch.float32)
+        nbytes = lib.se_features_workspace_bytes(B, D, F, delta)
+        ws = torch.empty(nbytes, device=raw.device, dtype=torch.uint8)
+        _lib.check(lib.se_features_f32(_lib.ptr(raw), int(raw_time_major), B, D, F, int(bool(log)), int(delta),
+                                       int(bool(cmvn)), float(self.eps), _lib.ptr(out), _lib.ptr(ws), nbytes,
+                                       _lib.stream()), 'se_features_f32')
+        return out
+
+    def forward(self, wavs=None, feat_list=None):
+        # wavs: (batch_size, channel, max_len); returns [(batch, max_feat_len, feat_dim), ...]
+        feat_list = self._check_list(feat_list)
+        if wavs is None:
+            max_channel_id = max(int(a['channel']) if 'channel' in a else 0 for a in feat_list)
+            wavs = self._pseudo_wavs[0].view(1, 1, -1).repeat(1, max_channel_id + 1, 1)
+        assert wavs.dim() >= 3
+        self._require_device(wavs)
+        wavs = wavs.contiguous().float()
+        lead = wavs.shape[:-2]
+        wavs3 = wavs.reshape(-1, wavs.shape[-2], wavs.shape[-1])
+
+        # which raw planes does each channel need?  (the reference transforms every channel every step and
+        # also computes an unused MFCC -- row A5; here only requested channels / planes are produced)
+        need = {}
+        for a in feat_list:
+            ft = a['feat_type']
+            if ft == 'mfcc':
+                raise NotImplementedError("feat_type 'mfcc' is not on the reference's configured path (SURVEY A5)")
+            need.setdefault(int(a.get('channel', 0)), set()).add(ft)
+        planes = {ch: self._stft_channel(wavs3, ch, kinds) for ch, kinds in need.items()}
+
+        feats = []
+        for a in feat_list:
+            ft, ch = a['feat_type'], int(a.get('channel', 0))
+            log, delta, cmvn = bool(a.get('log', False)), int(a.get('delta', 0)), bool(a.get('cmvn', False))
+            raw = planes[ch][ft]
+            if ft == 'mel':
+                feat = self._select(raw, False, log, delta, cmvn)
+            elif log or delta or cmvn:
+                feat = self._select(raw, True, log, delta, cmvn)
+            else:
+                feat = raw
+            feats.append(feat.reshape(*lead, *feat.shape[-2:]))
+        return feats
+
+    def istft(self, linears=None, phases=None, linear_power=2, complxs=None):
+        # linears, phases: (*, max_feat_len, n_freq) -> (*, max_wav_len)
+        if complxs is not None:
+            raise NotImplementedError('istft(complxs=) is unused by the reference (runner.py:267 passes linears, phases)')
+        assert linears is not None and phases is not None
+        wav, _ = self.istft_with_sumsq(linears, phases, linear_power=linear_power)
+        return wav
+
+    def istft_with_sumsq(self, linears, phases, linear_power=2, lengths=None, out_len=None):
+        """se_istft_f32; with `lengths` also returns the masked sum of squares (fused, for the dB normalisation)."""
+        self._require_device(linears)
+        lib = _lib.load()
+        lead = linears.shape[:-2]
+        F, K = linears.shape[-2:]
+        lin = linears.contiguous().float().reshape(-1, F, K)
+        ph = phases.contiguous().float().reshape(-1, F, K)
+        B = lin.shape[0]
+        n_out = self._win_args['hop_length'] * (F - 1)
+        stride = n_out if out_len is None else max(int(out_len), n_out)
+        wav = torch.empty(B, stride, device=lin.device, dtype=torch.float32)
+        sumsq = None
+        if lengths is not None:
+            lengths = lengths.to(device=lin.device, dtype=torch.int64).contiguous()
+            sumsq = torch.empty(B, device=lin.device, dtype=torch.float32)
+        _lib.check(lib.se_istft_f32(self._plan(lin.device), _lib.ptr(lin), _lib.ptr(ph), B, F, float(linear_power),
+                                    _lib.ptr(wav), stride, _lib.ptr(lengths), _lib.ptr(sumsq), _lib.stream()), 'se_istft_f32')
+        return wav.reshape(*lead, stride), sumsq
+
+    # ---- attributes used by sampler.hist_scoring (sampler.py:226-228) -----------------------------------
+    def _stft(self, wav2d, window=None):
+        """(N, T) -> (N, K, F, 2) real view, the torch<=1.6 torch.stft layout S3PRL exposed."""
+        self._require_device(wav2d)
+        out = self._stft_channel(wav2d.contiguous().float().unsqueeze(1), 0, {'complx'})['complx']   # (N, F, 2K)
+        N, F, _ = out.shape
+        return out.view(N, F, self._n_freq, 2).permute(0, 2, 1, 3).contiguous()
+
+    @staticmethod
+    def _magphase(complx, power=2.0):
+        """torchaudio.functional.magphase(power=2) on the (…, 2) real view: thin torch elementwise (not on the hot path)."""
+        mag = complx.pow(2).sum(-1).pow(power / 2.0)
+        phase = torch.atan2(complx[..., 1], complx[..., 0])
+        return mag, phase

@@ -1,0 +1,125 @@
+"""GPU parity: rows A1-A6 (STFT / power+phase / mel / select_feat / iSTFT) -- HIP path vs the CPU oracle,
+called through the C ABI (ctypes) via the OnlinePreprocessor drop-in.
+
+Tolerances (north_star: 1e-4 relative on magnitudes): power and waveform are compared norm-wise per
+utterance, max|a-b| <= 1e-4 * max|b| (a per-bin relative bound is meaningless for bins 60 dB below the
+peak even between two fp32 FFT libraries); phase is compared through the complex value it reconstructs."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle import preprocessor as opre
+
+pytestmark = pytest.mark.gpu
+
+GEOM = opre.Geometry()
+FEAT_LIST = None
+
+
+def _feat_list(P):
+    return [
+        {'feat_type': 'mel', 'channel': 0, 'log': True, 'delta': 1, 'cmvn': True},      # pretrain_sample.yaml:54-59
+        {'feat_type': 'mel', 'channel': 0, 'log': True, 'delta': 2, 'cmvn': False},     # pseudo_noise.yaml:11-15
+        P.get_feat_config('linear', 0), P.get_feat_config('phase', 0),
+        P.get_feat_config('linear', 1), P.get_feat_config('phase', 1),
+    ]
+
+
+def _relmax(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).abs().flatten(1).max(dim=1).values / b.abs().flatten(1).max(dim=1).values).max().item()
+
+
+@pytest.fixture(scope='module')
+def P(gpu):
+    from speech_enhancement_by_s3prl_amd.preprocessor import OnlinePreprocessor
+    p = OnlinePreprocessor(sample_rate=16000, win_ms=25, hop_ms=10, n_freq=201, n_mels=40, n_mfcc=13,
+                           roots=['x'], max_time=10000, target_level=-25, noise_proportion=0.5, snrs=[3, 6])
+    p.feat_list = _feat_list(p)
+    return p.to(gpu)
+
+
+@pytest.mark.parametrize('T', [16000, 160000, 8123, 401])
+def test_stft_features_vs_oracle(P, gpu, T):
+    from speech_enhancement_by_s3prl_amd import synth
+    torch.manual_seed(T)
+    if T == 160000:
+        _, wavs = synth.synth_batch(2, T)
+    else:
+        wavs = torch.randn(3, 3, T) * 0.1
+    feats = P(wavs.to(gpu))
+    ref = opre.forward(wavs, _feat_list(P), GEOM)
+    F = T // 160 + 1
+    assert [tuple(f.shape) for f in feats] == [tuple(r.shape) for r in ref]
+    assert feats[2].shape == (wavs.shape[0], F, 201)
+    # power (A1+A2)
+    assert _relmax(feats[2], ref[2]) < 1e-4
+    assert _relmax(feats[4], ref[4]) < 1e-4
+    # phase through the complex value: sqrt(P) e^{i phi}
+    for lin, ph, rlin, rph in ((feats[2], feats[3], ref[2], ref[3]), (feats[4], feats[5], ref[4], ref[5])):
+        z = torch.polar(lin.cpu().double().sqrt(), ph.cpu().double())
+        rz = torch.polar(rlin.double().sqrt(), rph.double())
+        assert ((z - rz).abs().flatten(1).max(dim=1).values / rz.abs().flatten(1).max(dim=1).values).max().item() < 1e-4
+    # log-mel + deltas (A3+A4): absolute tolerance on log values (log of a sum of >= 2 power bins)
+    assert (feats[1].cpu() - ref[1]).abs().max().item() < 2e-3
+    # CMVN'd features: unit-variance scale
+    assert (feats[0].cpu() - ref[0]).abs().max().item() < 5e-3
+    assert torch.isfinite(feats[0]).all()
+
+
+def test_stft_vs_float64_dft(P, gpu):
+    """second opinion: independent float64 DFT-matrix STFT (oracle/dft64.py)"""
+    torch.manual_seed(5)
+    wav = torch.randn(1, 1, 4000) * 0.3
+    lin, = P(wav.to(gpu), [P.get_feat_config('linear', 0)])
+    spec = oracle.dft64.stft64(wav[0, 0].numpy())
+    ref = torch.from_numpy(np.abs(spec) ** 2).T
+    assert _relmax(lin.cpu()[0:1], ref[None]) < 1e-5
+
+
+def test_pure_tone_known_answer(P, gpu):
+    """first-principles: a tone at bin k concentrates power at k (Hann main lobe k-1..k+1)."""
+    k = 37
+    t = torch.arange(16000, dtype=torch.float64)
+    wav = torch.cos(2 * np.pi * k * t / 400.0).float().view(1, 1, -1)
+    lin, = P(wav.to(gpu), [P.get_feat_config('linear', 0)])
+    mid = lin[0, 10:90].cpu()
+    assert (mid.argmax(dim=-1) == k).all()
+    # periodic Hann: |X[k]| = N/4 * 2 = sum(w)/2 = 100 -> power 1e4
+    assert torch.allclose(mid[:, k], torch.full_like(mid[:, k], 1.0e4), rtol=1e-4)
+    outside = torch.cat([mid[:, :k - 2], mid[:, k + 3:]], dim=1)
+    assert outside.max().item() < 1e-3
+
+
+@pytest.mark.parametrize('T', [16000, 160000, 4640 * 3, 480])
+def test_istft_roundtrip_and_oracle(P, gpu, T):
+    torch.manual_seed(T + 1)
+    wavs = torch.randn(2, 1, T) * 0.1
+    lin, ph = P(wavs.to(gpu), [P.get_feat_config('linear', 0), P.get_feat_config('phase', 0)])
+    wav = P.istft(lin, ph)
+    n_out = 160 * (T // 160)
+    assert wav.shape == (2, n_out)
+    assert _relmax(wav.cpu(), wavs[:, 0, :n_out]) < 1e-4            # iSTFT(STFT(x)) = x
+    # vs oracle on a MODIFIED spectrum (mask), the enhancement use case
+    mask = torch.rand(2, lin.shape[1], 201)
+    ref = opre.istft(lin.cpu() * mask, ph.cpu(), GEOM)
+    got = P.istft(lin * mask.to(gpu), ph)
+    assert _relmax(got.cpu(), ref) < 1e-4
+
+
+def test_zero_arg_dim_discovery(P):
+    """run_downstream.py:163-164: preprocessor() on the internal pseudo wav returns the six features."""
+    feats = P()
+    assert [f.shape[-1] for f in feats] == [80, 120, 201, 201, 201, 201]
+    assert feats[0].shape[:2] == (1, 101)
+
+
+def test_stft_attr_surface(P, gpu):
+    """sampler.py:226-228: _stft(wav2d, window=) -> (..., K, F, 2), _magphase -> (power, phase)."""
+    wav = torch.randn(2, 3200, device=gpu)
+    c = P._stft(wav, window=P._window)
+    assert c.shape == (2, 201, 21, 2)
+    lin, ph = P._magphase(c)
+    ref = opre.magphase(opre.stft(wav.cpu(), GEOM))
+    assert _relmax(lin.cpu().transpose(1, 2), ref[0].transpose(1, 2)) < 1e-4
