@@ -234,6 +234,15 @@ int se_layernorm_f32(const float* x, const float* w, const float* b, int M, int 
                      float* out_f32, uint16_t* out_bf16, void* stream);
 int se_cast_f32_bf16(const float* x, size_t n, uint16_t* out, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Optional in-library timing for bench.py's roofline leg: HIP events recorded on the launch stream around
+ * every kernel of a family while enabled.  kind: 0 = bf16 GEMM (work = 2MNK flop), 1 = MHSA (4 B h T^2 64 flop),
+ * 2 = STFT, 3 = iSTFT (work = algorithmic bytes).  se_prof_read synchronises on the recorded events.
+ * ---------------------------------------------------------------------------------------------- */
+int se_prof_enable(int on);
+int se_prof_reset(void);
+int se_prof_read(int kind, double* total_ms, double* total_work, long long* launches);
+
 #ifdef __cplusplus
 }
 #endif

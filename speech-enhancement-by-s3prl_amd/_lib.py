@@ -71,6 +71,9 @@ SIGNATURES = {
     'se_mhsa_fwd_bf16': (c_int, [_P, _P, c_int, c_int, c_int, _P, _P]),
     'se_layernorm_f32': (c_int, [_P, _P, _P, c_int, c_int, c_float, _P, _P, _P]),
     'se_cast_f32_bf16': (c_int, [_P, c_size_t, _P, _P]),
+    'se_prof_enable': (c_int, [c_int]),
+    'se_prof_reset': (c_int, []),
+    'se_prof_read': (c_int, [c_int, POINTER(c_double), POINTER(c_double), POINTER(ctypes.c_longlong)]),
 }
 
 _lib = None

@@ -1,0 +1,454 @@
+// encoder.hip -- rows B1-B4 + C3: the S3PRL TRANSFORMER encoder (BERT layout) and TransformerSpecPredictionHead
+// orchestrated over the bf16 MFMA GEMM (gemm.hip), the flash MHSA kernel (mhsa.hip) and the fused
+// row kernels below.  GEMM operands are bf16, accumulation / residual stream / LayerNorm / softmax are fp32.
+//
+// Per layer (M = B*T rows, H = 768):
+//   qkv  = x_bf16 Wqkv^T + b           (M, 3H) bf16        one fused 768 -> 2304 GEMM
+//   ctx  = MHSA(qkv)                   (M, H)  bf16
+//   a    = ctx Wo^T + b + x_f32        (M, H)  fp32        residual fused in the GEMM epilogue
+//   x    = LayerNorm(a)                fp32 + bf16 copies  (TF style, eps inside the sqrt)
+//   h    = gelu(x_bf16 W1^T + b)       (M, 4H) bf16        GELU(erf) fused in the GEMM epilogue
+//   o    = h W2^T + b + x_f32          (M, H)  fp32
+//   x    = LayerNorm(o)
+#include <math.h>
+#include <vector>
+#include "common.h"
+#include "bf16.h"
+
+namespace se {
+
+constexpr int kMaxPos = 5008;     // 50 s of 10 ms frames (MAX_POSITIONS_LEN = 16000*50 samples, runner.py:32)
+constexpr int kInPad = 128;       // input feature dim padded to a multiple of the GEMM K tile
+
+// one wave per row; H = 64 * 4 * NV
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ pe, int T,
+                                                        const float* __restrict__ w, const float* __restrict__ b, int M, float eps,
+                                                        float* __restrict__ out_f32, uint16_t* __restrict__ out_bf16) {
+  constexpr int H = 256 * NV;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float* xr = x + (size_t)row * H;
+  float4 v[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const float4*>(xr + (i * 64 + lane) * 4);
+  if (pe) {
+    const float* pr = pe + (size_t)(row % T) * H;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const float4 p = *reinterpret_cast<const float4*>(pr + (i * 64 + lane) * 4);
+      v[i].x += p.x; v[i].y += p.y; v[i].z += p.z; v[i].w += p.w;
+    }
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  const float mean = s * (1.0f / H);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+    q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off);
+  const float rstd = 1.0f / sqrtf(q * (1.0f / H) + eps);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    const float4 ww = *reinterpret_cast<const float4*>(w + c), bb = *reinterpret_cast<const float4*>(b + c);
+    float4 y;
+    y.x = ww.x * (v[i].x * rstd) + bb.x; y.y = ww.y * (v[i].y * rstd) + bb.y;
+    y.z = ww.z * (v[i].z * rstd) + bb.z; y.w = ww.w * (v[i].w * rstd) + bb.w;
+    if (out_f32) *reinterpret_cast<float4*>(out_f32 + (size_t)row * H + c) = y;
+    if (out_bf16) *reinterpret_cast<uint2*>(out_bf16 + (size_t)row * H + c) = make_uint2(pack_bf16x2(y.x, y.y), pack_bf16x2(y.z, y.w));
+  }
+}
+
+// generic-H fallback: one workgroup (256 threads) per row
+__global__ __launch_bounds__(256) void layernorm_generic_kernel(const float* __restrict__ x, const float* __restrict__ pe, int T,
+                                                                const float* __restrict__ w, const float* __restrict__ b, int H, float eps,
+                                                                float* __restrict__ out_f32, uint16_t* __restrict__ out_bf16) {
+  __shared__ float red[4];
+  const int row = blockIdx.x, tid = threadIdx.x;
+  const float* xr = x + (size_t)row * H;
+  const float* pr = pe ? pe + (size_t)(row % T) * H : nullptr;
+  float s = 0.f;
+  for (int c = tid; c < H; c += 256) s += xr[c] + (pr ? pr[c] : 0.f);
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+  if ((tid & 63) == 0) red[tid >> 6] = s;
+  __syncthreads();
+  const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)H;
+  __syncthreads();
+  float q = 0.f;
+  for (int c = tid; c < H; c += 256) {
+    const float d = xr[c] + (pr ? pr[c] : 0.f) - mean;
+    q += d * d;
+  }
+  for (int off = 32; off > 0; off >>= 1) q += __shfl_down(q, off);
+  if ((tid & 63) == 0) red[tid >> 6] = q;
+  __syncthreads();
+  const float rstd = 1.0f / sqrtf((red[0] + red[1] + red[2] + red[3]) / (float)H + eps);
+  for (int c = tid; c < H; c += 256) {
+    const float y = w[c] * ((xr[c] + (pr ? pr[c] : 0.f) - mean) * rstd) + b[c];
+    if (out_f32) out_f32[(size_t)row * H + c] = y;
+    if (out_bf16) out_bf16[(size_t)row * H + c] = f2bf(y);
+  }
+}
+
+// fp32 (rows, cols) -> bf16 (rows, ld_out) zero-padded; 4 elements per thread
+__global__ __launch_bounds__(256) void cast_pad_kernel(const float* __restrict__ x, size_t rows, int cols, int ld_out,
+                                                       uint16_t* __restrict__ out) {
+  const size_t n4 = rows * (size_t)(ld_out / 4);
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const size_t r = i / (ld_out / 4);
+    const int c = (int)(i - r * (ld_out / 4)) * 4;
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+    const float* xr = x + r * cols;
+    if (c + 3 < cols && (cols % 4 == 0)) {
+      const float4 t = *reinterpret_cast<const float4*>(xr + c);
+      v0 = t.x; v1 = t.y; v2 = t.z; v3 = t.w;
+    } else {
+      if (c < cols) v0 = xr[c];
+      if (c + 1 < cols) v1 = xr[c + 1];
+      if (c + 2 < cols) v2 = xr[c + 2];
+      if (c + 3 < cols) v3 = xr[c + 3];
+    }
+    *reinterpret_cast<uint2*>(out + r * ld_out + c) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+  }
+}
+
+// lengths[b] = #frames whose feature sum != 0 (S3PRL process_input_data)
+__global__ __launch_bounds__(256) void valid_lengths_kernel(const float* __restrict__ feats, int T, int D, int32_t* __restrict__ lengths) {
+  __shared__ int red[4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  int cnt = 0;
+  for (int t = tid; t < T; t += 256) {
+    const float* fr = feats + ((size_t)b * T + t) * D;
+    float s = 0.f;
+    for (int d = 0; d < D; ++d) s += fr[d];
+    cnt += (s != 0.f) ? 1 : 0;
+  }
+  for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off);
+  if ((tid & 63) == 0) red[tid >> 6] = cnt;
+  __syncthreads();
+  if (tid == 0) lengths[b] = red[0] + red[1] + red[2] + red[3];
+}
+
+// SpecHead.forward epilogue (model.py:121-125)
+__global__ __launch_bounds__(256) void spec_epilogue_kernel(const float* __restrict__ p, size_t n, int log_target, int act, float eps,
+                                                            float* __restrict__ predicted, float* __restrict__ log_predicted) {
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float v = p[i];
+    float pred, lp;
+    if (log_target) {
+      pred = expf(v);
+      lp = v;
+    } else {
+      pred = v;
+      lp = logf(v + eps);
+    }
+    if (act == SE_ACT_RELU) pred = fmaxf(pred, 0.f);
+    else if (act == SE_ACT_SIGMOID) pred = 1.f / (1.f + expf(-pred));
+    if (predicted) predicted[i] = pred;
+    if (log_predicted) log_predicted[i] = lp;
+  }
+}
+
+}  // namespace se
+
+struct se_encoder {
+  se_encoder_config cfg;
+  void* blob;          // one device allocation
+  size_t blob_bytes;
+  // device views
+  uint16_t* in_w;      // (H, kInPad) bf16
+  float *in_b, *in_ln_w, *in_ln_b, *pe;
+  struct Layer {
+    uint16_t *qkv_w, *ao_w, *ff1_w, *ff2_w;
+    float *qkv_b, *ao_b, *aln_w, *aln_b, *ff1_b, *ff2_b, *oln_w, *oln_b;
+  };
+  std::vector<Layer> layers;
+  uint16_t *sh_dense_w, *sh_out_w;
+  float *sh_dense_b, *sh_ln_w, *sh_ln_b, *sh_out_b;
+};
+
+static inline uint16_t host_f2bf(float f) {   // round to nearest even, NaN kept quiet
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+  return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+static int launch_layernorm(const float* x, const float* pe, int T, const float* w, const float* b, int M, int H, float eps,
+                            float* out_f32, uint16_t* out_bf16, hipStream_t st) {
+  if (H == 768) {
+    hipLaunchKernelGGL((se::layernorm_kernel<3>), dim3((M + 3) / 4), dim3(256), 0, st, x, pe, T, w, b, M, eps, out_f32, out_bf16);
+  } else if (H == 256) {
+    hipLaunchKernelGGL((se::layernorm_kernel<1>), dim3((M + 3) / 4), dim3(256), 0, st, x, pe, T, w, b, M, eps, out_f32, out_bf16);
+  } else if (H == 512) {
+    hipLaunchKernelGGL((se::layernorm_kernel<2>), dim3((M + 3) / 4), dim3(256), 0, st, x, pe, T, w, b, M, eps, out_f32, out_bf16);
+  } else if (H == 1024) {
+    hipLaunchKernelGGL((se::layernorm_kernel<4>), dim3((M + 3) / 4), dim3(256), 0, st, x, pe, T, w, b, M, eps, out_f32, out_bf16);
+  } else {
+    hipLaunchKernelGGL(se::layernorm_generic_kernel, dim3(M), dim3(256), 0, st, x, pe, T, w, b, H, eps, out_f32, out_bf16);
+  }
+  SE_LAUNCH_CHECK();
+  return SE_OK;
+}
+
+extern "C" int se_layernorm_f32(const float* x, const float* w, const float* b, int M, int H, float eps,
+                                float* out_f32, uint16_t* out_bf16, void* stream) {
+  SE_REQUIRE(x && w && b && (out_f32 || out_bf16) && M > 0 && H > 0, "se_layernorm_f32: bad argument");
+  return launch_layernorm(x, nullptr, 1, w, b, M, H, eps, out_f32, out_bf16, se::as_stream(stream));
+}
+
+extern "C" int se_cast_f32_bf16(const float* x, size_t n, uint16_t* out, void* stream) {
+  SE_REQUIRE(x && out && n > 0 && n % 4 == 0, "se_cast_f32_bf16: n must be a positive multiple of 4");
+  const size_t rows = n / 4;
+  const int grid = (int)std::min<size_t>((rows + 255) / 256, 4096);
+  hipLaunchKernelGGL(se::cast_pad_kernel, dim3(grid), dim3(256), 0, se::as_stream(stream), x, rows, 4, 4, out);
+  SE_LAUNCH_CHECK();
+  return SE_OK;
+}
+
+extern "C" int se_valid_lengths_i32(const float* feats, int B, int T, int D, int32_t* lengths, void* stream) {
+  SE_REQUIRE(feats && lengths && B > 0 && T > 0 && D > 0, "se_valid_lengths_i32: bad argument");
+  hipLaunchKernelGGL(se::valid_lengths_kernel, dim3(B), dim3(256), 0, se::as_stream(stream), feats, T, D, lengths);
+  SE_LAUNCH_CHECK();
+  return SE_OK;
+}
+
+extern "C" int se_encoder_create(const se_encoder_config* cfg, const se_encoder_weights* w, se_encoder** out) {
+  SE_REQUIRE(cfg && w && out, "se_encoder_create: null argument");
+  const int H = cfg->hidden, I = cfg->intermediate, L = cfg->layers, D = cfg->input_dim;
+  if (cfg->heads <= 0 || H != cfg->heads * 64 || H % 64 != 0 || I % 64 != 0 || D <= 0 || D > se::kInPad || L <= 0) {
+    se::set_error("se_encoder_create: unsupported config (hidden=%d heads=%d intermediate=%d input_dim=%d): head dim must be 64, "
+                  "hidden/intermediate multiples of 64, input_dim <= %d", H, cfg->heads, I, D, se::kInPad);
+    return SE_ERR_UNSUPPORTED;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    (void)hipGetLastError();
+    se::set_error("se_encoder_create: no HIP device visible (no CPU fallback)");
+    return SE_ERR_NO_DEVICE;
+  }
+  const bool has_head = cfg->spec_out > 0 && w->sh_dense_w;
+  // ---- host staging blob
+  std::vector<char> host;
+  auto reserve = [&](size_t bytes) {
+    const size_t off = (host.size() + 255) & ~(size_t)255;
+    host.resize(off + bytes, 0);
+    return off;
+  };
+  auto put_f32 = [&](const float* src, size_t n) {
+    const size_t off = reserve(n * 4);
+    memcpy(host.data() + off, src, n * 4);
+    return off;
+  };
+  auto put_bf16 = [&](const float* src, int rows, int cols, int ld) {   // (rows, cols) fp32 -> (rows, ld) bf16 zero padded
+    const size_t off = reserve((size_t)rows * ld * 2);
+    uint16_t* d = reinterpret_cast<uint16_t*>(host.data() + off);
+    for (int r = 0; r < rows; ++r)
+      for (int c = 0; c < cols; ++c) d[(size_t)r * ld + c] = host_f2bf(src[(size_t)r * cols + c]);
+    return off;
+  };
+  struct Off { size_t in_w, in_b, in_ln_w, in_ln_b, pe; std::vector<std::vector<size_t>> l; size_t shd_w, shd_b, shl_w, shl_b, sho_w, sho_b; } o;
+  o.in_w = put_bf16(w->in_w, H, D, se::kInPad);
+  o.in_b = put_f32(w->in_b, H);
+  o.in_ln_w = put_f32(w->in_ln_w, H);
+  o.in_ln_b = put_f32(w->in_ln_b, H);
+  {
+    o.pe = reserve((size_t)se::kMaxPos * H * 4);
+    float* pe = reinterpret_cast<float*>(host.data() + o.pe);
+    for (int pos = 0; pos < se::kMaxPos; ++pos)
+      for (int j = 0; j < H; ++j) {
+        const double ang = (double)pos / pow(10000.0, 2.0 * (double)(j / 2) / (double)H);
+        pe[(size_t)pos * H + j] = (float)((j & 1) ? cos(ang) : sin(ang));
+      }
+  }
+  for (int i = 0; i < L; ++i) {
+    std::vector<size_t> lo;
+    // fused QKV weight (3H, H) and bias (3H)
+    {
+      const size_t off = reserve((size_t)3 * H * H * 2);
+      uint16_t* d = reinterpret_cast<uint16_t*>(host.data() + off);
+      const float* srcs[3] = {w->q_w[i], w->k_w[i], w->v_w[i]};
+      for (int p = 0; p < 3; ++p)
+        for (size_t e = 0; e < (size_t)H * H; ++e) d[(size_t)p * H * H + e] = host_f2bf(srcs[p][e]);
+      lo.push_back(off);
+      const size_t boff = reserve((size_t)3 * H * 4);
+      float* bd = reinterpret_cast<float*>(host.data() + boff);
+      memcpy(bd, w->q_b[i], H * 4);
+      memcpy(bd + H, w->k_b[i], H * 4);
+      memcpy(bd + 2 * H, w->v_b[i], H * 4);
+      lo.push_back(boff);
+    }
+    lo.push_back(put_bf16(w->ao_w[i], H, H, H));
+    lo.push_back(put_f32(w->ao_b[i], H));
+    lo.push_back(put_f32(w->aln_w[i], H));
+    lo.push_back(put_f32(w->aln_b[i], H));
+    lo.push_back(put_bf16(w->ff1_w[i], I, H, H));
+    lo.push_back(put_f32(w->ff1_b[i], I));
+    lo.push_back(put_bf16(w->ff2_w[i], H, I, I));
+    lo.push_back(put_f32(w->ff2_b[i], H));
+    lo.push_back(put_f32(w->oln_w[i], H));
+    lo.push_back(put_f32(w->oln_b[i], H));
+    o.l.push_back(lo);
+  }
+  if (has_head) {
+    o.shd_w = put_bf16(w->sh_dense_w, H, H, H);
+    o.shd_b = put_f32(w->sh_dense_b, H);
+    o.shl_w = put_f32(w->sh_ln_w, H);
+    o.shl_b = put_f32(w->sh_ln_b, H);
+    o.sho_w = put_bf16(w->sh_out_w, cfg->spec_out, H, H);
+    o.sho_b = put_f32(w->sh_out_b, cfg->spec_out);
+  }
+  se_encoder* e = new se_encoder();
+  e->cfg = *cfg;
+  if (!has_head) e->cfg.spec_out = 0;
+  e->blob_bytes = host.size() + 256;
+  hipError_t err = hipMalloc(&e->blob, e->blob_bytes);
+  if (err != hipSuccess) {
+    delete e;
+    return se::hip_fail(err, "hipMalloc(encoder weights)", __FILE__, __LINE__);
+  }
+  err = hipMemcpy(e->blob, host.data(), host.size(), hipMemcpyHostToDevice);
+  if (err != hipSuccess) {
+    (void)hipFree(e->blob);
+    delete e;
+    return se::hip_fail(err, "hipMemcpy(encoder weights)", __FILE__, __LINE__);
+  }
+  char* base = reinterpret_cast<char*>(e->blob);
+  e->in_w = (uint16_t*)(base + o.in_w);
+  e->in_b = (float*)(base + o.in_b);
+  e->in_ln_w = (float*)(base + o.in_ln_w);
+  e->in_ln_b = (float*)(base + o.in_ln_b);
+  e->pe = (float*)(base + o.pe);
+  for (int i = 0; i < L; ++i) {
+    const auto& lo = o.l[i];
+    se_encoder::Layer y;
+    y.qkv_w = (uint16_t*)(base + lo[0]); y.qkv_b = (float*)(base + lo[1]);
+    y.ao_w = (uint16_t*)(base + lo[2]); y.ao_b = (float*)(base + lo[3]);
+    y.aln_w = (float*)(base + lo[4]); y.aln_b = (float*)(base + lo[5]);
+    y.ff1_w = (uint16_t*)(base + lo[6]); y.ff1_b = (float*)(base + lo[7]);
+    y.ff2_w = (uint16_t*)(base + lo[8]); y.ff2_b = (float*)(base + lo[9]);
+    y.oln_w = (float*)(base + lo[10]); y.oln_b = (float*)(base + lo[11]);
+    e->layers.push_back(y);
+  }
+  if (has_head) {
+    e->sh_dense_w = (uint16_t*)(base + o.shd_w); e->sh_dense_b = (float*)(base + o.shd_b);
+    e->sh_ln_w = (float*)(base + o.shl_w); e->sh_ln_b = (float*)(base + o.shl_b);
+    e->sh_out_w = (uint16_t*)(base + o.sho_w); e->sh_out_b = (float*)(base + o.sho_b);
+  }
+  *out = e;
+  return SE_OK;
+}
+
+extern "C" void se_encoder_destroy(se_encoder* enc) {
+  if (!enc) return;
+  if (enc->blob) (void)hipFree(enc->blob);
+  delete enc;
+}
+
+namespace {
+struct Ws {
+  uint16_t *xin, *x_bf, *qkv, *ctx, *h;
+  float *x_f32, *tmp;
+  size_t total;
+};
+inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+Ws carve(const se_encoder* e, size_t M, char* base) {
+  const size_t H = e->cfg.hidden, I = e->cfg.intermediate;
+  Ws w;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += al256(bytes); return p; };
+  w.xin = (uint16_t*)take(M * se::kInPad * 2);
+  w.x_bf = (uint16_t*)take(M * H * 2);
+  w.x_f32 = (float*)take(M * H * 4);
+  w.tmp = (float*)take(M * H * 4);
+  w.qkv = (uint16_t*)take(M * 3 * H * 2);
+  w.ctx = (uint16_t*)take(M * H * 2);
+  w.h = (uint16_t*)take(M * I * 2);
+  w.total = off;
+  return w;
+}
+}  // namespace
+
+extern "C" size_t se_encoder_workspace_bytes(const se_encoder* enc, int B, int T) {
+  if (!enc || B <= 0 || T <= 0) return 0;
+  return carve(enc, (size_t)B * T, nullptr).total + 256;
+}
+
+extern "C" int se_encoder_fwd_bf16(const se_encoder* enc, const float* feats, const int32_t* lengths, int B, int T,
+                                   float* hidden, void* workspace, size_t workspace_bytes, void* stream) {
+  SE_REQUIRE(enc && feats && hidden && workspace, "se_encoder_fwd_bf16: null argument");
+  SE_REQUIRE(B > 0 && B <= 65535 && T > 0 && T <= se::kMaxPos, "se_encoder_fwd_bf16: bad shape B=%d T=%d (T <= %d)", B, T, se::kMaxPos);
+  SE_REQUIRE(workspace_bytes >= se_encoder_workspace_bytes(enc, B, T), "se_encoder_fwd_bf16: workspace too small");
+  SE_REQUIRE((uintptr_t)workspace % 256 == 0 && (uintptr_t)hidden % 16 == 0, "se_encoder_fwd_bf16: workspace must be 256-B aligned");
+  const int H = enc->cfg.hidden, I = enc->cfg.intermediate, D = enc->cfg.input_dim;
+  const size_t Mz = (size_t)B * T;
+  SE_REQUIRE(Mz <= 0x7fffffff / 4, "se_encoder_fwd_bf16: B*T too large");
+  const int M = (int)Mz;
+  hipStream_t st = se::as_stream(stream);
+  Ws w = carve(enc, Mz, reinterpret_cast<char*>(workspace));
+  int rc;
+  // B1: input projection + positional encoding + LayerNorm
+  {
+    const int grid = (int)std::min<size_t>((Mz * (se::kInPad / 4) + 255) / 256, 8192);
+    hipLaunchKernelGGL(se::cast_pad_kernel, dim3(grid), dim3(256), 0, st, feats, Mz, D, se::kInPad, w.xin);
+    SE_LAUNCH_CHECK();
+  }
+  if ((rc = se_gemm_bf16(w.xin, se::kInPad, enc->in_w, se::kInPad, enc->in_b, nullptr, M, H, se::kInPad, SE_ACT_IDENTITY, nullptr, w.tmp, H, stream))) return rc;
+  if ((rc = launch_layernorm(w.tmp, enc->pe, T, enc->in_ln_w, enc->in_ln_b, M, H, enc->cfg.ln_eps, w.x_f32, w.x_bf, st))) return rc;
+  const int L = enc->cfg.layers;
+  for (int i = 0; i < L; ++i) {
+    const se_encoder::Layer& y = enc->layers[i];
+    // B2
+    if ((rc = se_gemm_bf16(w.x_bf, H, y.qkv_w, H, y.qkv_b, nullptr, M, 3 * H, H, SE_ACT_IDENTITY, w.qkv, nullptr, 3 * H, stream))) return rc;
+    if ((rc = se_mhsa_fwd_bf16(w.qkv, lengths, B, T, enc->cfg.heads, w.ctx, stream))) return rc;
+    if ((rc = se_gemm_bf16(w.ctx, H, y.ao_w, H, y.ao_b, w.x_f32, M, H, H, SE_ACT_IDENTITY, nullptr, w.tmp, H, stream))) return rc;
+    if ((rc = launch_layernorm(w.tmp, nullptr, 1, y.aln_w, y.aln_b, M, H, enc->cfg.ln_eps, w.x_f32, w.x_bf, st))) return rc;
+    // B3
+    if ((rc = se_gemm_bf16(w.x_bf, H, y.ff1_w, H, y.ff1_b, nullptr, M, I, H, SE_ACT_GELU, w.h, nullptr, I, stream))) return rc;
+    if ((rc = se_gemm_bf16(w.h, I, y.ff2_w, I, y.ff2_b, w.x_f32, M, H, I, SE_ACT_IDENTITY, nullptr, w.tmp, H, stream))) return rc;
+    float* xo = (i == L - 1) ? hidden : w.x_f32;
+    if ((rc = launch_layernorm(w.tmp, nullptr, 1, y.oln_w, y.oln_b, M, H, enc->cfg.ln_eps, xo, (i == L - 1) ? nullptr : w.x_bf, st))) return rc;
+  }
+  return SE_OK;
+}
+
+extern "C" int se_spechead_fwd_bf16(const se_encoder* enc, const float* hidden, int B, int T, int log_target, int act, float eps,
+                                    float* predicted, float* log_predicted, float* raw,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+  SE_REQUIRE(enc && hidden && workspace && (predicted || log_predicted || raw), "se_spechead_fwd_bf16: null argument");
+  SE_REQUIRE(enc->cfg.spec_out > 0, "se_spechead_fwd_bf16: encoder was created without a spec head");
+  SE_REQUIRE(B > 0 && T > 0, "se_spechead_fwd_bf16: bad shape");
+  SE_REQUIRE(workspace_bytes >= se_encoder_workspace_bytes(enc, B, T), "se_spechead_fwd_bf16: workspace too small");
+  const int H = enc->cfg.hidden, N = enc->cfg.spec_out;
+  const size_t Mz = (size_t)B * T;
+  const int M = (int)Mz;
+  hipStream_t st = se::as_stream(stream);
+  Ws w = carve(enc, Mz, reinterpret_cast<char*>(workspace));
+  int rc;
+  {
+    const int grid = (int)std::min<size_t>((Mz * (H / 4) + 255) / 256, 8192);
+    hipLaunchKernelGGL(se::cast_pad_kernel, dim3(grid), dim3(256), 0, st, hidden, Mz, H, H, w.x_bf);
+    SE_LAUNCH_CHECK();
+  }
+  if ((rc = se_gemm_bf16(w.x_bf, H, enc->sh_dense_w, H, enc->sh_dense_b, nullptr, M, H, H, SE_ACT_GELU, nullptr, w.tmp, H, stream))) return rc;
+  if ((rc = launch_layernorm(w.tmp, nullptr, 1, enc->sh_ln_w, enc->sh_ln_b, M, H, enc->cfg.ln_eps, nullptr, w.ctx, st))) return rc;
+  // raw linear output p (M, N) fp32: into `raw` if given, else the (free) x_f32 workspace
+  float* p = raw ? raw : w.x_f32;
+  if ((rc = se_gemm_bf16(w.ctx, H, enc->sh_out_w, H, enc->sh_out_b, nullptr, M, N, H, SE_ACT_IDENTITY, nullptr, p, N, stream))) return rc;
+  if (predicted || log_predicted) {
+    const size_t n = Mz * N;
+    const int grid = (int)std::min<size_t>((n + 255) / 256, 8192);
+    hipLaunchKernelGGL(se::spec_epilogue_kernel, dim3(grid), dim3(256), 0, st, p, n, log_target, act, eps, predicted, log_predicted);
+    SE_LAUNCH_CHECK();
+  }
+  return SE_OK;
+}

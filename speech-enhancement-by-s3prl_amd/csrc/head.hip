@@ -127,6 +127,13 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ fea
 
 }  // namespace se
 
+// internal (not part of the public header): column statistics shared with head_bwd.hip
+extern "C" int se_head_colstats_f32(const float* feats, int B, int F, int D, float eps, float* stats, void* stream) {
+  hipLaunchKernelGGL(se::colstats_kernel, dim3((D + 63) / 64, B), dim3(256), 0, se::as_stream(stream), feats, F, D, eps, stats);
+  SE_LAUNCH_CHECK();
+  return SE_OK;
+}
+
 extern "C" size_t se_head_workspace_bytes(int B, int F, int D, int N) {
   (void)F;
   // [stats: B*D*2 floats][bwd scratch: g_pre (B*F*N) is NOT kept here; see se_head_linear_bwd_f32]
@@ -152,8 +159,8 @@ extern "C" int se_head_linear_f32(const float* feats, const float* W, const floa
   if (cmvn) {
     SE_REQUIRE(workspace && workspace_bytes >= se_head_workspace_bytes(B, F, D, N), "se_head_linear_f32: workspace too small");
     stats = reinterpret_cast<float*>(workspace);
-    hipLaunchKernelGGL(se::colstats_kernel, dim3((D + 63) / 64, B), dim3(256), 0, st, feats, F, D, eps, stats);
-    SE_LAUNCH_CHECK();
+    int rc = se_head_colstats_f32(feats, B, F, D, eps, stats, stream);
+    if (rc) return rc;
   }
   const int rows = B * F;
   const int nt = (N + 31) / 32;

@@ -10,6 +10,7 @@
 //   ola    : out[n] = sum_f w[n - 160 f] z_f[n - 160 f] / sum_f w^2[n - 160 f]      (1/200 folded into w)
 // LDS 51 200 B -> 3 workgroups per CU.  Bound: HBM (2 249 608 B per utterance).
 #include "plan.h"
+#include "prof.h"
 #include "fft200.h"
 
 namespace se {
@@ -196,6 +197,7 @@ extern "C" int se_istft_f32(const se_plan* plan, const float* power, const float
   hipStream_t st = se::as_stream(stream);
   if (sumsq_out) SE_HIP(hipMemsetAsync(sumsq_out, 0, sizeof(float) * B, st));
   dim3 grid((n_out + se::kISpan - 1) / se::kISpan, B);
+  se::ProfScope prof(se::kProfIstft, (double)B * (8.0 * F * se::kBins + 4.0 * n_out), st);
   hipLaunchKernelGGL(se::istft_kernel, grid, dim3(se::kIThreads), 0, st, power, phase, F, 1.0f / linear_power,
                      plan->d_window_inv, plan->d_window_sq, plan->d_tw200, plan->d_tw400, wav_out, wav_stride, lengths, sumsq_out);
   SE_LAUNCH_CHECK();

@@ -1,0 +1,204 @@
+// mhsa.hip -- row B2 core: softmax(Q K^T / sqrt(64) + pad-mask) V for 64-wide heads, flash style (the
+// (B, heads, T, T) score tensor the reference materialises -- 48 MB per utterance and layer -- never exists).
+//
+// qkv is the fused projection output (B*T, 3H) bf16 = [Q | K | V]; head h owns columns 64h..64h+63 of each.
+// Workgroup = 4 waves = 128 query rows of one (utterance, head); wave = 32 query rows.  Per 64-key tile:
+//   S^T = K Q^T   v_mfma_f32_32x32x16_bf16 with K as the A operand ("swapped"): each lane then holds 32 of the
+//                 64 scores of ONE query row, so row max / sum are in-register (+1 exchange with lane^32)
+//   P             exp2 with 1/sqrt(64) log2(e) folded in; online softmax, running max / sum per lane
+//   O^T += V^T P^T  the S^T accumulator registers are used directly as the B operand (no LDS round trip, no
+//                 lane movement); V^T fragments come from the row-major V tile through ds_read_b64_tr_b16
+//                 (hardware-transposed LDS read), 4 consecutive keys x one d column per lane, in the same
+//                 permuted k order as the accumulator registers.  O^T keeps the query on the lane, so the
+//                 online-softmax rescale is lane-local.
+// K / V tiles: global -> registers -> LDS, double buffered, XOR-swizzled 16-B chunks (conflict-free b128 and
+// tr_b16 reads).  Keys >= lengths[b] are excluded (the reference adds -10000, i.e. exp() == 0 in fp32).
+// Bound: MFMA (4 T^2 64 flop per head) -- with d = 64 the exp stream (v_exp_f32) is the co-limiter.
+#include "common.h"
+#include "prof.h"
+#include "bf16.h"
+
+namespace se {
+
+constexpr int kAQ = 128;        // query rows per workgroup
+constexpr int kAK = 64;         // keys per tile
+constexpr int kHD = 64;         // head dim
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+
+// byte offset of 16-B chunk `ch` (8 bf16) of row `key` inside a [64][64] bf16 tile; f is a bit permutation of
+// (key>>1)&7 chosen so that (a) 16 rows at one chunk hit 16 distinct 16-B slots (b128 reads of K) and
+// (b) 4 consecutive keys land in 4 distinct 64-B quarters of the 256-B bank row (tr_b16 reads of V)
+__device__ __forceinline__ int kv_off(int key, int ch) {
+  const int f = (((key >> 1) & 1) << 2) | ((key >> 2) & 3);
+  return key * 128 + ((ch ^ f) << 4);
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void mhsa_fwd_kernel(
+    const uint16_t* __restrict__ qkv, const int32_t* __restrict__ lengths, int T, int H, uint16_t* __restrict__ ctx) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * 2 * kAK * kHD * 2];   // 2 buffers x (K, V) x 8 KiB = 32 KiB
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int b = blockIdx.z, head = blockIdx.y, q0 = blockIdx.x * kAQ + wave * 32;
+  const int ld = 3 * H;
+  const int len = lengths ? min(max(lengths[b], 1), T) : T;
+  const int nkt = (len + kAK - 1) / kAK;
+  const uint16_t* base = qkv + (size_t)b * T * ld + head * kHD;
+
+  // ---- Q fragments (B operand of S^T = K Q^T): lane -> query row q0 + l31, d = 16 s + 8 hh .. +7
+  bf16x8 qf[4];
+  {
+    const int q = min(q0 + l31, T - 1);
+    const uint16_t* qp = base + (size_t)q * ld + 8 * hh;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
+  }
+
+  // ---- staging: K and V tiles are 64 rows x 128 B; 256 threads x 16 B = 32 rows per pass
+  const int srow = tid >> 3, sch = tid & 7;
+  const uint16_t* kp = base + H + sch * 8;
+  const uint16_t* vp = base + 2 * H + sch * 8;
+  uint4 rk0, rk1, rv0, rv1;
+  const int so0 = kv_off(srow, sch), so1 = kv_off(srow + 32, sch);
+#define SE_A_ISSUE(kt)                                                                       \
+  do {                                                                                       \
+    const size_t r0 = (size_t)min((kt) * kAK + srow, T - 1) * ld;                            \
+    const size_t r1 = (size_t)min((kt) * kAK + srow + 32, T - 1) * ld;                       \
+    rk0 = *reinterpret_cast<const uint4*>(kp + r0);                                          \
+    rk1 = *reinterpret_cast<const uint4*>(kp + r1);                                          \
+    rv0 = *reinterpret_cast<const uint4*>(vp + r0);                                          \
+    rv1 = *reinterpret_cast<const uint4*>(vp + r1);                                          \
+  } while (0)
+#define SE_A_WRITE(buf)                                                 \
+  do {                                                                  \
+    char* k_w = smem + (buf) * 16384;                                   \
+    char* v_w = k_w + 8192;                                             \
+    *reinterpret_cast<uint4*>(k_w + so0) = rk0;                         \
+    *reinterpret_cast<uint4*>(k_w + so1) = rk1;                         \
+    *reinterpret_cast<uint4*>(v_w + so0) = rv0;                         \
+    *reinterpret_cast<uint4*>(v_w + so1) = rv1;                         \
+  } while (0)
+
+  f32x16 o0, o1;                      // O^T d-blocks 0 / 1: col = query (lane & 31), row = d
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+  float m_run = -INFINITY, l_run = 0.f;
+  const float c = 0.125f * 1.44269504088896340736f;     // 1/sqrt(64) * log2(e)
+
+  SE_A_ISSUE(0);
+  SE_A_WRITE(0);
+  __syncthreads();
+
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nkt) SE_A_ISSUE(kt + 1);
+    const char* k_s = smem + cur * 16384;
+    const char* v_s = k_s + 8192;
+
+    // ---- S^T = K Q^T : two 32-key blocks x 4 k-steps over d
+    f32x16 s0, s1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const bf16x8 ka = *reinterpret_cast<const bf16x8*>(k_s + kv_off(l31, 2 * s + hh));
+      const bf16x8 kb = *reinterpret_cast<const bf16x8*>(k_s + kv_off(32 + l31, 2 * s + hh));
+      s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[s], s0, 0, 0, 0);
+      s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb, qf[s], s1, 0, 0, 0);
+    }
+    // ---- key mask (only the tile that crosses `len`); accumulator row map: key = (r&3) + 8 (r>>2) + 4 hh
+    if ((kt + 1) * kAK > len) {
+      const int kbase = kt * kAK + 4 * hh;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kbase + (r & 3) + 8 * (r >> 2);
+        if (key >= len) s0[r] = -INFINITY;
+        if (key + 32 >= len) s1[r] = -INFINITY;
+      }
+    }
+    // ---- online softmax (this lane: 32 of the 64 keys of query row l31; partner lane^32 holds the rest)
+    float mx = s0[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s0[r]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s1[r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);          // finite: key 0 is always valid and lives in tile 0
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+    const float mc = m_new * c;
+    float rs = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      s0[r] = __builtin_amdgcn_exp2f(fmaf(s0[r], c, -mc));
+      s1[r] = __builtin_amdgcn_exp2f(fmaf(s1[r], c, -mc));
+      rs += s0[r] + s1[r];
+    }
+    l_run = fmaf(l_run, alpha, rs);
+    m_run = m_new;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+
+    // ---- P fragments: registers 8 s .. 8 s + 7 of block kb -> k-step (kb, s)
+    bf16x8 pf[2][2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        pf[0][s][j] = (__bf16)s0[8 * s + j];
+        pf[1][s][j] = (__bf16)s1[8 * s + j];
+      }
+
+    // ---- O^T += V^T P^T : A operand = V^T via transposed LDS reads (4 consecutive keys x column d per lane)
+    //      lane group g = lane>>4: keys key0 + (lane&15)/4, columns d0 + 4 ((lane&15)&3); d0 = 32 dblk + 16 (g&1)
+    const int tq = (lane & 15) >> 2, tp = lane & 3;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int key0 = kb * 32 + 16 * s + 4 * hh + tq;          // row this lane ADDRESSES (elements j = 0..3)
+#pragma unroll
+        for (int dblk = 0; dblk < 2; ++dblk) {
+          const int dcol = dblk * 32 + 16 * ((lane >> 4) & 1) + 4 * tp;     // first of the 4 columns this lane addresses
+          const int ch = dcol >> 3, sub = (dcol & 7) * 2;
+          const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+              (__attribute__((address_space(3))) bf16x4*)(v_s + kv_off(key0, ch) + sub));
+          const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+              (__attribute__((address_space(3))) bf16x4*)(v_s + kv_off(key0 + 8, ch) + sub));
+          const bf16x8 va = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          if (dblk == 0) o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, pf[kb][s], o0, 0, 0, 0);
+          else o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, pf[kb][s], o1, 0, 0, 0);
+        }
+      }
+
+    if (kt + 1 < nkt) SE_A_WRITE(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: O / l ; lane holds query q0 + l31, d = 32 dblk + (r&3) + 8 (r>>2) + 4 hh
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float inv = 1.0f / l_tot;
+  const int q = q0 + l31;
+  if (q < T) {
+    uint16_t* op = ctx + ((size_t)b * T + q) * H + head * kHD + 4 * hh;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      uint2 w0 = make_uint2(pack_bf16x2(o0[4 * g] * inv, o0[4 * g + 1] * inv), pack_bf16x2(o0[4 * g + 2] * inv, o0[4 * g + 3] * inv));
+      uint2 w1 = make_uint2(pack_bf16x2(o1[4 * g] * inv, o1[4 * g + 1] * inv), pack_bf16x2(o1[4 * g + 2] * inv, o1[4 * g + 3] * inv));
+      *reinterpret_cast<uint2*>(op + 8 * g) = w0;
+      *reinterpret_cast<uint2*>(op + 32 + 8 * g) = w1;
+    }
+  }
+}
+
+}  // namespace se
+
+extern "C" int se_mhsa_fwd_bf16(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, void* stream) {
+  SE_REQUIRE(qkv && ctx, "se_mhsa_fwd_bf16: null argument");
+  SE_REQUIRE(B > 0 && B <= 65535 && T > 0 && heads > 0 && heads <= 65535, "se_mhsa_fwd_bf16: bad shape B=%d T=%d heads=%d", B, T, heads);
+  const int H = heads * se::kHD;
+  dim3 grid((T + se::kAQ - 1) / se::kAQ, heads, B);
+  se::ProfScope prof(se::kProfMhsa, 4.0 * B * (double)heads * T * (double)T * se::kHD, se::as_stream(stream));
+  hipLaunchKernelGGL(se::mhsa_fwd_kernel, grid, dim3(256), 0, se::as_stream(stream), qkv, lengths, T, H, ctx);
+  SE_LAUNCH_CHECK();
+  return SE_OK;
+}

@@ -10,6 +10,7 @@
 //   mel    : sparse HTK triangles over the power kept in LDS, written feature-major (B, n_mels, F)
 // LDS: 32 x 200 float2 = 51 200 B  -> 3 workgroups per CU.  Bound: HBM (2 249 608 B per utterance-channel).
 #include "plan.h"
+#include "prof.h"
 #include "fft200.h"
 
 namespace se {
@@ -149,6 +150,8 @@ extern "C" int se_stft_f32(const se_plan* plan, const float* wavs, int B, int C,
   SE_REQUIRE(B <= 65535, "se_stft_f32: B=%d exceeds grid.y limit", B);
   const int F = T / se::kHop + 1;
   dim3 grid((F + se::kFR - 1) / se::kFR, B);
+  // algorithmic bytes: 4 T in + 4 F K per written plane
+  se::ProfScope prof(se::kProfStft, (double)B * (4.0 * T + 4.0 * F * se::kBins * ((power != nullptr) + (phase != nullptr) + 2 * (complx != nullptr)) + (mel ? 4.0 * F * plan->geom.n_mels : 0.0)), se::as_stream(stream));
   hipLaunchKernelGGL(se::stft_kernel, grid, dim3(se::kThreads), 0, se::as_stream(stream), wavs, C, T, channel, F,
                      plan->d_window, plan->d_tw200, plan->d_tw400, plan->d_mel_start, plan->d_mel_len, plan->d_mel_w,
                      plan->geom.n_mels, power, phase, complx, mel);

@@ -44,11 +44,16 @@ def masked_normalize_decibel(audio, target, lengths, eps=1e-8, audio_sumsq=None,
     if isinstance(target, (int, float)):
         fixed = float(target)
     elif isinstance(target, torch.Tensor) and target.dim() > 1:
-        ref = target.contiguous().float()
+        ref = target
+        if ref.dtype != torch.float32 or ref.stride(1) != 1:
+            ref = ref.contiguous().float()
         if ref.shape[1] < T:
             raise _lib.SEError('reference audio shorter than the audio to normalise')
+        if not ref.is_cuda:
+            raise _lib.SEError('reference audio must live on the GPU (no CPU fallback)')
         ref_sumsq = torch.empty(B, device=audio.device, dtype=torch.float32)
-        _lib.check(lib.se_masked_sumsq_f32(_lib.ptr(ref), B, T, ref.shape[1], _lib.ptr(lengths), _lib.ptr(ref_sumsq),
+        # rows may be strided (wavs[:, channel_tar] of a (B, C, T) batch is read in place, runner.py:561,570)
+        _lib.check(lib.se_masked_sumsq_f32(ref.data_ptr(), B, T, ref.stride(0), _lib.ptr(lengths), _lib.ptr(ref_sumsq),
                                            _lib.stream()), 'se_masked_sumsq_f32')
     else:
         raise NotImplementedError('per-utterance dB tensor targets are unused by the reference')

@@ -8,6 +8,8 @@ import torch
 import torch.nn as nn
 
 from . import _lib
+from .preprocessor import OnlinePreprocessor
+from .transformer import TRANSFORMER, TransformerConfig, TransformerSpecPredictionHead
 
 
 class _HeadLinearFn(torch.autograd.Function):
@@ -89,3 +91,70 @@ class LinearResidual(nn.Module):
         predicted, offset = _HeadLinearFn.apply(features, linears, self.linear.weight, self.linear.bias, self._act,
                                                 self.cmvn, self.eps)
         return predicted, {'offset': offset}
+
+
+class SpecHead(nn.Module):
+    """model.py:94-126: TransformerSpecPredictionHead from an upstream checkpoint + exp / log / activation epilogue,
+    fused into one se_spechead_fwd_bf16 call."""
+
+    def __init__(self, output_size, ckpt, activation='ReLU', random_init=False, eps=1e-6, **kwargs):
+        super().__init__()
+        assert ckpt != ''
+        ckpt = torch.load(ckpt, map_location='cpu') if isinstance(ckpt, str) else ckpt
+        trans_config = TransformerConfig(ckpt['Settings']['Config'])
+        trans_spechead = TransformerSpecPredictionHead(trans_config, output_size)
+        trans_spechead.load_state_dict(ckpt['SpecHead'])
+        assert trans_spechead.output.out_features == output_size
+        self.spechead = trans_spechead
+        self.eps = eps
+        target_config = ckpt['Settings']['Config']['online']['target']
+        self.log = False if 'log' not in target_config else target_config['log']
+        self.activation = activation
+        _act_id(activation)
+        if random_init:
+            for param in self.parameters():
+                if param.dim() >= 2:
+                    nn.init.xavier_uniform_(param.data)
+                else:
+                    nn.init.constant_(param.data, 0)
+
+    def forward(self, features, **kwargs):
+        predicted, log_predicted = self.spechead._engine.spechead(self.spechead, None, features, mode='full',
+                                                                  log_target=self.log, act=self.activation, eps=self.eps)
+        return predicted, {'log_predicted': log_predicted}
+
+
+class Mockingjay(nn.Module):
+    """model.py:129-171: the whole upstream encoder + spec head as the downstream model (ignores `linears`).
+    Forward only this round (no backward through the encoder yet)."""
+
+    def __init__(self, dckpt, activation='ReLU', eps=1e-6, **kwargs):
+        super().__init__()
+        options = {'ckpt_file': dckpt, 'load_pretrain': 'True', 'no_grad': 'False', 'dropout': 'default', 'spec_aug': 'False',
+                   'spec_aug_prev': 'True', 'weighted_sum': 'False', 'select_layer': -1, 'permute_input': 'False'}
+        ckpt = torch.load(dckpt, map_location='cpu')
+        pretrain_config = ckpt['Settings']['Config']
+        online = pretrain_config['online']
+        # feature dims without running the (GPU-only) preprocessor: D = base * (1 + delta)
+        def feat_dim(cfg):
+            base = {'mel': online.get('n_mels', 40), 'linear': online.get('n_freq', 201), 'phase': online.get('n_freq', 201),
+                    'complx': 2 * online.get('n_freq', 201)}[cfg['feat_type']]
+            return base * (1 + int(cfg.get('delta', 0)))
+        inp_dim, tar_dim = feat_dim(online['input']), feat_dim(online['target'])
+        self.mockingjay = TRANSFORMER(options, inp_dim)
+        trans_config = TransformerConfig(pretrain_config)
+        trans_spechead = TransformerSpecPredictionHead(trans_config, tar_dim)
+        trans_spechead.load_state_dict(ckpt['SpecHead'])
+        assert trans_spechead.output.out_features == tar_dim
+        self.spechead = trans_spechead
+        self.eps = eps
+        target_config = online['target']
+        self.log = False if 'log' not in target_config else target_config['log']
+        self.activation = activation
+        _act_id(activation)
+
+    def forward(self, features, **kwargs):
+        features = self.mockingjay(features)
+        predicted, log_predicted = self.spechead._engine.spechead(self.spechead, None, features, mode='full',
+                                                                  log_target=self.log, act=self.activation, eps=self.eps)
+        return predicted, {'log_predicted': log_predicted}

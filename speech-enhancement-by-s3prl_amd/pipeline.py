@@ -1,0 +1,135 @@
+"""The per-batch hot path assembled the way Runner.evaluate() / Runner.train() run it (runner.py:431-471,556-575),
+plus seeded random weights at the real sizes (no checkpoints exist offline).  Used by bench.py, the smoke test
+and the parity tests; `run_downstream.py`-style drivers compose the same objects themselves."""
+import copy
+
+import torch
+
+from . import decode
+from .heads import SpecHead
+from .objective import L1
+from .preprocessor import OnlinePreprocessor
+from .transformer import TRANSFORMER
+
+# config/pretrain_sample.yaml restated (the only architecture config the reference ships)
+PRETRAIN_SAMPLE = {
+    'transformer': {'input_dim': 80, 'downsample_rate': 1, 'hidden_size': 768, 'num_hidden_layers': 6,
+                    'num_attention_heads': 12, 'intermediate_size': 3072, 'hidden_act': 'gelu',
+                    'hidden_dropout_prob': 0.1, 'attention_probs_dropout_prob': 0.1, 'initializer_range': 0.02,
+                    'layer_norm_eps': '1e-12', 'share_layer': False},
+    'online': {'sample_rate': 16000, 'max_time': 10000, 'target_level': -25, 'noise_proportion': 0.5, 'snrs': [3, 6],
+               'win_ms': 25, 'hop_ms': 10, 'n_freq': 201, 'n_mels': 40, 'n_mfcc': 13,
+               'input': {'feat_type': 'mel', 'channel': 0, 'log': True, 'delta': 1, 'cmvn': True},
+               'target': {'feat_type': 'linear', 'channel': 1, 'log': True, 'delta': 0, 'cmvn': False}},
+}
+# config/pseudo_noise.yaml preprocessor.baseline
+BASELINE_FEAT = {'feat_type': 'mel', 'log': True, 'delta': 2, 'cmvn': False}
+
+
+def make_config(layers=6, hidden=768, heads=12, intermediate=3072):
+    cfg = copy.deepcopy(PRETRAIN_SAMPLE)
+    cfg['transformer'].update(num_hidden_layers=layers, hidden_size=hidden, num_attention_heads=heads, intermediate_size=intermediate)
+    return cfg
+
+
+def random_upstream_states(config, inp_dim=80, spec_out=201, seed=0):
+    """Seeded state dicts (S3PRL key names) at the sizes of `config`: N(0, initializer_range) matrices and biases,
+    LayerNorm weight 1 + 0.1 N(0,1), bias 0.1 N(0,1).  Returns (transformer_state, spechead_state)."""
+    t = config['transformer']
+    H, I, L, r = t['hidden_size'], t['intermediate_size'], t['num_hidden_layers'], float(t['initializer_range'])
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+
+    def lin(d, name, o, i):
+        d[name + '.weight'] = torch.randn(o, i, generator=g) * r
+        d[name + '.bias'] = torch.randn(o, generator=g) * r
+
+    def ln(d, name):
+        d[name + '.weight'] = 1.0 + 0.1 * torch.randn(H, generator=g)
+        d[name + '.bias'] = 0.1 * torch.randn(H, generator=g)
+
+    lin(sd, 'input_representations.spec_transform', H, inp_dim)
+    ln(sd, 'input_representations.LayerNorm')
+    for i in range(L):
+        p = f'encoder.layer.{i}.'
+        for n in ('query', 'key', 'value'):
+            lin(sd, p + 'attention.self.' + n, H, H)
+        lin(sd, p + 'attention.output.dense', H, H)
+        ln(sd, p + 'attention.output.LayerNorm')
+        lin(sd, p + 'intermediate.dense', I, H)
+        lin(sd, p + 'output.dense', H, I)
+        ln(sd, p + 'output.LayerNorm')
+    head = {}
+    lin(head, 'dense', H, H)
+    ln(head, 'LayerNorm')
+    lin(head, 'output', spec_out, H)
+    return sd, head
+
+
+def synthetic_checkpoint(config=None, seed=0, inp_dim=80, spec_out=201):
+    """An in-memory checkpoint with the S3PRL layout the reference reads (model.py:98-108,144-153)."""
+    config = config or make_config()
+    sd, head = random_upstream_states(config, inp_dim, spec_out, seed)
+    return {'Settings': {'Config': config, 'Paras': None}, 'Transformer': sd, 'SpecHead': head}
+
+
+def build_upstream(ckpt, device):
+    """TRANSFORMER + SpecHead from a checkpoint dict, as run_downstream.get_upstream_model (run_downstream.py:167-185)."""
+    options = {'ckpt_file': '', 'load_pretrain': 'False', 'no_grad': 'True', 'dropout': 'default', 'spec_aug': 'False',
+               'spec_aug_prev': 'True', 'weighted_sum': 'False', 'select_layer': -1, 'permute_input': 'False'}
+    inp_dim = ckpt['Transformer']['input_representations.spec_transform.weight'].shape[1]
+    out_dim = ckpt['SpecHead']['output.weight'].shape[0]
+    upstream = TRANSFORMER(options, inp_dim, config=ckpt['Settings']['Config'])
+    upstream.model.load_state_dict(ckpt['Transformer'])
+    setattr(upstream, 'SpecHead', SpecHead(out_dim, ckpt))
+    return upstream.to(device).eval()
+
+
+def build_preprocessor(config, device, channel_inp=0, channel_tar=1, downstream_feat=None):
+    """run_downstream.get_preprocessor (run_downstream.py:123-164): the six-feature list."""
+    online = config['online']
+    up = dict(online['input'], channel=channel_inp)
+    down = dict(downstream_feat or BASELINE_FEAT, channel=channel_inp)
+    P = OnlinePreprocessor
+    feat_list = [up, down, P.get_feat_config('linear', channel_inp), P.get_feat_config('phase', channel_inp),
+                 P.get_feat_config('linear', channel_tar), P.get_feat_config('phase', channel_tar)]
+    pre = OnlinePreprocessor(**online, feat_list=feat_list)
+    pre.channel_inp, pre.channel_tar = channel_inp, channel_tar
+    return pre.to(device)
+
+
+class UpstreamEnhanceStep:
+    """One evaluate()-style pass (runner.py:556-575) with the upstream + SpecHead as the enhancer
+    (the _pseudo_clean path, runner.py:273-277): wavs -> 6 features -> encoder -> spec head -> decode_wav
+    (iSTFT with the noisy phase, normalised to the clean wav's level) -> L1 loss."""
+
+    def __init__(self, preprocessor, upstream, criterion=None):
+        self.pre, self.up = preprocessor, upstream
+        self.criterion = criterion or L1()
+
+    @torch.no_grad()
+    def __call__(self, wavs, lengths, max_len=None):
+        feats_up, feats_down, lin_inp, ph_inp, lin_tar, ph_tar = self.pre(wavs)
+        hidden = self.up(feats_up)
+        predicted, res = self.up.SpecHead(hidden)
+        wav_tar = wavs[:, self.pre.channel_tar, :]
+        wav_pred = decode.decode_wav(self.pre, predicted, ph_inp, lengths, wav_tar, max_len=max_len)
+        stft_lengths = lengths // self.pre._win_args['hop_length'] + 1
+        loss, _ = self.criterion(log_predicted=res['log_predicted'], linear_tar=lin_tar, stft_lengths=stft_lengths)
+        return wav_pred, loss, predicted
+
+
+class HeadEnhanceStep:
+    """evaluate()-style pass for a feature-input head (LinearResidual / Linear), config 1 / 4:
+    wavs -> features -> mask head -> mask (.) noisy power -> decode_wav."""
+
+    def __init__(self, preprocessor, head):
+        self.pre, self.head = preprocessor, head
+
+    @torch.no_grad()
+    def __call__(self, wavs, lengths, max_len=None):
+        feats_up, feats_down, lin_inp, ph_inp, lin_tar, ph_tar = self.pre(wavs)
+        predicted, res = self.head(features=feats_down, linears=lin_inp)
+        wav_tar = wavs[:, self.pre.channel_tar, :]
+        wav_pred = decode.decode_wav(self.pre, predicted, ph_inp, lengths, wav_tar, max_len=max_len)
+        return wav_pred, predicted, lin_tar

@@ -1,0 +1,323 @@
+"""S3PRL transformer plugin surface on the gfx950 encoder (rows B1-B6 of SURVEY.md section 8a).
+
+Mirrors, with the same names / constructor arguments / state_dict keys:
+  transformer.model.TransformerConfig(config_dict)                       model.py:99,151
+  transformer.model.TransformerSpecPredictionHead(cfg, out_dim)          model.py:100-103,120,152-154,165
+  transformer.nn_transformer.TRANSFORMER(options, inp_dim)               run_downstream.py:170-185; model.py:132-149,164
+  downstream.model.dummy_upstream(input_dim)                             run_downstream.py:188
+
+Checkpoint layout consumed (the S3PRL one the reference reads): ckpt['Settings']['Config']{'transformer','online'},
+ckpt['Transformer'] (state_dict of TransformerModel), ckpt['SpecHead'] (state_dict of the head).
+
+The forward pass runs on libse_amd.so only (bf16 MFMA GEMMs + flash MHSA, fp32 residual stream); there is no
+CPU fallback.  Inference / no_grad use (the reference's upstream role, runner.py:273-284) is what this round
+implements; a backward pass through the encoder (Mockingjay fine-tuning) is not available yet and raises.
+"""
+import ctypes
+import warnings
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .preprocessor import OnlinePreprocessor
+
+
+class TransformerConfig(object):
+    """Plain config object built from ckpt['Settings']['Config'] (reads config['transformer'])."""
+
+    def __init__(self, config):
+        t = config['transformer']
+        self.downsample_rate = int(t.get('downsample_rate', 1))
+        self.hidden_size = int(t.get('hidden_size', 768))
+        self.num_hidden_layers = int(t.get('num_hidden_layers', 6))
+        self.num_attention_heads = int(t.get('num_attention_heads', 12))
+        self.hidden_act = t.get('hidden_act', 'gelu')
+        self.intermediate_size = int(t.get('intermediate_size', 3072))
+        self.hidden_dropout_prob = float(t.get('hidden_dropout_prob', 0.1))
+        self.attention_probs_dropout_prob = float(t.get('attention_probs_dropout_prob', 0.1))
+        self.initializer_range = float(t.get('initializer_range', 0.02))
+        self.layer_norm_eps = float(t.get('layer_norm_eps', 1e-12))
+        self.share_layer = bool(t.get('share_layer', False))
+        self.pre_layer_norm = bool(t.get('pre_layer_norm', False))
+
+
+class TransformerLayerNorm(nn.Module):
+    """Parameter holder (TF-style LayerNorm, eps inside the sqrt); the arithmetic runs in the fused HIP kernels."""
+
+    def __init__(self, hidden_size, eps=1e-12):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(hidden_size))
+        self.bias = nn.Parameter(torch.zeros(hidden_size))
+        self.variance_epsilon = eps
+
+
+def _holder(**children):
+    m = nn.Module()
+    for k, v in children.items():
+        m.add_module(k, v)
+    return m
+
+
+class TransformerModel(nn.Module):
+    """Parameter tree with S3PRL's state_dict keys (input_representations.*, encoder.layer.N.*)."""
+
+    def __init__(self, config, input_dim):
+        super().__init__()
+        H, I = config.hidden_size, config.intermediate_size
+        self.config = config
+        self.input_dim = input_dim
+        self.input_representations = _holder(spec_transform=nn.Linear(input_dim * config.downsample_rate, H),
+                                             LayerNorm=TransformerLayerNorm(H, config.layer_norm_eps))
+        layers = []
+        for _ in range(config.num_hidden_layers):
+            attention = _holder(self=_holder(query=nn.Linear(H, H), key=nn.Linear(H, H), value=nn.Linear(H, H)),
+                                output=_holder(dense=nn.Linear(H, H), LayerNorm=TransformerLayerNorm(H, config.layer_norm_eps)))
+            layers.append(_holder(attention=attention, intermediate=_holder(dense=nn.Linear(H, I)),
+                                  output=_holder(dense=nn.Linear(I, H), LayerNorm=TransformerLayerNorm(H, config.layer_norm_eps))))
+        self.encoder = _holder(layer=nn.ModuleList(layers))
+        self.apply(self._init_weights)
+
+    def _init_weights(self, module):
+        if isinstance(module, nn.Linear):
+            module.weight.data.normal_(mean=0.0, std=self.config.initializer_range)
+            module.bias.data.zero_()
+
+
+class TransformerSpecPredictionHead(nn.Module):
+    """dense -> gelu -> LayerNorm -> output; forward(hidden) -> (pred, hidden_after_LN is NOT materialised: None)."""
+
+    def __init__(self, config, output_dim, input_dim=None):
+        super().__init__()
+        self.config = config
+        self.output_dim = output_dim
+        H = config.hidden_size
+        self.dense = nn.Linear(H if input_dim is None else input_dim, H)
+        if input_dim is not None and input_dim != H:
+            raise NotImplementedError('spec head input_dim != hidden_size is unused by the reference')
+        self.LayerNorm = TransformerLayerNorm(H, eps=config.layer_norm_eps)
+        self.output = nn.Linear(H, output_dim * config.downsample_rate)
+        if config.hidden_act != 'gelu':
+            raise NotImplementedError("only hidden_act 'gelu' (config/pretrain_sample.yaml:8) is supported")
+        self._engine = _Engine()
+
+    def forward(self, hidden_states):
+        raw = self._engine.spechead(self, None, hidden_states, mode='raw')
+        return raw, None
+
+
+class _Engine:
+    """Owns the se_encoder handle for a parameter set; re-packs when any parameter changed (version counters)."""
+
+    def __init__(self):
+        self.handle = None
+        self.key = None
+        self.ws = None
+
+    def __del__(self):
+        try:
+            if self.handle is not None and _lib._lib is not None:
+                _lib._lib.se_encoder_destroy(self.handle)
+        except Exception:
+            pass
+
+    def __getstate__(self):
+        return {}
+
+    def __setstate__(self, state):
+        self.handle, self.key, self.ws = None, None, None
+
+    def __deepcopy__(self, memo):
+        return _Engine()
+
+    @staticmethod
+    def _np(t):
+        return np.ascontiguousarray(t.detach().float().cpu().numpy())
+
+    def _build(self, model, head, device):
+        lib = _lib.load()
+        keep = []          # keep numpy arrays alive during the create call
+        FP = ctypes.POINTER(ctypes.c_float)
+
+        def fp(t):
+            a = self._np(t)
+            keep.append(a)
+            return a.ctypes.data_as(FP)
+
+        def fpp(ts):
+            arr = (FP * len(ts))(*[fp(t) for t in ts])
+            keep.append(arr)
+            return ctypes.cast(arr, ctypes.POINTER(FP))
+
+        w = _lib.EncoderWeights()
+        if model is not None:
+            cfg = model.config
+            ir = model.input_representations
+            w.in_w, w.in_b = fp(ir.spec_transform.weight), fp(ir.spec_transform.bias)
+            w.in_ln_w, w.in_ln_b = fp(ir.LayerNorm.weight), fp(ir.LayerNorm.bias)
+            Ls = list(model.encoder.layer)
+            w.q_w, w.q_b = fpp([l.attention.self.query.weight for l in Ls]), fpp([l.attention.self.query.bias for l in Ls])
+            w.k_w, w.k_b = fpp([l.attention.self.key.weight for l in Ls]), fpp([l.attention.self.key.bias for l in Ls])
+            w.v_w, w.v_b = fpp([l.attention.self.value.weight for l in Ls]), fpp([l.attention.self.value.bias for l in Ls])
+            w.ao_w, w.ao_b = fpp([l.attention.output.dense.weight for l in Ls]), fpp([l.attention.output.dense.bias for l in Ls])
+            w.aln_w, w.aln_b = fpp([l.attention.output.LayerNorm.weight for l in Ls]), fpp([l.attention.output.LayerNorm.bias for l in Ls])
+            w.ff1_w, w.ff1_b = fpp([l.intermediate.dense.weight for l in Ls]), fpp([l.intermediate.dense.bias for l in Ls])
+            w.ff2_w, w.ff2_b = fpp([l.output.dense.weight for l in Ls]), fpp([l.output.dense.bias for l in Ls])
+            w.oln_w, w.oln_b = fpp([l.output.LayerNorm.weight for l in Ls]), fpp([l.output.LayerNorm.bias for l in Ls])
+            in_dim, layers = ir.spec_transform.in_features, cfg.num_hidden_layers
+        else:
+            # head-only engine: a 1-layer dummy trunk is never run; the C side needs valid trunk pointers
+            cfg = head.config
+            H, I = cfg.hidden_size, cfg.intermediate_size
+            zH, zHH, zI, zIH, zHI = (torch.zeros(H), torch.zeros(H, H), torch.zeros(I), torch.zeros(I, H), torch.zeros(H, I))
+            w.in_w, w.in_b, w.in_ln_w, w.in_ln_b = fp(torch.zeros(H, 64)), fp(zH), fp(zH), fp(zH)
+            for name, t in (('q_w', zHH), ('q_b', zH), ('k_w', zHH), ('k_b', zH), ('v_w', zHH), ('v_b', zH), ('ao_w', zHH),
+                            ('ao_b', zH), ('aln_w', zH), ('aln_b', zH), ('ff1_w', zIH), ('ff1_b', zI), ('ff2_w', zHI),
+                            ('ff2_b', zH), ('oln_w', zH), ('oln_b', zH)):
+                setattr(w, name, fpp([t]))
+            in_dim, layers = 64, 1
+        spec_out = 0
+        if head is not None:
+            w.sh_dense_w, w.sh_dense_b = fp(head.dense.weight), fp(head.dense.bias)
+            w.sh_ln_w, w.sh_ln_b = fp(head.LayerNorm.weight), fp(head.LayerNorm.bias)
+            w.sh_out_w, w.sh_out_b = fp(head.output.weight), fp(head.output.bias)
+            spec_out = head.output.out_features
+        c = _lib.EncoderConfig(in_dim, cfg.hidden_size, layers, cfg.num_attention_heads, cfg.intermediate_size,
+                               cfg.layer_norm_eps, spec_out)
+        out = _lib.c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(lib.se_encoder_create(c, w, out), 'se_encoder_create')
+        if self.handle is not None:
+            lib.se_encoder_destroy(self.handle)
+        self.handle = out.value
+
+    def _ensure(self, model, head, device):
+        params = ([p for p in model.parameters()] if model is not None else []) + ([p for p in head.parameters()] if head is not None else [])
+        key = (device.index, tuple((p.data_ptr(), p._version) for p in params))
+        if self.handle is None or key != self.key:
+            self._build(model, head, device)
+            self.key = key
+        return self.handle
+
+    def _workspace(self, handle, B, T, device):
+        lib = _lib.load()
+        n = lib.se_encoder_workspace_bytes(handle, B, T)
+        if self.ws is None or self.ws.numel() < n or self.ws.device != device:
+            self.ws = torch.empty(n, device=device, dtype=torch.uint8)
+        return self.ws, n
+
+    def encode(self, model, head, feats, lengths=None):
+        if not feats.is_cuda:
+            raise _lib.SEError('TRANSFORMER runs on MI355X only (no CPU fallback): move the module and inputs to the GPU')
+        lib = _lib.load()
+        feats = feats.contiguous().float()
+        B, T, D = feats.shape
+        h = self._ensure(model, head, feats.device)
+        ws, n = self._workspace(h, B, T, feats.device)
+        if lengths is None:
+            lengths = torch.empty(B, device=feats.device, dtype=torch.int32)
+            _lib.check(lib.se_valid_lengths_i32(_lib.ptr(feats), B, T, D, _lib.ptr(lengths), _lib.stream()), 'se_valid_lengths_i32')
+        hidden = torch.empty(B, T, model.config.hidden_size, device=feats.device, dtype=torch.float32)
+        _lib.check(lib.se_encoder_fwd_bf16(h, _lib.ptr(feats), _lib.ptr(lengths), B, T, _lib.ptr(hidden), _lib.ptr(ws), n,
+                                           _lib.stream()), 'se_encoder_fwd_bf16')
+        return hidden
+
+    def spechead(self, head, model, hidden, mode='raw', log_target=False, act='ReLU', eps=1e-6):
+        if not hidden.is_cuda:
+            raise _lib.SEError('TransformerSpecPredictionHead runs on MI355X only (no CPU fallback)')
+        lib = _lib.load()
+        hidden = hidden.contiguous().float()
+        B, T, H = hidden.shape
+        h = self._ensure(model, head, hidden.device)
+        ws, n = self._workspace(h, B, T, hidden.device)
+        N = head.output.out_features
+        dev = hidden.device
+        if mode == 'raw':
+            raw = torch.empty(B, T, N, device=dev, dtype=torch.float32)
+            _lib.check(lib.se_spechead_fwd_bf16(h, _lib.ptr(hidden), B, T, 0, 0, float(eps), None, None, _lib.ptr(raw), _lib.ptr(ws), n,
+                                                _lib.stream()), 'se_spechead_fwd_bf16')
+            return raw
+        pred = torch.empty(B, T, N, device=dev, dtype=torch.float32)
+        logp = torch.empty(B, T, N, device=dev, dtype=torch.float32)
+        _lib.check(lib.se_spechead_fwd_bf16(h, _lib.ptr(hidden), B, T, int(bool(log_target)), _lib.SE_ACT[act], float(eps),
+                                            _lib.ptr(pred), _lib.ptr(logp), None, _lib.ptr(ws), n, _lib.stream()), 'se_spechead_fwd_bf16')
+        return pred, logp
+
+
+def _str2bool(v):
+    return v if isinstance(v, bool) else str(v) == 'True'
+
+
+class TRANSFORMER(nn.Module):
+    """S3PRL nn_transformer.TRANSFORMER: loads its own weights from options['ckpt_file'];
+    forward(x) -> (B, T', out_dim) for x = features (B, T', D) or waveform (B, T, C)."""
+
+    def __init__(self, options, inp_dim, config=None, online_config=None):
+        super().__init__()
+        if config is not None:
+            self.all_states = None
+            self.config = config
+        else:
+            self.all_states = torch.load(options['ckpt_file'], map_location='cpu')
+            self.config = self.all_states['Settings']['Config']
+        self.no_grad = _str2bool(options.get('no_grad', 'False'))
+        self.spec_aug = _str2bool(options.get('spec_aug', 'False'))
+        self.weighted_sum = _str2bool(options.get('weighted_sum', 'False'))
+        self.select_layer = int(options.get('select_layer', -1))
+        self.permute_input = _str2bool(options.get('permute_input', 'False'))
+        if self.weighted_sum or self.select_layer != -1:
+            raise NotImplementedError('weighted_sum / select_layer != -1 are unused by the reference (model.py:138-139)')
+        if self.spec_aug:
+            raise NotImplementedError("spec_aug is 'False' at every reference call site (model.py:136)")
+        if options.get('dropout', 'default') != 'default':
+            d = float(options['dropout'])
+            self.config['transformer']['hidden_dropout_prob'] = d
+            self.config['transformer']['attention_probs_dropout_prob'] = d
+        self.model_config = TransformerConfig(self.config)
+        self.dr = self.model_config.downsample_rate
+        if self.dr != 1:
+            raise NotImplementedError('downsample_rate != 1 (config/pretrain_sample.yaml:3 uses 1)')
+        self.hidden_size = self.model_config.hidden_size
+        self.num_layers = self.model_config.num_hidden_layers
+        if online_config is None and 'online' in self.config:
+            online_config = self.config['online']
+        if online_config is not None:
+            self.preprocessor = OnlinePreprocessor(**online_config)
+            self.preprocessor.feat_list = [online_config['input']] if 'input' in online_config else None
+        self.inp_dim = inp_dim
+        self.model = TransformerModel(self.model_config, inp_dim)
+        if _str2bool(options.get('load_pretrain', 'False')) and self.all_states is not None:
+            self.model.load_state_dict(self.all_states['Transformer'])
+        self.out_dim = self.hidden_size
+        self._engine = _Engine()
+        self._warned = False
+        self.all_states = None      # free the checkpoint copy
+
+    def forward(self, x):
+        if self.training and not self._warned and self.model_config.hidden_dropout_prob > 0:
+            warnings.warn('TRANSFORMER.forward in training mode: dropout is not applied by the MI355X encoder (inference path)')
+            self._warned = True
+        if torch.is_grad_enabled() and not self.no_grad and any(p.requires_grad for p in self.model.parameters()) and x.requires_grad:
+            raise NotImplementedError('backward through the MI355X encoder is not implemented yet (inference / no_grad only)')
+        if self.permute_input:
+            x = x.permute(1, 0, 2)
+        if hasattr(self, 'preprocessor') and x.size(-1) != self.inp_dim:
+            # waveform input (B, T, C): the internal preprocessor extracts the pre-training input feature
+            x = self.preprocessor(x.transpose(1, 2).contiguous())[0]
+        with torch.no_grad():
+            out = self._engine.encode(self.model, None, x)
+        if self.permute_input:
+            out = out.permute(1, 0, 2)
+        return out
+
+
+class dummy_upstream(nn.Module):
+    """downstream.model.dummy_upstream: identity upstream with .out_dim (run_downstream.py:188-191)."""
+
+    def __init__(self, input_dim):
+        super().__init__()
+        self.out_dim = input_dim
+
+    def forward(self, features):
+        return features

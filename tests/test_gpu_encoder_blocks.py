@@ -1,0 +1,133 @@
+"""GPU parity of the encoder building blocks (se_gemm_bf16, se_mhsa_fwd_bf16, se_layernorm_f32) through the
+C ABI against plain PyTorch fp32 references of the same op on the SAME bf16-rounded operands (so the only
+differences are accumulation order and the bf16 rounding of P / outputs).  Exact-integer checks catch
+fragment-layout bugs (A = I with an asymmetric B)."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _lib():
+    from speech_enhancement_by_s3prl_amd import _lib
+    return _lib
+
+
+def gemm(A, W, bias=None, residual=None, act=0, out='f32'):
+    L = _lib()
+    lib = L.load()
+    M, K = A.shape
+    N = W.shape[0]
+    o32 = torch.empty(M, N, device=A.device, dtype=torch.float32) if out in ('f32', 'both') else None
+    o16 = torch.empty(M, N, device=A.device, dtype=torch.bfloat16) if out in ('bf16', 'both') else None
+    L.check(lib.se_gemm_bf16(L.ptr(A), K, L.ptr(W), K, L.ptr(bias), L.ptr(residual), M, N, K, act, L.ptr(o16), L.ptr(o32), N,
+                             L.stream()), 'se_gemm_bf16')
+    return o32, o16
+
+
+def test_gemm_identity_asymmetric(gpu):
+    """A = I (padded), W asymmetric small integers: exact in bf16 -> exact output, catches row/col swaps."""
+    K = 128
+    A = torch.zeros(256, K, device=gpu)
+    A[:K, :K] = torch.eye(K, device=gpu)
+    W = (torch.arange(200 * K, device=gpu).reshape(200, K) % 97 - 40).float()   # W[n][k]
+    o32, _ = gemm(A.bfloat16(), W.bfloat16())
+    assert torch.equal(o32[:K].cpu(), W.T.cpu())
+    assert torch.count_nonzero(o32[K:]) == 0
+
+
+@pytest.mark.parametrize('M,N,K', [(128, 128, 64), (1001, 768, 768), (300, 201, 768), (2002, 2304, 768), (515, 768, 3072), (77, 768, 128)])
+def test_gemm_vs_torch(gpu, M, N, K):
+    torch.manual_seed(M + N + K)
+    A = torch.randn(M, K, device=gpu).bfloat16()
+    W = (torch.randn(N, K, device=gpu) * 0.05).bfloat16()
+    bias = torch.randn(N, device=gpu)
+    res = torch.randn(M, N, device=gpu)
+    ref = A.float().double() @ W.float().double().T + bias.double()
+    o32, o16 = gemm(A, W, bias, None, 0, 'both')
+    scale = ref.abs().max().item()
+    assert (o32.double() - ref).abs().max().item() < 2e-5 * scale + 1e-5 * math.sqrt(K)
+    assert (o16.double() - ref).abs().max().item() < 8e-3 * scale
+    # fused GELU + residual
+    o32, _ = gemm(A, W, bias, res, 3)
+    refg = torch.nn.functional.gelu(ref.float()).double() + res.double()
+    assert (o32.double() - refg).abs().max().item() < 3e-5 * refg.abs().max().item() + 1e-4
+
+
+def mhsa_ref(qkv, lengths, B, T, heads):
+    H = heads * 64
+    x = qkv.float().view(B, T, 3, heads, 64).permute(2, 0, 3, 1, 4).double()    # (3, B, h, T, 64)
+    q, k, v = x[0], x[1], x[2]
+    s = q @ k.transpose(-1, -2) / 8.0
+    mask = torch.arange(T, device=qkv.device)[None, :] >= lengths[:, None]       # (B, T) True = masked
+    s = s.masked_fill(mask[:, None, None, :], float('-inf'))
+    p = torch.softmax(s, dim=-1)
+    return (p @ v).permute(0, 2, 1, 3).reshape(B * T, H)
+
+
+@pytest.mark.parametrize('B,T,heads,lens', [(2, 128, 2, None), (2, 1001, 12, None), (3, 200, 3, [200, 77, 1]), (1, 65, 1, [64]), (2, 333, 2, [300, 129])])
+def test_mhsa_vs_torch(gpu, B, T, heads, lens):
+    L = _lib()
+    lib = L.load()
+    torch.manual_seed(T)
+    H = heads * 64
+    qkv = (torch.randn(B * T, 3 * H, device=gpu) * 1.5).bfloat16()
+    lengths = torch.tensor(lens if lens else [T] * B, device=gpu, dtype=torch.int32)
+    ctx = torch.empty(B * T, H, device=gpu, dtype=torch.bfloat16)
+    L.check(lib.se_mhsa_fwd_bf16(L.ptr(qkv), L.ptr(lengths) if lens else None, B, T, heads, L.ptr(ctx), L.stream()), 'se_mhsa_fwd_bf16')
+    ref = mhsa_ref(qkv, lengths, B, T, heads)
+    err = (ctx.double() - ref).abs().max().item()
+    assert err < 2e-2 * ref.abs().max().item(), err      # P and the output are rounded to bf16 (2^-9 relative)
+
+
+def test_mhsa_exact_integers(gpu):
+    """uniform attention (Q = 0) over integer V: output = mean of V rows -> exercises the V^T / P operand maps."""
+    L = _lib()
+    lib = L.load()
+    B, T, heads = 1, 64, 1
+    qkv = torch.zeros(T, 192, device=gpu)
+    V = (torch.arange(T * 64, device=gpu).reshape(T, 64) % 13 - 6).float()          # asymmetric small ints
+    qkv[:, 128:] = V
+    qkv[:, 64:128] = torch.randn(T, 64, device=gpu)                                  # K irrelevant when Q = 0
+    ctx = torch.empty(T, 64, device=gpu, dtype=torch.bfloat16)
+    L.check(lib.se_mhsa_fwd_bf16(L.ptr(qkv.bfloat16()), None, B, T, heads, L.ptr(ctx), L.stream()), 'se_mhsa_fwd_bf16')
+    ref = V.mean(dim=0, keepdim=True).expand(T, 64)
+    assert (ctx.float() - ref).abs().max().item() < 2e-2
+
+
+def test_mhsa_one_hot_attention(gpu):
+    """Q.K large on one key per query -> output row = that V row (checks the key <-> register map)."""
+    L = _lib()
+    lib = L.load()
+    T = 128
+    torch.manual_seed(3)
+    perm = torch.randperm(T, device=gpu)
+    basis = torch.zeros(T, 64, device=gpu)
+    # orthogonal-ish codes: use 7-bit binary code of the key index in +-1, scaled
+    idx = torch.arange(T, device=gpu)
+    for bit in range(7):
+        basis[:, bit] = ((idx >> bit) & 1).float() * 2 - 1
+    K = basis * 16.0
+    Q = basis[perm] * 16.0              # query i matches key perm[i] with score 7*256/8 = 224, others <= 160
+    V = (torch.randn(T, 64, device=gpu)).bfloat16().float()
+    qkv = torch.cat([Q, K, V], dim=1).bfloat16()
+    ctx = torch.empty(T, 64, device=gpu, dtype=torch.bfloat16)
+    L.check(lib.se_mhsa_fwd_bf16(L.ptr(qkv), None, 1, T, 1, L.ptr(ctx), L.stream()), 'se_mhsa_fwd_bf16')
+    assert (ctx.float() - V[perm]).abs().max().item() < 1e-2
+
+
+@pytest.mark.parametrize('M,H', [(1001, 768), (7, 768), (33, 320)])
+def test_layernorm(gpu, M, H):
+    L = _lib()
+    lib = L.load()
+    torch.manual_seed(M)
+    x = torch.randn(M, H, device=gpu) * 3 + 1
+    w, b = torch.randn(H, device=gpu), torch.randn(H, device=gpu)
+    o32 = torch.empty_like(x)
+    o16 = torch.empty(M, H, device=gpu, dtype=torch.bfloat16)
+    L.check(lib.se_layernorm_f32(L.ptr(x), L.ptr(w), L.ptr(b), M, H, 1e-12, L.ptr(o32), L.ptr(o16), L.stream()), 'se_layernorm_f32')
+    ref = torch.nn.functional.layer_norm(x.double(), (H,), w.double(), b.double(), 1e-12)
+    assert (o32.double() - ref).abs().max().item() < 2e-5
+    assert (o16.double() - ref).abs().max().item() < 4e-2
