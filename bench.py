@@ -1,0 +1,205 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the MI355X speech-enhancement hot path.
+
+Metric (BASELINE.json): enhanced 10 s utterances / second.  Workload at every N = configs[1]:
+"TERA-base upstream + 2-layer mask head on libri-test-clean-10s, batch 32, bf16, 1 x MI355X", i.e. one
+evaluate()-style pass (runner.py:556-575) per step over a batch of 32 synthetic 10 s / 16 kHz utterances
+already resident in HBM:  STFT of the noisy + clean channels -> mel/log/delta/CMVN features -> 6-layer
+768/12/3072 encoder (the only architecture config the reference ships, config/pretrain_sample.yaml:1-22)
+-> TransformerSpecPredictionHead + exp/ReLU -> iSTFT with the noisy phase -> level normalisation to the
+clean wav -> masked log-L1 loss.  Weights: seeded random at the real sizes (no checkpoints exist offline).
+
+Multi-GPU: utterances shard data-parallel with NO data-path collective (inference); every rank runs
+the same per-GPU batch ("weak" scaling); value = all utterances / max-over-ranks time.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16
+
+
+def cpu_baseline(batch, layers, seconds_budget=25.0):
+    """The oracle (CPU restatement of the reference path) timed on this box's host cores, bounded sample."""
+    import oracle
+    from oracle import decode as odec, encoder as oenc, heads as oheads, objective as oobj, preprocessor as opre
+    from speech_enhancement_by_s3prl_amd import pipeline, synth
+    # threads actually used: this process's CPU share (affinity), capped at 16 -- the GPU box gives one GPU job a
+    # 16-core share of a 256-thread host; asking torch for all 256 oversubscribes it by 16x
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))
+    torch.set_num_threads(cores)
+    cfg = pipeline.make_config(layers=layers)
+    ckpt = pipeline.synthetic_checkpoint(cfg, seed=0)
+    ocfg = oenc.Config(cfg)
+    geom = opre.Geometry()
+    feat_list = [dict(cfg['online']['input'], channel=0), dict(pipeline.BASELINE_FEAT, channel=0),
+                 opre.get_feat_config('linear', 0), opre.get_feat_config('phase', 0),
+                 opre.get_feat_config('linear', 1), opre.get_feat_config('phase', 1)]
+    lengths, wavs = synth.fast_batch(batch, 160000, seed=1)
+
+    def one():
+        with torch.no_grad():
+            f = opre.forward(wavs, feat_list, geom)
+            hid = oenc.encoder_forward(f[0], ckpt['Transformer'], ocfg, lengths=torch.full((batch,), f[0].shape[1]))
+            pred, res = oheads.spec_head(hid, ckpt['SpecHead'], ocfg, log=True)
+            wav = odec.decode_wav(pred, f[3], lengths, geom, wavs[:, 1])
+            loss = oobj.l1(res['log_predicted'], f[4], odec.get_length_masks(lengths // 160 + 1))
+        return wav, loss
+
+    t0 = time.perf_counter()
+    one()                      # warm-up (also sizes the sample)
+    warm = time.perf_counter() - t0
+    iters = max(1, min(5, int(seconds_budget / max(warm, 1e-3)) - 1))
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        one()
+    dt = (time.perf_counter() - t0) / iters
+    cpu_name = ''
+    try:
+        with open('/proc/cpuinfo') as fh:
+            for line in fh:
+                if line.startswith('model name'):
+                    cpu_name = line.split(':', 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {'value': batch / dt, 'unit': 'utt/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{iters} x batch of {batch} synthetic 10 s utterances, same pass (fp32 torch CPU oracle, L={layers}), '
+                      f'{dt:.2f} s per batch on {cpu_name}'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=32, help='utterances per GPU per step (configs[1]: 32)')
+    ap.add_argument('--layers', type=int, default=6, help='encoder depth (6 = config/pretrain_sample.yaml; 3 = "base")')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    distributed = world > 1
+    if not torch.cuda.is_available():
+        print('bench.py needs an MI355X: the hot path has no CPU fallback', file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
+
+    from speech_enhancement_by_s3prl_amd import _lib, pipeline, synth
+    lib = _lib.load()
+    cfg = pipeline.make_config(layers=args.layers)
+    ckpt = pipeline.synthetic_checkpoint(cfg, seed=0)
+    upstream = pipeline.build_upstream(ckpt, dev)
+    pre = pipeline.build_preprocessor(cfg, dev)
+    step = pipeline.UpstreamEnhanceStep(pre, upstream)
+    lengths, wavs = synth.fast_batch(args.batch, 160000, seed=1000 + rank, device=dev)   # resident in HBM before timing
+    max_len = 160000
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(wavs, lengths, max_len)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        wav_pred, loss, _ = step(wavs, lengths, max_len)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        dist.barrier()
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    assert torch.isfinite(wav_pred).all() and torch.isfinite(loss)
+
+    total_utts = args.batch * world * args.steps
+    out = {
+        'metric': 'enhanced 10s utts/sec', 'value': total_utts / elapsed, 'unit': 'utt/s', 'n_gpus': world,
+        'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1000.0 * elapsed / args.steps,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+        'config': {'workload': 'configs[1]: TERA/Mockingjay upstream (6x768x12x3072, pretrain_sample.yaml) + '
+                               'TransformerSpecPredictionHead, evaluate()-style pass, 10 s @ 16 kHz',
+                   'batch_per_gpu': args.batch, 'global_batch': args.batch * world, 'layers': args.layers,
+                   'frames': 1001, 'parallelism': f'dp{world} (utterance-sharded inference, no data-path collective)',
+                   'weights': 'seeded random, real sizes'},
+    }
+
+    if rank == 0 and not args.no_roofline:
+        # roofline leg: the same K steps with HIP events recorded (in-library, on the launch stream) around every
+        # kernel of the dominant families.  Dominant kernel = the bf16 MFMA GEMM (QKV / out-proj / FFN / head).
+        lib.se_prof_reset()
+        lib.se_prof_enable(1)
+        for _ in range(args.steps):
+            step(wavs, lengths, max_len)
+        torch.cuda.synchronize()
+        lib.se_prof_enable(0)
+        fam = {}
+        for kind, name in ((0, 'gemm_bf16'), (1, 'mhsa_fwd'), (2, 'stft'), (3, 'istft')):
+            ms, work, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_longlong()
+            lib.se_prof_read(kind, ctypes.byref(ms), ctypes.byref(work), ctypes.byref(n))
+            fam[name] = (ms.value, work.value, n.value)
+        g_ms, g_flop, g_n = fam['gemm_bf16']
+        achieved = g_flop / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
+        out['roofline'] = {'bound': 'mfma', 'kernel': 'gemm_bf16_kernel', 'achieved': achieved, 'peak': MFMA_BF16_PEAK_TFLOPS,
+                           'unit': 'TFLOP/s', 'frac': achieved / MFMA_BF16_PEAK_TFLOPS, 'traffic': None,
+                           'launches': g_n, 'avg_launch_ms': g_ms / max(g_n, 1),
+                           'algorithmic_flop_per_launch': g_flop / max(g_n, 1)}
+        others = {}
+        m_ms, m_flop, m_n = fam['mhsa_fwd']
+        if m_ms > 0:
+            a = m_flop / (m_ms * 1e-3) / 1e12
+            others['mhsa_fwd_kernel'] = {'bound': 'mfma', 'achieved': a, 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                                         'frac': a / MFMA_BF16_PEAK_TFLOPS, 'avg_launch_ms': m_ms / m_n, 'share_of_step_ms': m_ms / args.steps}
+        for name in ('stft', 'istft'):
+            ms, byts, n = fam[name]
+            if ms > 0:
+                a = byts / (ms * 1e-3) / 1e9
+                others[name + '_kernel'] = {'bound': 'hbm', 'achieved': a, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': a / HBM_PEAK_GBS,
+                                            'avg_launch_ms': ms / n, 'share_of_step_ms': ms / args.steps}
+        others['gemm_share_of_step_ms'] = g_ms / args.steps
+        out['roofline_other_kernels'] = others
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            out['cpu_baseline'] = cpu_baseline(batch=4, layers=args.layers)
+        except Exception as e:      # the baseline is a reported extra; never lose the GPU line
+            out['cpu_baseline'] = {'value': None, 'unit': 'utt/s', 'cores': os.cpu_count(), 'kind': 'port', 'sample': f'failed: {e}'}
+
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()
