@@ -1,0 +1,86 @@
+"""Data-parallel glue: one process per GPU, `torch.distributed` ("nccl" == RCCL over xGMI on
+ROCm; "gloo" in the CPU tests).  The reference has no distributed code at all; this is what the build adds.
+
+Inference (configs 2, 4): utterances shard i = r (mod world); NO collective on the data path.
+Training (configs 3, 5): replicate the downstream parameters; every rank computes the UN-normalised L1 sum and its
+masked element count; ONE all-reduce(sum) of (sum, count) gives the global masked mean (objective.py:113-116 is a
+global mean over the whole batch -- a mean of per-rank means would break parity on ragged batches); the local
+gradients are therefore already scaled by 1/global_count, and ONE all-reduce(sum) over a single flat fp32 buffer
+of all downstream gradients yields the exact single-process gradient.  Clipping and the NaN/Inf skip decision
+(runner.py:463-470) are then taken on the all-reduced gradient, identically on every rank.
+Message sizes: 24 321 floats (LinearResidual 120->201) ... 43.3 M floats (Mockingjay L=6): one flat buffer, one
+collective per step -- small messages are latency-bound on the xGMI mesh, large ones want one big ring / direct
+reduce-scatter instead of many small buckets."""
+import math
+
+import torch
+import torch.distributed as dist
+
+
+def is_distributed():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def shard_indices(n_items, rank=None, world=None):
+    """Utterance sharding for inference: item i goes to rank i % world."""
+    rank = dist.get_rank() if rank is None else rank
+    world = dist.get_world_size() if world is None else world
+    return list(range(rank, n_items, world))
+
+
+def all_reduce_sums(sums):
+    """reduce_fn for objective.L1: (sum |.|, count) -> global sums (in place, returns the tensor)."""
+    if is_distributed():
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+    return sums
+
+
+class FlatGradAllReducer:
+    """All-reduces (sum) the gradients of `params` through ONE flat fp32 buffer (allocated once)."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        self.numel = sum(p.numel() for p in self.params)
+        p0 = self.params[0]
+        self.flat = torch.zeros(self.numel, device=p0.device, dtype=torch.float32)
+        self.views, off = [], 0
+        for p in self.params:
+            self.views.append(self.flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+
+    def reduce(self):
+        for p, v in zip(self.params, self.views):
+            if p.grad is None:
+                v.zero_()
+            else:
+                v.copy_(p.grad)
+        if is_distributed():
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+        for p, v in zip(self.params, self.views):
+            if p.grad is None:
+                p.grad = v.clone()
+            else:
+                p.grad.copy_(v)
+        return self.flat
+
+
+class DataParallelTrainStep:
+    """The reference's training step (runner.py:453-471) under data parallelism.
+    `forward_fn(batch) -> (log_predicted, linear_tar, stft_lengths)`; criterion = objective.L1."""
+
+    def __init__(self, model, criterion, optimizer, grad_clip=1.0):
+        self.model, self.criterion, self.optimizer, self.grad_clip = model, criterion, optimizer, grad_clip
+        self.criterion.reduce_fn = all_reduce_sums
+        self.reducer = FlatGradAllReducer(list(model.parameters()))
+
+    def step(self, loss):
+        """loss already computed with the global-mean criterion; backward, all-reduce, clip, (maybe) step."""
+        loss.backward()
+        self.reducer.reduce()
+        grad_norm = torch.nn.utils.clip_grad_norm_(self.reducer.params, self.grad_clip)
+        gn = float(grad_norm)
+        skipped = math.isnan(gn) or math.isinf(gn)          # identical on every rank: taken on the reduced gradient
+        if not skipped:
+            self.optimizer.step()
+        self.optimizer.zero_grad()
+        return gn, skipped
