@@ -12,6 +12,7 @@
 //               bf16 and / or fp32 output
 //   grid      : XCD-aware bijective remap so the blocks that share an A panel run on one XCD back to back
 // Bound: MFMA (2 M N K flop against the 2.5 PFLOP/s dense bf16 peak).
+#include <stdlib.h>
 #include "common.h"
 #include "prof.h"
 #include "bf16.h"
@@ -189,6 +190,12 @@ __global__ __launch_bounds__(kGThreads) __attribute__((amdgpu_waves_per_eu(2, 2)
 
 }  // namespace se
 
+extern "C" int se_gemm2_launch(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias, const float* residual_f32,
+                               int M, int N, int K, int act, uint16_t* out_bf16, float* out_f32, int ldc, int vec_ok, int variant, void* stream);
+extern "C" int se_gemm3_launch(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias, const float* residual_f32,
+                               int M, int N, int K, int act, uint16_t* out_bf16, float* out_f32, int ldc, int vec_ok, void* stream);
+static int g_gemm_variant = -1;   // -1: read SE_AMD_GEMM once (1 = register-staged 128x128 kernel of this file, 2 = gemm2.hip lockstep, 3 = gemm2.hip ping-pong, 4 = gemm2.hip 128x128 x 2 workgroups / CU, 5 = gemm3.hip 256x256 [default])
+
 extern "C" int se_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias,
                             const float* residual_f32, int M, int N, int K, int act,
                             uint16_t* out_bf16, float* out_f32, int ldc, void* stream) {
@@ -199,6 +206,17 @@ extern "C" int se_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, int l
   SE_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0, "se_gemm_bf16: operands must be 16-B aligned");
   // vector epilogue needs 16-B aligned rows of every tensor it touches
   const int vec_ok = (ldc % 8 == 0) && (((uintptr_t)out_bf16 | (uintptr_t)out_f32 | (uintptr_t)residual_f32 | (uintptr_t)bias) % 16 == 0);
+  if (g_gemm_variant < 0) {
+    const char* e = getenv("SE_AMD_GEMM");
+    g_gemm_variant = (e && e[0] >= '1' && e[0] <= '5') ? (e[0] - '0') : 5;
+  }
+  if (g_gemm_variant == 5) {      // 256 x 256 kernel for wide outputs (enough tiles to fill 256 CUs several times), 256 x 128 ping-pong otherwise
+    const int rc = (N >= 1536) ? se_gemm3_launch(A, lda, W, ldw, bias, residual_f32, M, N, K, act, out_bf16, out_f32, ldc, vec_ok, stream) : 1;
+    if (rc <= 0) return rc;
+    return se_gemm2_launch(A, lda, W, ldw, bias, residual_f32, M, N, K, act, out_bf16, out_f32, ldc, vec_ok, 3, stream);
+  }
+  if (g_gemm_variant >= 2)
+    return se_gemm2_launch(A, lda, W, ldw, bias, residual_f32, M, N, K, act, out_bf16, out_f32, ldc, vec_ok, g_gemm_variant, stream);
   const int tiles_m = (M + se::kBM - 1) / se::kBM, tiles_n = (N + se::kBN - 1) / se::kBN;
   static bool attr_set = false;
   if (!attr_set) {

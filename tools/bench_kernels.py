@@ -1,0 +1,89 @@
+"""Micro-benchmarks of the individual kernels on the bench shapes (developer tool; run on the GPU box).
+    python tools/bench_kernels.py gemm|mhsa|stft|all
+"""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from speech_enhancement_by_s3prl_amd import _lib  # noqa: E402
+
+L = _lib
+lib = _lib.load()
+dev = torch.device('cuda:0')
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters
+
+
+def bench_gemm():
+    M = 32 * 1001
+    for (N, K, act, res) in [(2304, 768, 0, False), (768, 768, 0, True), (3072, 768, 3, False), (768, 3072, 0, True), (768, 128, 0, False), (201, 768, 0, False)]:
+        A = torch.randn(M, K, device=dev).bfloat16()
+        W = (torch.randn(N, K, device=dev) * 0.05).bfloat16()
+        bias = torch.randn(N, device=dev)
+        resid = torch.randn(M, N, device=dev) if res else None
+        o16 = torch.empty(M, N, device=dev, dtype=torch.bfloat16) if not res else None
+        o32 = torch.empty(M, N, device=dev) if res or N == 201 else None
+        if N == 201:
+            o16 = None
+
+        def run():
+            L.check(lib.se_gemm_bf16(L.ptr(A), K, L.ptr(W), K, L.ptr(bias), L.ptr(resid), M, N, K, act, L.ptr(o16), L.ptr(o32), N, L.stream()), 'gemm')
+        ms = timeit(run)
+        # spot check
+        ref = (A[:64].float() @ W.float().T + bias)
+        if act == 3:
+            ref = torch.nn.functional.gelu(ref)
+        if res:
+            ref = ref + resid[:64]
+        got = (o32 if o32 is not None else o16.float())[:64]
+        err = (got - ref).abs().max().item() / ref.abs().max().item()
+        print(f'gemm M={M} N={N} K={K} act={act} res={res}: {ms*1e3:8.1f} us  {2.0*M*N*K/ms/1e9:8.1f} TF/s  relerr {err:.1e}', flush=True)
+
+
+def bench_mhsa():
+    B, T, heads = 32, 1001, 12
+    qkv = (torch.randn(B * T, 3 * 768, device=dev)).bfloat16()
+    ctx = torch.empty(B * T, 768, device=dev, dtype=torch.bfloat16)
+
+    def run():
+        L.check(lib.se_mhsa_fwd_bf16(L.ptr(qkv), None, B, T, heads, L.ptr(ctx), L.stream()), 'mhsa')
+    ms = timeit(run)
+    print(f'mhsa B={B} T={T}: {ms*1e3:8.1f} us  {4.0*B*heads*T*T*64/ms/1e9:8.1f} TF/s', flush=True)
+
+
+def bench_stft():
+    from speech_enhancement_by_s3prl_amd.preprocessor import OnlinePreprocessor
+    P = OnlinePreprocessor().to(dev)
+    for B in (32, 256):
+        wavs = torch.randn(B, 3, 160000, device=dev) * 0.1
+        fl = [P.get_feat_config('linear', 0), P.get_feat_config('phase', 0)]
+        ms = timeit(lambda: P(wavs, fl))
+        byts = B * 2249608
+        print(f'stft B={B}: {ms*1e3:8.1f} us  {byts/ms/1e6:8.1f} GB/s', flush=True)
+        lin, ph = P(wavs, fl)
+        ms = timeit(lambda: P.istft(lin, ph))
+        print(f'istft B={B}: {ms*1e3:8.1f} us  {byts/ms/1e6:8.1f} GB/s', flush=True)
+
+
+if __name__ == '__main__':
+    what = sys.argv[1] if len(sys.argv) > 1 else 'all'
+    if what in ('gemm', 'all'):
+        bench_gemm()
+    if what in ('mhsa', 'all'):
+        bench_mhsa()
+    if what in ('stft', 'all'):
+        bench_stft()
