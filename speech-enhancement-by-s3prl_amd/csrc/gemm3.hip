@@ -8,7 +8,7 @@
 //   tile     : 256 x 256, K walked in 32-deep steps; 512 threads = 8 waves as 2 (M) x 4 (N), wave tile 128 x 64
 //              = 8 x 4 v_mfma_f32_16x16x32_bf16 tiles, 128 accumulator registers; one workgroup per CU
 //   LDS      : ring of 4 stages x (A 256 x 32 + B 256 x 32) bf16 = 4 x 32 KiB; rows are 64 B, 16-B chunk index XOR-ed
-//              with (row >> 2) & 3 (on the DMA source address and again on the ds_read_b128 side): conflict-free
+//              with (-(row >> 2)) & 3 (on the DMA source address and again on the ds_read_b128 side): conflict-free
 //   staging  : global_load_lds_dwordx4, 4 per wave per K-step, K-steps g+1 .. g+3 in flight while g is multiplied;
 //              counted s_waitcnt vmcnt, raw s_barrier only
 //   schedule : ping-pong -- waves 4-7 run one barrier behind waves 0-3; per K-step two {LDS reads | barrier | 16 MFMAs |
@@ -29,7 +29,11 @@ constexpr int k3NDma = 4;                                                       
 typedef __attribute__((address_space(3))) void* lds3_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb3_ptr_t;
 
-__device__ __forceinline__ int swz3(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
+// 16-B chunk swizzle for 64-B rows: chunk' = chunk ^ f(row), f = (-(row >> 2)) & 3.  ds_read_b128 is serviced in
+// 16-lane groups {0-3, 12-15, 20-27}, ... i.e. rows {0-3, 12-15} at chunk c TOGETHER WITH rows {4-11} at chunk c^1;
+// f must make those 16 addresses hit 16 distinct 16-B slots of the 256-B bank row (the obvious (row >> 2) & 3 is 2-way).
+__device__ __forceinline__ int swz3_f(int row) { return (-(row >> 2)) & 3; }
+__device__ __forceinline__ int swz3(int row, int chunk) { return row * 64 + ((chunk ^ swz3_f(row)) << 4); }
 
 __device__ __forceinline__ float act3(float v, int act) {
   if (act == SE_ACT_GELU) return gelu_erf(v);
@@ -46,7 +50,9 @@ __device__ __forceinline__ void stamp3(unsigned long long* buf, int& idx, bool o
 }
 
 // ACT: compile-time activation; EF bit 0: fp32 residual, bit 1: bf16 output, bit 2: fp32 output (N % 4 == 0, 16-B rows)
-template <int ACT, int EF>
+// SCHED 0: two {reads | barrier | 16 MFMAs | barrier} pairs per K-step; SCHED 1: one {12 reads + DMA issue + waits | barrier |
+// 32 MFMAs | barrier} pair per K-step (half the barriers; the LDS latency is absorbed in the read phase)
+template <int ACT, int EF, int SCHED>
 __global__ __launch_bounds__(k3Threads) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm3_bf16_kernel(
     const uint16_t* __restrict__ A, int lda, const uint16_t* __restrict__ W, int ldw, const float* __restrict__ bias,
     const float* __restrict__ residual, int M, int N, int K, uint16_t* __restrict__ out_bf16, float* __restrict__ out_f32,
@@ -73,7 +79,7 @@ __global__ __launch_bounds__(k3Threads) __attribute__((amdgpu_waves_per_eu(2, 2)
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int row = 16 * (i * 8 + wave) + r16;
-    const int lc = (pos ^ ((row >> 2) & 3)) << 3;
+    const int lc = (pos ^ swz3_f(row)) << 3;
     a_src[i] = A + (size_t)min(m0 + row, M - 1) * lda + lc;
     b_src[i] = W + (size_t)min(n0 + row, N - 1) * ldw + lc;
   }
@@ -113,6 +119,7 @@ __global__ __launch_bounds__(k3Threads) __attribute__((amdgpu_waves_per_eu(2, 2)
   __builtin_amdgcn_s_barrier();
   if (late) __builtin_amdgcn_s_barrier();                  // stagger
 
+  if constexpr (SCHED == 0) {
   int st = 0;
   stamp3(st_buf, st_i, st_on);
   for (int g = 0; g < nk; ++g) {
@@ -173,6 +180,40 @@ __global__ __launch_bounds__(k3Threads) __attribute__((amdgpu_waves_per_eu(2, 2)
     __builtin_amdgcn_sched_barrier(0);
     st = (st + 1) & 3;
   }
+  } else {
+  int st = 0;
+  for (int g = 0; g < nk; ++g) {
+    const char* sb = smem + st * k3Stage;
+    bf16x8 af[8], bfr[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(sb + b_off[j]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sb + a_off[i]);
+    // ring slot (g+3)%4 == (g-1)%4: every wave finished (lgkmcnt(0) below) its reads of step g-1 before the barrier
+    // that ended ITS read phase, and this wave has passed that barrier -> safe to refill here
+    if (g + 3 < nk) {
+      SE3_ISSUE(g + 3, (st + 3) & 3);
+      asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");     // K-step g+1 landed; fragments of step g in registers
+    } else if (g + 2 < nk) {
+      asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    st = (st + 1) & 3;
+  }
+  }
   if (!late) __builtin_amdgcn_s_barrier();                 // re-align the two groups (barrier counts must match)
 
   // ---- epilogue: C^T accumulators: col = lane & 15 -> output row, row = 4 (lane >> 4) + r -> 4 consecutive columns
@@ -216,6 +257,191 @@ __global__ __launch_bounds__(k3Threads) __attribute__((amdgpu_waves_per_eu(2, 2)
 #undef SE3_EPILOGUE_BODY
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Persistent form: gridDim.x workgroups (one per CU, a multiple of 8) each walk a list of output tiles.  The LDS ring
+// runs CONTINUOUSLY across tile boundaries (the last three K-steps of a tile already fetch the first three of the
+// next), and the epilogue's stores are left in flight under the next tile's main loop -- counted vmcnt waits include
+// them -- so neither the pipeline fill nor the HBM-bound store phase leaves the matrix pipe idle.
+// Tile order: XCD x (= blockIdx & 7) owns a contiguous range of tile ids (n fastest); its 32 workgroups take ids
+// range_start + (blockIdx >> 3) + 32 i, so the tiles in flight on one XCD share A panels / weight rows in its L2.
+// ------------------------------------------------------------------------------------------------------------------
+template <int ACT, int EF>
+__global__ __launch_bounds__(k3Threads) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm3p_bf16_kernel(
+    const uint16_t* __restrict__ A, int lda, const uint16_t* __restrict__ W, int ldw, const float* __restrict__ bias,
+    const float* __restrict__ residual, int M, int N, int K, uint16_t* __restrict__ out_bf16, float* __restrict__ out_f32,
+    int ldc, int tiles_m, int tiles_n) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+
+  // ---- this workgroup's tile list
+  const int nwg = tiles_m * tiles_n;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, wpx = gridDim.x >> 3;
+  const int q = nwg >> 3, rem = nwg & 7;
+  const int range_start = (xcd < rem) ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q;
+  const int range_count = q + (xcd < rem ? 1 : 0);
+  const int my_tiles = (range_count > slot) ? (range_count - slot + wpx - 1) / wpx : 0;
+  if (my_tiles == 0) return;
+
+  const int r16 = lane >> 2, pos = lane & 3;
+  const uint16_t* a_cur[2];
+  const uint16_t* b_cur[2];
+  const uint16_t* a_nxt[2];
+  const uint16_t* b_nxt[2];
+#define SE3P_SET_PTRS(ap, bp, tile_id)                                             \
+  do {                                                                             \
+    const int tm_ = (tile_id) / tiles_n, tn_ = (tile_id) - tm_ * tiles_n;          \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                \
+      const int row = 16 * (i * 8 + wave) + r16;                                   \
+      const int lc = (pos ^ swz3_f(row)) << 3;                                     \
+      ap[i] = A + (size_t)min(tm_ * k3BM + row, M - 1) * lda + lc;                 \
+      bp[i] = W + (size_t)min(tn_ * k3BN + row, N - 1) * ldw + lc;                 \
+    }                                                                              \
+  } while (0)
+#define SE3P_ISSUE(ap, bp, g, st)                                                                                          \
+  do {                                                                                                                     \
+    char* sb_ = smem + (st) * k3Stage + wave * 1024;                                                                       \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                        \
+      __builtin_amdgcn_global_load_lds((glb3_ptr_t)(ap[i] + (g) * k3BK), (lds3_ptr_t)(sb_ + i * 8192), 16, 0, 0);          \
+      __builtin_amdgcn_global_load_lds((glb3_ptr_t)(bp[i] + (g) * k3BK), (lds3_ptr_t)(sb_ + k3ABytes + i * 8192), 16, 0, 0); \
+    }                                                                                                                      \
+  } while (0)
+
+  const int frow = lane & 15, fch = lane >> 4;
+  int a_off[8], b_off[4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a_off[i] = swz3(wr * 128 + i * 16 + frow, fch);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) b_off[j] = k3ABytes + swz3(wc * 64 + j * 16 + frow, fch);
+
+  const int nk = K / k3BK;                 // >= 3 (launcher)
+  int tile_id = range_start + slot;
+  SE3P_SET_PTRS(a_cur, b_cur, tile_id);
+  SE3P_ISSUE(a_cur, b_cur, 0, 0);
+  SE3P_ISSUE(a_cur, b_cur, 1, 1);
+  SE3P_ISSUE(a_cur, b_cur, 2, 2);
+  const bool late = wave >= 4;
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (late) __builtin_amdgcn_s_barrier();
+
+  constexpr bool RES = EF & 1, OBF = EF & 2, OF32 = EF & 4;
+  constexpr int kStores = 32;              // store instructions of one interior-tile epilogue (8 x 4, one output type)
+  const int mrow = lane & 15, ncol = 4 * (lane >> 4);
+  int st = 0;
+  bool stores_pending = false;             // the previous tile's epilogue left exactly kStores stores in flight
+  for (int ti = 0; ti < my_tiles; ++ti) {
+    const bool has_next = ti + 1 < my_tiles;
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int g = 0; g < nk; ++g) {
+      const char* sb = smem + st * k3Stage;
+      bf16x8 af[8], bfr[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(sb + b_off[j]);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sb + a_off[i]);
+      // refill ring slot (st+3)&3 with the K-step three ahead in the continuous stream (this tile's or the next tile's)
+      const int gi = g + 3;
+      bool issued = false;
+      if (gi < nk) {
+        SE3P_ISSUE(a_cur, b_cur, gi, (st + 3) & 3);
+        issued = true;
+      } else if (has_next) {
+        if (gi == nk) SE3P_SET_PTRS(a_nxt, b_nxt, tile_id + wpx);
+        SE3P_ISSUE(a_nxt, b_nxt, gi - nk, (st + 3) & 3);
+        issued = true;
+      }
+      // wait until the NEXT K-step of the stream has landed.  VMEM ops younger than its 4 DMAs, in issue order:
+      //   [previous tile's epilogue stores, only while g < 2] + the DMA groups of the two following steps.
+      if (issued) {
+        if (stores_pending && g < 2) asm volatile("s_waitcnt vmcnt(40) lgkmcnt(0)" ::: "memory");   // 8 + kStores
+        else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+      } else if (g + 2 < nk) {
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");      // stream tail: only step g+2 remains younger
+      } else {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      st = (st + 1) & 3;
+    }
+
+    // ---- epilogue of this tile (no LDS, no barrier); its stores stay in flight under the next tile's first K-steps
+    const int tm = tile_id / tiles_n, tn = tile_id - tm * tiles_n;
+    const int m0 = tm * k3BM, n0 = tn * k3BN;
+    float4 bb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int gn = min(n0 + wc * 64 + j * 16 + ncol, N - 4);
+      bb[j] = bias ? *reinterpret_cast<const float4*>(bias + gn) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const bool interior = (m0 + k3BM <= M) && (n0 + k3BN <= N);      // wave-uniform
+#define SE3P_EPILOGUE_BODY(PRED)                                                                                           \
+  _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                                          \
+    const int gm = m0 + wr * 128 + i * 16 + mrow;                                                                          \
+    const bool mok = gm < M;                                                                                               \
+    const size_t orow = (size_t)min(gm, M - 1) * ldc;                                                                      \
+    float4 rr[4];                                                                                                          \
+    if constexpr (RES) {                                                                                                   \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                      \
+        const int gn = min(n0 + wc * 64 + j * 16 + ncol, N - 4);                                                           \
+        rr[j] = *reinterpret_cast<const float4*>(residual + orow + gn);                                                    \
+      }                                                                                                                    \
+    }                                                                                                                      \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                        \
+      const int gn = n0 + wc * 64 + j * 16 + ncol;                                                                         \
+      float v0 = acc[i][j][0] + bb[j].x, v1 = acc[i][j][1] + bb[j].y, v2 = acc[i][j][2] + bb[j].z, v3 = acc[i][j][3] + bb[j].w; \
+      v0 = act3(v0, ACT); v1 = act3(v1, ACT); v2 = act3(v2, ACT); v3 = act3(v3, ACT);                                      \
+      if constexpr (RES) { v0 += rr[j].x; v1 += rr[j].y; v2 += rr[j].z; v3 += rr[j].w; }                                   \
+      if (!(PRED) || (mok && gn < N)) {                                                                                    \
+        if constexpr (OF32) *reinterpret_cast<float4*>(out_f32 + orow + gn) = make_float4(v0, v1, v2, v3);                 \
+        if constexpr (OBF) *reinterpret_cast<uint2*>(out_bf16 + orow + gn) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3)); \
+      }                                                                                                                    \
+    }                                                                                                                      \
+  }
+    if (interior) {
+      SE3P_EPILOGUE_BODY(false)
+      stores_pending = true;               // exactly kStores store instructions were issued by this wave
+    } else {
+      SE3P_EPILOGUE_BODY(true)
+      // exec-masked stores: the instruction count is not fixed, so drain everything (the stores are the YOUNGEST
+      // operations, in-order retirement means only vmcnt(0) covers them) before the counted waits resume
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      stores_pending = false;
+    }
+#undef SE3P_EPILOGUE_BODY
+    static_assert(kStores == 8 * 4, "one store per (i, j) tile and output type");
+    if (has_next) {
+      tile_id += wpx;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        a_cur[i] = a_nxt[i];
+        b_cur[i] = b_nxt[i];
+      }
+    }
+  }
+  if (!late) __builtin_amdgcn_s_barrier();                 // re-align the two groups (barrier counts must match)
+#undef SE3P_SET_PTRS
+#undef SE3P_ISSUE
+}
+
 }  // namespace se
 
 namespace {
@@ -224,6 +450,9 @@ struct G3Args {
   uint16_t* out_bf16; float* out_f32; int ldc; hipStream_t st;
 };
 template <int ACT, int EF>
+int launch3s(const G3Args& g, int sched);
+
+template <int ACT, int EF, int SCHED>
 int launch3(const G3Args& g) {
   const int tiles_m = (g.M + se::k3BM - 1) / se::k3BM, tiles_n = (g.N + se::k3BN - 1) / se::k3BN;
   static int dbg = -1;
@@ -233,13 +462,43 @@ int launch3(const G3Args& g) {
   }
   static bool attr_set = false;
   if (!attr_set) {
-    SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::gemm3_bf16_kernel<ACT, EF>), hipFuncAttributeMaxDynamicSharedMemorySize, se::k3Lds));
+    SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::gemm3_bf16_kernel<ACT, EF, SCHED>), hipFuncAttributeMaxDynamicSharedMemorySize, se::k3Lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL((se::gemm3_bf16_kernel<ACT, EF>), dim3(tiles_m * tiles_n), dim3(se::k3Threads), se::k3Lds, g.st, g.A, g.lda, g.W, g.ldw,
+  hipLaunchKernelGGL((se::gemm3_bf16_kernel<ACT, EF, SCHED>), dim3(tiles_m * tiles_n), dim3(se::k3Threads), se::k3Lds, g.st, g.A, g.lda, g.W, g.ldw,
                      g.bias, g.residual, g.M, g.N, g.K, g.out_bf16, g.out_f32, g.ldc, tiles_m, tiles_n, dbg);
   SE_LAUNCH_CHECK();
   return SE_OK;
+}
+template <int ACT, int EF>
+int launch3p(const G3Args& g) {
+  const int tiles_m = (g.M + se::k3BM - 1) / se::k3BM, tiles_n = (g.N + se::k3BN - 1) / se::k3BN;
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    SE_HIP(hipGetDevice(&dev));
+    SE_HIP(hipGetDeviceProperties(&prop, dev));
+    n_cu = prop.multiProcessorCount & ~7;          // one workgroup per CU, a multiple of the 8 XCDs
+    if (n_cu < 8) n_cu = 8;
+    SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::gemm3p_bf16_kernel<ACT, EF>), hipFuncAttributeMaxDynamicSharedMemorySize, se::k3Lds));
+  }
+  static bool attr_set = false;
+  if (!attr_set) {
+    SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::gemm3p_bf16_kernel<ACT, EF>), hipFuncAttributeMaxDynamicSharedMemorySize, se::k3Lds));
+    attr_set = true;
+  }
+  const int grid = n_cu;
+  hipLaunchKernelGGL((se::gemm3p_bf16_kernel<ACT, EF>), dim3(grid), dim3(se::k3Threads), se::k3Lds, g.st, g.A, g.lda, g.W, g.ldw, g.bias,
+                     g.residual, g.M, g.N, g.K, g.out_bf16, g.out_f32, g.ldc, tiles_m, tiles_n);
+  SE_LAUNCH_CHECK();
+  return SE_OK;
+}
+
+template <int ACT, int EF>
+int launch3s(const G3Args& g, int sched) {
+  if (sched == 2) return launch3p<ACT, EF>(g);
+  return sched ? launch3<ACT, EF, 1>(g) : launch3<ACT, EF, 0>(g);
 }
 }  // namespace
 
@@ -252,10 +511,15 @@ extern "C" int se_gemm3_launch(const uint16_t* A, int lda, const uint16_t* W, in
   G3Args g{A, lda, W, ldw, bias, residual_f32, M, N, K, out_bf16, out_f32, ldc, se::as_stream(stream)};
   const bool gelu = act == SE_ACT_GELU, res = residual_f32 != nullptr, obf = out_bf16 != nullptr;
   se::ProfScope prof(se::kProfGemm, 2.0 * M * (double)N * K, g.st);
-  if (!gelu && !res && obf) return launch3<SE_ACT_IDENTITY, 2>(g);
-  if (gelu && !res && obf) return launch3<SE_ACT_GELU, 2>(g);
-  if (!gelu && res && !obf) return launch3<SE_ACT_IDENTITY, 4 | 1>(g);
-  if (!gelu && !res && !obf) return launch3<SE_ACT_IDENTITY, 4>(g);
-  if (gelu && !res && !obf) return launch3<SE_ACT_GELU, 4>(g);
+  static int sched = -1;
+  if (sched < 0) {
+    const char* e = getenv("SE_AMD_GEMM3_SCHED");
+    sched = e ? atoi(e) : 1;        // 0 / 1: one workgroup per tile (two / one [default] barrier pairs per K-step); 2: persistent (measured equal)
+  }
+  if (!gelu && !res && obf) return launch3s<SE_ACT_IDENTITY, 2>(g, sched);
+  if (gelu && !res && obf) return launch3s<SE_ACT_GELU, 2>(g, sched);
+  if (!gelu && res && !obf) return launch3s<SE_ACT_IDENTITY, 4 | 1>(g, sched);
+  if (!gelu && !res && !obf) return launch3s<SE_ACT_IDENTITY, 4>(g, sched);
+  if (gelu && !res && !obf) return launch3s<SE_ACT_GELU, 4>(g, sched);
   return 1;
 }

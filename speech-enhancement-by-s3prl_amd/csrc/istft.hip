@@ -2,31 +2,35 @@
 // envelope division, trim) with the masked square-sum for the dB normalisation fused in; plus the
 // dB-normalise scale pass, the masked square-sum of a reference waveform and the length masks.
 //
-// iSTFT workgroup = 256 threads = 29 hop-blocks (4 640 output samples) of one utterance; it inverse-
-// transforms the 32 frames that overlap that span (3 of them shared with the neighbours, re-read from L2):
+// iSTFT workgroup = 256 threads = 27 hop-blocks (4 320 output samples) of one utterance; it inverse-
+// transforms the 30 frames that overlap that span (3 of them shared with the neighbours, re-read from L2):
 //   load   : X[k] = sqrt(P) (cos phi, sin phi), Im X[0] = Im X[200] = 0 (c2r semantics); X[200].re rides in X[0].y
 //   fold   : Z[k] = E[k] + i O[k]  in place on pairs (k, 200-k)
 //   pass A / pass B : fft200.h with DIR = +1
 //   ola    : out[n] = sum_f w[n - 160 f] z_f[n - 160 f] / sum_f w^2[n - 160 f]      (1/200 folded into w)
-// LDS 51 200 B -> 3 workgroups per CU.  Bound: HBM (2 249 608 B per utterance).
+// All tables (twiddles, window) live in LDS and every global load of a thread is issued up front, so the output loop
+// holds stores only (a load there would drain the stores every iteration: one in-order vmcnt on gfx950).
+// LDS 52 816 B -> 3 workgroups per CU.  Bound: HBM (2 249 608 B per utterance).
 #include "plan.h"
 #include "prof.h"
 #include "fft200.h"
 
 namespace se {
 
-constexpr int kIFR = 32;                 // frames transformed per workgroup
-constexpr int kIHB = 29;                 // hop-blocks of output per workgroup
-constexpr int kISpan = kIHB * kHop;      // 4640 samples
+constexpr int kIFR = 30;                 // frames transformed per workgroup (30 x 25 = 750 pass-A items = 3 full rounds; 3 workgroups / CU)
+constexpr int kIHB = 27;                 // hop-blocks of output per workgroup
+constexpr int kISpan = kIHB * kHop;      // 4320 samples
 constexpr int kIThreads = 256;
+constexpr int kILoadIters = (kIFR * kBins + kIThreads - 1) / kIThreads;   // 25
+constexpr int kIOlaIters = (kISpan + kIThreads - 1) / kIThreads;         // 18
 
 __global__ __launch_bounds__(kIThreads) void istft_kernel(
     const float* __restrict__ power, const float* __restrict__ phase, int F, float inv_lp,
-    const float* __restrict__ window_inv, const float* __restrict__ window_sq,
-    const float2* __restrict__ tw200g, const float2* __restrict__ tw400,
+    const float* __restrict__ window, const float2* __restrict__ tw400g,
     float* __restrict__ wav, int wav_stride, const int64_t* __restrict__ lengths, float* __restrict__ sumsq) {
   __shared__ float2 Y[kIFR * kHalf];
-  __shared__ float2 tw200[kHalf];
+  __shared__ float2 tw[kHalf];            // (cos, sin)(2 pi k / 400), k < 200
+  __shared__ float win[kNfft];
   __shared__ float red[kIThreads / 64];
 
   const int tid = threadIdx.x;
@@ -36,29 +40,45 @@ __global__ __launch_bounds__(kIThreads) void istft_kernel(
   const int fbase = blockIdx.x * kIHB - 1;            // first frame overlapping the span (may be -1)
   const int flo = max(fbase, 0);
   const int fhi = min(fbase + kIFR, F);               // exclusive
-  if (tid < kHalf) tw200[tid] = tw200g[tid];
+  const int nfr = fhi - flo;
+  if (tid < kHalf) tw[tid] = tw400g[tid];
+  for (int i = tid; i < kNfft; i += kIThreads) win[i] = window[i];
 
-  // ---- load + polar:  item (f, k), k = 0..200, contiguous in (B, F, K)
+  // ---- load + polar: item (f, k), k = 0..200, contiguous in (B, F, K); all global loads issued before any use
   {
     const size_t gbase = ((size_t)b * F + flo) * kBins;
-    const int nitems = (fhi - flo) * kBins;
-    for (int it = tid; it < nitems; it += kIThreads) {
-      const int fl = it / kBins, k = it - fl * kBins;
-      const float p = power[gbase + it];
-      const float ph = phase[gbase + it];
-      const float mag = (inv_lp == 0.5f) ? sqrtf(p) : powf(p, inv_lp);
-      float s, c;
-      sincosf(ph, &s, &c);
-      float2* Z = Y + (flo + fl - fbase) * kHalf;
-      if (k == 0) Z[0].x = mag * c;
-      else if (k == kHalf) Z[0].y = mag * c;
-      else Z[k] = make_float2(mag * c, mag * s);
+    const int nitems = nfr * kBins;
+    float pv[kILoadIters], hv[kILoadIters];
+#pragma unroll
+    for (int r = 0; r < kILoadIters; ++r) {
+      const int it = tid + kIThreads * r;
+      const bool ok = it < nitems;
+      pv[r] = ok ? power[gbase + it] : 0.f;
+      hv[r] = ok ? phase[gbase + it] : 0.f;
+    }
+    int fl = tid / kBins, k = tid - fl * kBins;
+#pragma unroll
+    for (int r = 0; r < kILoadIters; ++r) {
+      if (fl < nfr) {
+        const float mag = (inv_lp == 0.5f) ? sqrtf(pv[r]) : powf(pv[r], inv_lp);
+        // sin / cos through the hardware units (argument in revolutions, reduced to [-0.5, 0.5])
+        float rev = hv[r] * 0.15915494309189535f;
+        rev -= rintf(rev);
+        const float c = __builtin_amdgcn_cosf(rev), sn = __builtin_amdgcn_sinf(rev);
+        float2* Z = Y + (flo + fl - fbase) * kHalf;
+        if (k == 0) Z[0].x = mag * c;                  // Im X[0], Im X[200] are ignored (c2r semantics)
+        else if (k == kHalf) Z[0].y = mag * c;         // X[200].re rides in X[0].y
+        else Z[k] = make_float2(mag * c, mag * sn);
+      }
+      k += kIThreads - kBins;                          // 256 = 201 + 55
+      fl += 1;
+      if (k >= kBins) { k -= kBins; fl += 1; }
     }
   }
   __syncthreads();
 
   // ---- fold pairs (k, 200-k): Z[k] = E + iO, Z[200-k] = conj(E) + i conj(O)
-  for (int it = tid; it < (fhi - flo) * 101; it += kIThreads) {
+  for (int it = tid; it < nfr * 101; it += kIThreads) {
     const int fl = it / 101, k = it - fl * 101;
     float2* Z = Y + (flo + fl - fbase) * kHalf;
     if (k == 0) {
@@ -71,7 +91,7 @@ __global__ __launch_bounds__(kIThreads) void istft_kernel(
       const float2 xk = Z[k], xn = Z[kHalf - k];
       const float2 E = make_float2(0.5f * (xk.x + xn.x), 0.5f * (xk.y - xn.y));
       const float2 D = make_float2(0.5f * (xk.x - xn.x), 0.5f * (xk.y + xn.y));
-      const float2 w = tw400[k];                                   // W^-k = (cos, +sin)
+      const float2 w = tw[k];                                      // W^-k = (cos, +sin)
       const float2 O = make_float2(D.x * w.x - D.y * w.y, D.x * w.y + D.y * w.x);
       Z[k] = make_float2(E.x - O.y, E.y + O.x);                    // E + iO
       Z[kHalf - k] = make_float2(E.x + O.y, -E.y + O.x);           // conj(E) + i conj(O)
@@ -79,15 +99,29 @@ __global__ __launch_bounds__(kIThreads) void istft_kernel(
   }
   __syncthreads();
 
-  for (int it = tid; it < (fhi - flo) * 25; it += kIThreads) {
+  // ---- pass A (inverse): W200^(+j q) from the 400-table
+  for (int it = tid; it < nfr * 25; it += kIThreads) {
     const int fl = it / 25, j = it - fl * 25;
-    fft200_pass_a<+1>(Y + (flo + fl - fbase) * kHalf, j, tw200);
+    float2* frame = Y + (flo + fl - fbase) * kHalf;
+    float2 v[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) v[m] = frame[25 * m + j];
+    fft8<+1>(v);
+#pragma unroll
+    for (int q = 1; q < 8; ++q) {
+      const int t2 = 2 * j * q;
+      const float2 w = tw[t2 < kHalf ? t2 : t2 - kHalf];
+      const float sg = t2 < kHalf ? 1.f : -1.f;
+      v[q] = cmul(v[q], make_float2(sg * w.x, sg * w.y));
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) frame[25 * q + j] = v[q];
   }
   __syncthreads();
 
   {
     const int f = tid >> 3, q = tid & 7;
-    const bool active = (fbase + f >= flo) && (fbase + f < fhi);
+    const bool active = (f < kIFR) && (fbase + f >= flo) && (fbase + f < fhi);
     float2 y[25];
     if (active) {
 #pragma unroll
@@ -96,41 +130,45 @@ __global__ __launch_bounds__(kIThreads) void istft_kernel(
     }
     __syncthreads();
     if (active) {
-      const float2* w2 = reinterpret_cast<const float2*>(window_inv);
+      const float sc = 1.0f / (float)kHalf;            // inverse-transform scale
 #pragma unroll
       for (int c = 0; c < 5; ++c)
 #pragma unroll
         for (int d = 0; d < 5; ++d) {
           const int n = q + 8 * (c + 5 * d);
-          const float2 w = w2[n];
-          Y[f * kHalf + n] = make_float2(y[5 * c + d].x * w.x, y[5 * c + d].y * w.y);
+          const float2 w = *reinterpret_cast<const float2*>(win + 2 * n);
+          Y[f * kHalf + n] = make_float2(y[5 * c + d].x * (w.x * sc), y[5 * c + d].y * (w.y * sc));
         }
     }
   }
   __syncthreads();
 
-  // ---- overlap-add + envelope + masked square sum
+  // ---- overlap-add + envelope + masked square sum; the loop contains LDS reads and global STORES only
   const float* xs = reinterpret_cast<const float*>(Y);
   const int len_b = lengths ? (int)min((int64_t)n_out, lengths[b]) : 0;
   float ss = 0.f;
-  for (int o = tid; o < kISpan; o += kIThreads) {
+#pragma unroll 2
+  for (int r = 0; r < kIOlaIters; ++r) {
+    const int o = tid + kIThreads * r;
     const int n = o0 + o;
-    if (n >= n_out) break;
-    const int p = n + kHalf;                       // padded index
-    const int f_last = min(p / kHop, F - 1);
-    float acc = 0.f, env = 0.f;
+    if (o < kISpan && n < n_out) {
+      const int p = n + kHalf;                       // padded index
+      const int f_last = min(p / kHop, F - 1);
+      float acc = 0.f, env = 0.f;
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {
-      const int f = f_last - t;
-      const int r = p - f * kHop;
-      if (f >= 0 && r < kNfft) {
-        acc += xs[(f - fbase) * kNfft + r];
-        env += window_sq[r];
+      for (int t = 0; t < 3; ++t) {
+        const int f = f_last - t;
+        const int rr = p - f * kHop;
+        if (f >= 0 && rr < kNfft) {
+          acc += xs[(f - fbase) * kNfft + rr];
+          const float w = win[rr];
+          env = fmaf(w, w, env);
+        }
       }
+      const float v = acc / env;
+      wav[(size_t)b * wav_stride + n] = v;
+      if (n < len_b) ss = fmaf(v, v, ss);
     }
-    const float v = acc / env;
-    wav[(size_t)b * wav_stride + n] = v;
-    if (n < len_b) ss = fmaf(v, v, ss);
   }
   // right-pad region [n_out, wav_stride) -- zero-filled by the last workgroup of the row
   if (blockIdx.x == gridDim.x - 1)
@@ -199,7 +237,7 @@ extern "C" int se_istft_f32(const se_plan* plan, const float* power, const float
   dim3 grid((n_out + se::kISpan - 1) / se::kISpan, B);
   se::ProfScope prof(se::kProfIstft, (double)B * (8.0 * F * se::kBins + 4.0 * n_out), st);
   hipLaunchKernelGGL(se::istft_kernel, grid, dim3(se::kIThreads), 0, st, power, phase, F, 1.0f / linear_power,
-                     plan->d_window_inv, plan->d_window_sq, plan->d_tw200, plan->d_tw400, wav_out, wav_stride, lengths, sumsq_out);
+                     plan->d_window, plan->d_tw400, wav_out, wav_stride, lengths, sumsq_out);
   SE_LAUNCH_CHECK();
   return SE_OK;
 }

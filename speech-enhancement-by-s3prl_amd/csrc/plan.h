@@ -24,7 +24,7 @@ struct se_plan {
   float* d_window_inv;  // [400]   window / 200 (inverse transform scale folded in)
   float* d_window_sq;   // [400]   window^2
   float2* d_tw200;      // [200]   (cos, sin)(2 pi t / 200)
-  float2* d_tw400;      // [101]   (cos, sin)(2 pi k / 400)
+  float2* d_tw400;      // [200]   (cos, sin)(2 pi k / 400), k < 200 (also serves W200^t = tw400[2t] / -tw400[2t-200])
   int* d_mel_start;     // [kMelMax]
   int* d_mel_len;       // [kMelMax]
   float* d_mel_w;       // [kMelMax][kMelMaxW]

@@ -92,9 +92,9 @@ extern "C" int se_plan_create(const se_geometry* geom, se_plan** out) {
     winv[n] = p->h_window[n] / (float)se::kHalf;
     wsq[n] = p->h_window[n] * p->h_window[n];
   }
-  std::vector<float2> tw200(se::kHalf), tw400(101);
+  std::vector<float2> tw200(se::kHalf), tw400(se::kHalf);
   for (int t = 0; t < se::kHalf; ++t) tw200[t] = make_float2((float)cos(2.0 * M_PI * t / 200.0), (float)sin(2.0 * M_PI * t / 200.0));
-  for (int k = 0; k <= 100; ++k) tw400[k] = make_float2((float)cos(2.0 * M_PI * k / 400.0), (float)sin(2.0 * M_PI * k / 400.0));
+  for (int k = 0; k < se::kHalf; ++k) tw400[k] = make_float2((float)cos(2.0 * M_PI * k / 400.0), (float)sin(2.0 * M_PI * k / 400.0));
   std::vector<int> mstart(se::kMelMax, 0), mlen(se::kMelMax, 0);
   std::vector<float> mw((size_t)se::kMelMax * se::kMelMaxW, 0.f);
   for (int m = 0; m < geom->n_mels; ++m) {
@@ -127,7 +127,7 @@ extern "C" int se_plan_create(const se_geometry* geom, se_plan** out) {
   // one blob, 256-B aligned sections
   auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
   size_t o_win = 0, o_winv = o_win + al(400 * 4), o_wsq = o_winv + al(400 * 4), o_t200 = o_wsq + al(400 * 4),
-         o_t400 = o_t200 + al(200 * 8), o_ms = o_t400 + al(101 * 8), o_ml = o_ms + al(se::kMelMax * 4),
+         o_t400 = o_t200 + al(200 * 8), o_ms = o_t400 + al(200 * 8), o_ml = o_ms + al(se::kMelMax * 4),
          o_mw = o_ml + al(se::kMelMax * 4), total = o_mw + al(mw.size() * 4);
   e = hipMalloc(&p->d_blob, total);
   if (e != hipSuccess) {
@@ -147,7 +147,7 @@ extern "C" int se_plan_create(const se_geometry* geom, se_plan** out) {
   SE_HIP(hipMemcpy(p->d_window_inv, winv.data(), 400 * 4, hipMemcpyHostToDevice));
   SE_HIP(hipMemcpy(p->d_window_sq, wsq.data(), 400 * 4, hipMemcpyHostToDevice));
   SE_HIP(hipMemcpy(p->d_tw200, tw200.data(), 200 * 8, hipMemcpyHostToDevice));
-  SE_HIP(hipMemcpy(p->d_tw400, tw400.data(), 101 * 8, hipMemcpyHostToDevice));
+  SE_HIP(hipMemcpy(p->d_tw400, tw400.data(), 200 * 8, hipMemcpyHostToDevice));
   SE_HIP(hipMemcpy(p->d_mel_start, mstart.data(), se::kMelMax * 4, hipMemcpyHostToDevice));
   SE_HIP(hipMemcpy(p->d_mel_len, mlen.data(), se::kMelMax * 4, hipMemcpyHostToDevice));
   SE_HIP(hipMemcpy(p->d_mel_w, mw.data(), mw.size() * 4, hipMemcpyHostToDevice));

@@ -1,22 +1,29 @@
 // stft.hip -- rows A1+A2(+A3): framing + Hann + 400-point real FFT -> power / phase / complex / raw mel.
 //
-// One workgroup (256 threads) transforms FR = 32 consecutive frames of one (utterance, channel):
-//   fill   : z[n] = (w[2n] x[2n], w[2n+1] x[2n+1]) straight from global (reflect padding at the edges);
-//            neighbouring frames overlap by 60 %, the re-reads are L1/L2 hits, HBM sees each sample once
+// One workgroup (256 threads) transforms FR = 30 consecutive frames of one (utterance, channel):
+//   fill   : z[n] = (w[2n] x[2n], w[2n+1] x[2n+1]); all of a thread's global loads are issued back to back (one wait),
+//            neighbouring frames overlap by 60 %: the re-reads are L1/L2 hits, HBM sees each sample once
 //   pass A : 25 in-place radix-8 butterflies per frame          (fft200.h)
 //   pass B : 8 in-register 25-point DFTs per frame
-//   post   : X[k], X[200-k] from Z[k], Z[200-k]; power / phase written time-major -- the 32 frames of a
-//            workgroup are ONE contiguous span of (B, F, K), so stores are perfectly coalesced
-//   mel    : sparse HTK triangles over the power kept in LDS, written feature-major (B, n_mels, F)
-// LDS: 32 x 200 float2 = 51 200 B  -> 3 workgroups per CU.  Bound: HBM (2 249 608 B per utterance-channel).
+//   post   : X[k], X[200-k] from Z[k], Z[200-k]; power / phase written time-major -- the frames of a workgroup
+//            are ONE contiguous span of (B, F, K).  The loop contains stores only (all tables live in LDS): a global
+//            load inside it would force vmcnt(0) per iteration, which on gfx950 also drains the previous iteration's
+//            stores (one in-order counter) and serialises the loop on the HBM write latency.
+//   mel    : sparse HTK triangles over the power kept in LDS; the filter table is staged into the unused .y halves
+//            of the power slots; written feature-major (B, n_mels, F)
+// LDS: 30 x 200 float2 + twiddles + window = 51 200 B -> 3 workgroups per CU.  Bound: HBM (2 249 608 B per
+// utterance-channel).
 #include "plan.h"
 #include "prof.h"
 #include "fft200.h"
 
 namespace se {
 
-constexpr int kFR = 32;          // frames per workgroup
+constexpr int kFR = 30;          // frames per workgroup: 30 x 25 = 750 pass-A items = 3 full rounds of 256 threads (31 would need a
+                                 // 4th, nearly empty round), 30 x 8 = 240 pass-B items; LDS 51.2 KB -> 3 workgroups / CU
 constexpr int kThreads = 256;
+constexpr int kFillIters = (kFR * kHalf + kThreads - 1) / kThreads;     // 25
+constexpr int kPostIters = (kFR * 101 + kThreads - 1) / kThreads;       // 13
 
 __device__ __forceinline__ int reflect(int i, int T) {
   // numpy / torch 'reflect' (no edge repeat); valid for |overshoot| < T
@@ -25,13 +32,36 @@ __device__ __forceinline__ int reflect(int i, int T) {
   return i;
 }
 
+// atan2 with the libm minimax polynomial for atan on [0, 1] but a one-instruction reciprocal range reduction and no
+// inf / nan / denormal special cases (inputs are finite FFT outputs): ~20 instructions instead of ~40.
+// |error| <= ~2e-7 rad.  (0, 0) -> 0 (libm returns +-pi for x = -0; the phase of a zero-magnitude bin is immaterial).
+__device__ __forceinline__ float fast_atan2(float y, float x) {
+  const float ax = fabsf(x), ay = fabsf(y);
+  const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+  float a = mn * __builtin_amdgcn_rcpf(mx);
+  a = (mx == 0.f) ? 0.f : a;
+  const float s = a * a;
+  float p = fmaf(s, 0.00264226692f, -0.0152803790f);      // 0x3b2d2a58, 0xbc7a590c
+  p = fmaf(s, p, 0.0414993092f);                          // 0x3d29fb3f
+  p = fmaf(s, p, -0.0741364285f);                         // 0xbd97d4d7
+  p = fmaf(s, p, 0.106052168f);                           // 0x3dd931b2
+  p = fmaf(s, p, -0.141971514f);                          // 0xbe1160e6
+  p = fmaf(s, p, 0.199923798f);                           // 0x3e4cb8bf
+  p = fmaf(s, p, -0.333331168f);                          // 0xbeaaaa62
+  float r = fmaf(a * s, p, a);
+  r = (ay > ax) ? (1.57079632679f - r) : r;
+  r = (x < 0.f) ? (3.14159265359f - r) : r;
+  return copysignf(r, y);
+}
+
 __global__ __launch_bounds__(kThreads) void stft_kernel(
     const float* __restrict__ wavs, int C, int T, int channel, int F,
-    const float* __restrict__ window, const float2* __restrict__ tw200g, const float2* __restrict__ tw400,
+    const float* __restrict__ window, const float2* __restrict__ tw400g,
     const int* __restrict__ mel_start, const int* __restrict__ mel_len, const float* __restrict__ mel_w, int n_mels,
     float* __restrict__ power, float* __restrict__ phase, float* __restrict__ complx, float* __restrict__ mel) {
   __shared__ float2 Y[kFR * kHalf];
-  __shared__ float2 tw200[kHalf];
+  __shared__ float2 tw[kHalf];        // (cos, sin)(2 pi k / 400), k < 200;  W200^t = tw[2t] (t < 100), -tw[2t-200] otherwise
+  __shared__ float win[kNfft];
 
   const int tid = threadIdx.x;
   const int b = blockIdx.y;
@@ -39,36 +69,68 @@ __global__ __launch_bounds__(kThreads) void stft_kernel(
   const int nf = min(kFR, F - f0);
   const float* x = wavs + ((size_t)b * C + channel) * (size_t)T;
 
-  if (tid < kHalf) tw200[tid] = tw200g[tid];
+  if (tid < kHalf) tw[tid] = tw400g[tid];
+  for (int i = tid; i < kNfft; i += kThreads) win[i] = window[i];
 
-  // ---- fill: windowed samples as packed complex
+  // ---- fill: windowed samples as packed complex.  item = tid + 256 r -> (frame, n) advanced incrementally.
   const bool interior = (f0 * kHop - kHalf >= 0) && ((f0 + nf - 1) * kHop + kHalf <= T);
-  const float2* win2 = reinterpret_cast<const float2*>(window);
   if (interior) {
-    for (int it = tid; it < nf * kHalf; it += kThreads) {
-      const int f = it / kHalf, n = it - f * kHalf;
-      const float2 xv = *reinterpret_cast<const float2*>(x + (f0 + f) * kHop - kHalf + 2 * n);
-      const float2 w = win2[n];
-      Y[it] = make_float2(xv.x * w.x, xv.y * w.y);
+    float2 xv[kFillIters];
+    {
+      int f = tid / kHalf, n = tid - f * kHalf;          // one division per thread
+#pragma unroll
+      for (int r = 0; r < kFillIters; ++r) {
+        xv[r] = (f < nf) ? *reinterpret_cast<const float2*>(x + (f0 + f) * kHop - kHalf + 2 * n) : make_float2(0.f, 0.f);
+        n += kThreads - kHalf;                            // 256 = 200 + 56
+        f += 1;
+        if (n >= kHalf) { n -= kHalf; f += 1; }
+      }
+    }
+    __syncthreads();                                      // window table visible
+    {
+      int f = tid / kHalf, n = tid - f * kHalf;
+#pragma unroll
+      for (int r = 0; r < kFillIters; ++r) {
+        if (f < nf) {
+          const float2 w = *reinterpret_cast<const float2*>(win + 2 * n);
+          Y[f * kHalf + n] = make_float2(xv[r].x * w.x, xv[r].y * w.y);
+        }
+        n += kThreads - kHalf;
+        f += 1;
+        if (n >= kHalf) { n -= kHalf; f += 1; }
+      }
     }
   } else {
+    __syncthreads();
     for (int it = tid; it < nf * kHalf; it += kThreads) {
       const int f = it / kHalf, n = it - f * kHalf;
       const int s = (f0 + f) * kHop - kHalf + 2 * n;
-      const float2 w = win2[n];
-      Y[it] = make_float2(x[reflect(s, T)] * w.x, x[reflect(s + 1, T)] * w.y);
+      Y[it] = make_float2(x[reflect(s, T)] * win[2 * n], x[reflect(s + 1, T)] * win[2 * n + 1]);
     }
   }
   __syncthreads();
 
-  // ---- pass A
+  // ---- pass A (twiddle W200^(j q) from the 400-table)
   for (int it = tid; it < nf * 25; it += kThreads) {
     const int f = it / 25, j = it - f * 25;
-    fft200_pass_a<-1>(Y + f * kHalf, j, tw200);
+    float2* frame = Y + f * kHalf;
+    float2 v[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) v[m] = frame[25 * m + j];
+    fft8<-1>(v);
+#pragma unroll
+    for (int q = 1; q < 8; ++q) {
+      const int t2 = 2 * j * q;                            // < 400
+      float2 w = tw[t2 < kHalf ? t2 : t2 - kHalf];
+      const float sg = t2 < kHalf ? 1.f : -1.f;
+      v[q] = cmul(v[q], make_float2(sg * w.x, -sg * w.y)); // forward: exp(-i ...)
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) frame[25 * q + j] = v[q];
   }
   __syncthreads();
 
-  // ---- pass B (8 items per frame; 32 frames x 8 = 256 threads)
+  // ---- pass B (8 items per frame)
   {
     const int f = tid >> 3, q = tid & 7;
     float2 y[25];
@@ -88,53 +150,82 @@ __global__ __launch_bounds__(kThreads) void stft_kernel(
   }
   __syncthreads();
 
-  // ---- post: pairs (k, 200-k), k = 0..100
+  // ---- post: pairs (k, 200-k), k = 0..100; stores only
   const size_t obase = ((size_t)b * F + f0) * kBins;
-  for (int it = tid; it < nf * 101; it += kThreads) {
-    const int f = it / 101, k = it - f * 101;
-    float2* Z = Y + f * kHalf;
-    const float2 zk = Z[k];
-    const float2 zn = Z[k == 0 ? 0 : kHalf - k];
-    // E = (zk + conj(zn))/2 ; O = (zk - conj(zn))/(2i) ; P = W^k O, W^k = (c, -s)
-    const float2 E = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
-    const float2 O = make_float2(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
-    const float2 w = tw400[k];
-    const float2 P = make_float2(O.x * w.x + O.y * w.y, O.y * w.x - O.x * w.y);
-    const float2 X1 = make_float2(E.x + P.x, E.y + P.y);          // X[k]
-    const float2 X2 = make_float2(E.x - P.x, -(E.y - P.y));       // X[200-k] = conj(E - P)
-    const float p1 = X1.x * X1.x + X1.y * X1.y;
-    const float p2 = X2.x * X2.x + X2.y * X2.y;
-    const size_t o1 = obase + (size_t)f * kBins + k;
-    const size_t o2 = obase + (size_t)f * kBins + (kHalf - k);
-    if (power) {
-      power[o1] = p1;
-      if (k != 100) power[o2] = p2;
+  {
+    int f = tid / 101, k = tid - f * 101;
+#pragma unroll 1
+    for (int r = 0; r < kPostIters; ++r) {
+      if (f < nf) {
+        float2* Z = Y + f * kHalf;
+        const float2 zk = Z[k];
+        const float2 zn = Z[k == 0 ? 0 : kHalf - k];
+        // E = (zk + conj(zn))/2 ; O = (zk - conj(zn))/(2i) ; P = W^k O, W^k = (c, -s)
+        const float2 E = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
+        const float2 O = make_float2(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
+        const float2 w = tw[k];
+        const float2 P = make_float2(O.x * w.x + O.y * w.y, O.y * w.x - O.x * w.y);
+        const float2 X1 = make_float2(E.x + P.x, E.y + P.y);          // X[k]
+        const float2 X2 = make_float2(E.x - P.x, -(E.y - P.y));       // X[200-k] = conj(E - P)
+        const float p1 = X1.x * X1.x + X1.y * X1.y;
+        const float p2 = X2.x * X2.x + X2.y * X2.y;
+        const size_t o1 = obase + (size_t)f * kBins + k;
+        const size_t o2 = o1 + (kHalf - 2 * k);
+        if (power) {
+          power[o1] = p1;
+          if (k != 100) power[o2] = p2;
+        }
+        if (phase) {
+          phase[o1] = fast_atan2(X1.y, X1.x);
+          if (k != 100) phase[o2] = fast_atan2(X2.y, X2.x);
+        }
+        if (complx) {
+          reinterpret_cast<float2*>(complx)[o1] = X1;
+          if (k != 100) reinterpret_cast<float2*>(complx)[o2] = X2;
+        }
+        // power back into LDS for the mel stage: bin k -> Z[k].x ; bin 200 has zero weight in every HTK filter
+        Z[k].x = p1;
+        if (k != 0 && k != 100) Z[kHalf - k].x = p2;
+      }
+      k += kThreads - 2 * 101;                              // 256 = 2 * 101 + 54
+      f += 2;
+      if (k >= 101) { k -= 101; f += 1; }
     }
-    if (phase) {
-      phase[o1] = atan2f(X1.y, X1.x);
-      if (k != 100) phase[o2] = atan2f(X2.y, X2.x);
-    }
-    if (complx) {
-      reinterpret_cast<float2*>(complx)[o1] = X1;
-      if (k != 100) reinterpret_cast<float2*>(complx)[o2] = X2;
-    }
-    // power back into LDS for the mel stage: bin k -> Z[k].x ; bin 200 has zero weight in every HTK filter
-    Z[k].x = p1;
-    if (k != 0 && k != 100) Z[kHalf - k].x = p2;
   }
 
   if (mel == nullptr) return;
   __syncthreads();
-  for (int it = tid; it < n_mels * kFR; it += kThreads) {
-    const int m = it / kFR, fl = it - m * kFR;
+  // ---- mel: stage the sparse filter table into the free .y halves of the power slots (one batched load per thread)
+  float* Yf = reinterpret_cast<float*>(Y);
+  {
+    float wv[5];
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+      const int i = tid + kThreads * r;                     // < 1280 = 40 x 32
+      wv[r] = (i < n_mels * kMelMaxW) ? mel_w[i] : 0.f;
+    }
+    const int ms = (tid < n_mels) ? mel_start[tid] : 0, ml = (tid < n_mels) ? mel_len[tid] : 0;
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+      const int i = tid + kThreads * r;
+      if (i < kMelMax * kMelMaxW) Yf[2 * i + 1] = wv[r];
+    }
+    if (tid < kMelMax) {
+      Yf[2 * (kMelMax * kMelMaxW + tid) + 1] = __int_as_float(ms);
+      Yf[2 * (kMelMax * kMelMaxW + kMelMax + tid) + 1] = __int_as_float(ml);
+    }
+  }
+  __syncthreads();
+  for (int it = tid; it < n_mels * 32; it += kThreads) {
+    const int m = it >> 5, fl = it & 31;                    // lane <-> frame: conflict-free power reads (stride 400 dwords)
     if (fl >= nf) continue;
-    const int st = mel_start[m], len = mel_len[m];
-    const float* wrow = mel_w + m * kMelMaxW;
+    const int st = __float_as_int(Yf[2 * (kMelMax * kMelMaxW + m) + 1]);
+    const int len = __float_as_int(Yf[2 * (kMelMax * kMelMaxW + kMelMax + m) + 1]);
     float acc = 0.f;
     for (int i = 0; i < len; ++i) {
       const int k = st + i;
-      const float pk = (k < kHalf) ? Y[fl * kHalf + k].x : 0.f;
-      acc = fmaf(wrow[i], pk, acc);
+      const float pk = (k < kHalf) ? Yf[2 * (fl * kHalf + k)] : 0.f;
+      acc = fmaf(Yf[2 * (m * kMelMaxW + i) + 1], pk, acc);
     }
     mel[((size_t)b * n_mels + m) * F + f0 + fl] = acc;
   }
@@ -153,7 +244,7 @@ extern "C" int se_stft_f32(const se_plan* plan, const float* wavs, int B, int C,
   // algorithmic bytes: 4 T in + 4 F K per written plane
   se::ProfScope prof(se::kProfStft, (double)B * (4.0 * T + 4.0 * F * se::kBins * ((power != nullptr) + (phase != nullptr) + 2 * (complx != nullptr)) + (mel ? 4.0 * F * plan->geom.n_mels : 0.0)), se::as_stream(stream));
   hipLaunchKernelGGL(se::stft_kernel, grid, dim3(se::kThreads), 0, se::as_stream(stream), wavs, C, T, channel, F,
-                     plan->d_window, plan->d_tw200, plan->d_tw400, plan->d_mel_start, plan->d_mel_len, plan->d_mel_w,
+                     plan->d_window, plan->d_tw400, plan->d_mel_start, plan->d_mel_len, plan->d_mel_w,
                      plan->geom.n_mels, power, phase, complx, mel);
   SE_LAUNCH_CHECK();
   return SE_OK;
