@@ -41,8 +41,9 @@ __global__ __launch_bounds__(kIThreads) void istft_kernel(
   const int flo = max(fbase, 0);
   const int fhi = min(fbase + kIFR, F);               // exclusive
   const int nfr = fhi - flo;
-  if (tid < kHalf) tw[tid] = tw400g[tid];
-  for (int i = tid; i < kNfft; i += kIThreads) win[i] = window[i];
+  // table loads are issued together with the spectrum loads below and written to LDS afterwards (one memory latency)
+  const float2 twv = tw400g[min(tid, kHalf - 1)];
+  const float wv0 = window[tid], wv1 = window[min(tid + kIThreads, kNfft - 1)];
 
   // ---- load + polar: item (f, k), k = 0..200, contiguous in (B, F, K); all global loads issued before any use
   {
@@ -56,6 +57,9 @@ __global__ __launch_bounds__(kIThreads) void istft_kernel(
       pv[r] = ok ? power[gbase + it] : 0.f;
       hv[r] = ok ? phase[gbase + it] : 0.f;
     }
+    if (tid < kHalf) tw[tid] = twv;
+    win[tid] = wv0;
+    if (tid + kIThreads < kNfft) win[tid + kIThreads] = wv1;
     int fl = tid / kBins, k = tid - fl * kBins;
 #pragma unroll
     for (int r = 0; r < kILoadIters; ++r) {

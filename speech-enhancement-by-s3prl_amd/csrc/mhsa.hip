@@ -14,6 +14,7 @@
 // K / V tiles: global -> registers -> LDS, double buffered, XOR-swizzled 16-B chunks (conflict-free b128 and
 // tr_b16 reads).  Keys >= lengths[b] are excluded (the reference adds -10000, i.e. exp() == 0 in fp32).
 // Bound: MFMA (4 T^2 64 flop per head) -- with d = 64 the exp stream (v_exp_f32) is the co-limiter.
+#include <stdlib.h>
 #include "common.h"
 #include "prof.h"
 #include "bf16.h"
@@ -33,7 +34,8 @@ __device__ __forceinline__ int kv_off(int key, int ch) {
   return key * 128 + ((ch ^ f) << 4);
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void mhsa_fwd_kernel(
+template <int OCC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void mhsa_fwd_kernel(
     const uint16_t* __restrict__ qkv, const int32_t* __restrict__ lengths, int T, int H, uint16_t* __restrict__ ctx) {
   __shared__ __attribute__((aligned(16))) char smem[2 * 2 * kAK * kHD * 2];   // 2 buffers x (K, V) x 8 KiB = 32 KiB
 
@@ -84,95 +86,101 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
   float m_run = -INFINITY, l_run = 0.f;
   const float c = 0.125f * 1.44269504088896340736f;     // 1/sqrt(64) * log2(e)
+  typedef float f2 __attribute__((ext_vector_type(2)));
+
+  // ---- loop-invariant LDS byte offsets (buffer / key-block / k-step parts are compile-time immediates below)
+  //   K fragment (b128): row l31 (+32 for key block 1 = +4096 B), logical chunk 2 s + hh -> 4 per-lane values
+  //   V^T fragment (tr_b16): lane addresses key tq + 4 hh (+8 for elements 4..7), columns 32 dblk + 16 g1 + 4 tp;
+  //   adding 16 s + 32 kb to the key leaves the swizzle term unchanged (it reads key bits 1-3) -> +2048 s + 4096 kb
+  int koff[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) koff[s] = kv_off(l31, 2 * s + hh);
+  const int tq = (lane & 15) >> 2, tp = lane & 3, g1 = (lane >> 4) & 1;
+  int voff[2][2];                     // [dblk][lo / hi]
+#pragma unroll
+  for (int dblk = 0; dblk < 2; ++dblk) {
+    const int dcol = dblk * 32 + 16 * g1 + 4 * tp;
+    voff[dblk][0] = 8192 + kv_off(4 * hh + tq, dcol >> 3) + (dcol & 7) * 2;
+    voff[dblk][1] = 8192 + kv_off(4 * hh + tq + 8, dcol >> 3) + (dcol & 7) * 2;
+  }
 
   SE_A_ISSUE(0);
   SE_A_WRITE(0);
   __syncthreads();
 
-  for (int kt = 0; kt < nkt; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nkt) SE_A_ISSUE(kt + 1);
-    const char* k_s = smem + cur * 16384;
-    const char* v_s = k_s + 8192;
-
-    // ---- S^T = K Q^T : two 32-key blocks x 4 k-steps over d
-    f32x16 s0, s1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const bf16x8 ka = *reinterpret_cast<const bf16x8*>(k_s + kv_off(l31, 2 * s + hh));
-      const bf16x8 kb = *reinterpret_cast<const bf16x8*>(k_s + kv_off(32 + l31, 2 * s + hh));
-      s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[s], s0, 0, 0, 0);
-      s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb, qf[s], s1, 0, 0, 0);
-    }
-    // ---- key mask (only the tile that crosses `len`); accumulator row map: key = (r&3) + 8 (r>>2) + 4 hh
-    if ((kt + 1) * kAK > len) {
-      const int kbase = kt * kAK + 4 * hh;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = kbase + (r & 3) + 8 * (r >> 2);
-        if (key >= len) s0[r] = -INFINITY;
-        if (key + 32 >= len) s1[r] = -INFINITY;
-      }
-    }
-    // ---- online softmax (this lane: 32 of the 64 keys of query row l31; partner lane^32 holds the rest)
-    float mx = s0[0];
-#pragma unroll
-    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s0[r]);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s1[r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float m_new = fmaxf(m_run, mx);          // finite: key 0 is always valid and lives in tile 0
-    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-    const float mc = m_new * c;
-    float rs = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      s0[r] = __builtin_amdgcn_exp2f(fmaf(s0[r], c, -mc));
-      s1[r] = __builtin_amdgcn_exp2f(fmaf(s1[r], c, -mc));
-      rs += s0[r] + s1[r];
-    }
-    l_run = fmaf(l_run, alpha, rs);
-    m_run = m_new;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
-
-    // ---- P fragments: registers 8 s .. 8 s + 7 of block kb -> k-step (kb, s)
-    bf16x8 pf[2][2];
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        pf[0][s][j] = (__bf16)s0[8 * s + j];
-        pf[1][s][j] = (__bf16)s1[8 * s + j];
-      }
-
-    // ---- O^T += V^T P^T : A operand = V^T via transposed LDS reads (4 consecutive keys x column d per lane)
-    //      lane group g = lane>>4: keys key0 + (lane&15)/4, columns d0 + 4 ((lane&15)&3); d0 = 32 dblk + 16 (g&1)
-    const int tq = (lane & 15) >> 2, tp = lane & 3;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const int key0 = kb * 32 + 16 * s + 4 * hh + tq;          // row this lane ADDRESSES (elements j = 0..3)
-#pragma unroll
-        for (int dblk = 0; dblk < 2; ++dblk) {
-          const int dcol = dblk * 32 + 16 * ((lane >> 4) & 1) + 4 * tp;     // first of the 4 columns this lane addresses
-          const int ch = dcol >> 3, sub = (dcol & 7) * 2;
-          const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-              (__attribute__((address_space(3))) bf16x4*)(v_s + kv_off(key0, ch) + sub));
-          const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-              (__attribute__((address_space(3))) bf16x4*)(v_s + kv_off(key0 + 8, ch) + sub));
-          const bf16x8 va = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-          if (dblk == 0) o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, pf[kb][s], o0, 0, 0, 0);
-          else o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, pf[kb][s], o1, 0, 0, 0);
-        }
-      }
-
-    if (kt + 1 < nkt) SE_A_WRITE(cur ^ 1);
-    __syncthreads();
+#define SE_A_TILE(CUR)                                                                                                     \
+  {                                                                                                                        \
+    if (kt + 1 < nkt) SE_A_ISSUE(kt + 1);                                                                                  \
+    const char* t_s = smem + (CUR) * 16384;                                                                                \
+    f32x16 s0, s1;                                                                                                         \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }                                           \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                                        \
+      const bf16x8 ka = *reinterpret_cast<const bf16x8*>(t_s + koff[s]);                                                   \
+      const bf16x8 kb_ = *reinterpret_cast<const bf16x8*>(t_s + koff[s] + 4096);                                           \
+      s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[s], s0, 0, 0, 0);                                                \
+      s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb_, qf[s], s1, 0, 0, 0);                                               \
+    }                                                                                                                      \
+    if ((kt + 1) * kAK > len) {                                                                                            \
+      const int kbase = kt * kAK + 4 * hh;                                                                                 \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                                     \
+        const int key = kbase + (r & 3) + 8 * (r >> 2);                                                                    \
+        if (key >= len) s0[r] = -INFINITY;                                                                                 \
+        if (key + 32 >= len) s1[r] = -INFINITY;                                                                            \
+      }                                                                                                                    \
+    }                                                                                                                      \
+    float mx = fmaxf(s0[0], s1[0]);                                                                                        \
+    _Pragma("unroll") for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s0[r], s1[r]));                                    \
+    mx = fmaxf(mx, __shfl_xor(mx, 32));                                                                                    \
+    const float m_new = fmaxf(m_run, mx);                                                                                  \
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);                                                       \
+    const f2 c2 = {c, c}, mc2 = {-m_new * c, -m_new * c};                                                                  \
+    f2 rs2 = {0.f, 0.f};                                                                                                   \
+    _Pragma("unroll") for (int r = 0; r < 16; r += 2) {                                                                    \
+      f2 a0 = {s0[r], s0[r + 1]}, a1 = {s1[r], s1[r + 1]};                                                                 \
+      a0 = __builtin_elementwise_fma(a0, c2, mc2);                                                                         \
+      a1 = __builtin_elementwise_fma(a1, c2, mc2);                                                                         \
+      a0.x = __builtin_amdgcn_exp2f(a0.x); a0.y = __builtin_amdgcn_exp2f(a0.y);                                            \
+      a1.x = __builtin_amdgcn_exp2f(a1.x); a1.y = __builtin_amdgcn_exp2f(a1.y);                                            \
+      rs2 += a0 + a1;                                                                                                      \
+      s0[r] = a0.x; s0[r + 1] = a0.y; s1[r] = a1.x; s1[r + 1] = a1.y;                                                      \
+    }                                                                                                                      \
+    l_run = fmaf(l_run, alpha, rs2.x + rs2.y);                                                                             \
+    m_run = m_new;                                                                                                         \
+    if (__any(alpha != 1.0f)) {                                                                                            \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }                                   \
+    }                                                                                                                      \
+    bf16x8 pf[2][2];                                                                                                       \
+    _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                                          \
+      _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                                      \
+        pf[0][s][j] = (__bf16)s0[8 * s + j];                                                                               \
+        pf[1][s][j] = (__bf16)s1[8 * s + j];                                                                               \
+      }                                                                                                                    \
+    _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                                                       \
+      _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                                      \
+        _Pragma("unroll") for (int dblk = 0; dblk < 2; ++dblk) {                                                           \
+          const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(                                                      \
+              (__attribute__((address_space(3))) bf16x4*)(t_s + voff[dblk][0] + kb * 4096 + s * 2048));                    \
+          const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(                                                      \
+              (__attribute__((address_space(3))) bf16x4*)(t_s + voff[dblk][1] + kb * 4096 + s * 2048));                    \
+          const bf16x8 va = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};                                      \
+          if (dblk == 0) o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, pf[kb][s], o0, 0, 0, 0);                         \
+          else o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, pf[kb][s], o1, 0, 0, 0);                                   \
+        }                                                                                                                  \
+      }                                                                                                                    \
+    if (kt + 1 < nkt) SE_A_WRITE((CUR) ^ 1);                                                                               \
+    __syncthreads();                                                                                                       \
   }
+
+  // unrolled by two so the double-buffer offset is an immediate
+  int kt = 0;
+  for (; kt + 1 < nkt; kt += 2) {
+    SE_A_TILE(0)
+    ++kt;
+    SE_A_TILE(1)
+    --kt;
+  }
+  if (kt < nkt) SE_A_TILE(0)
+#undef SE_A_TILE
 
   // ---- epilogue: O / l ; lane holds query q0 + l31, d = 32 dblk + (r&3) + 8 (r>>2) + 4 hh
   const float l_tot = l_run + __shfl_xor(l_run, 32);
@@ -198,7 +206,13 @@ extern "C" int se_mhsa_fwd_bf16(const uint16_t* qkv, const int32_t* lengths, int
   const int H = heads * se::kHD;
   dim3 grid((T + se::kAQ - 1) / se::kAQ, heads, B);
   se::ProfScope prof(se::kProfMhsa, 4.0 * B * (double)heads * T * (double)T * se::kHD, se::as_stream(stream));
-  hipLaunchKernelGGL(se::mhsa_fwd_kernel, grid, dim3(256), 0, se::as_stream(stream), qkv, lengths, T, H, ctx);
+  static int occ = -1;
+  if (occ < 0) {
+    const char* e = getenv("SE_AMD_MHSA_OCC");
+    occ = e ? atoi(e) : 3;
+  }
+  if (occ == 2) hipLaunchKernelGGL(se::mhsa_fwd_kernel<2>, grid, dim3(256), 0, se::as_stream(stream), qkv, lengths, T, H, ctx);
+  else hipLaunchKernelGGL(se::mhsa_fwd_kernel<3>, grid, dim3(256), 0, se::as_stream(stream), qkv, lengths, T, H, ctx);
   SE_LAUNCH_CHECK();
   return SE_OK;
 }

@@ -5,14 +5,16 @@
 //            neighbouring frames overlap by 60 %: the re-reads are L1/L2 hits, HBM sees each sample once
 //   pass A : 25 in-place radix-8 butterflies per frame          (fft200.h)
 //   pass B : 8 in-register 25-point DFTs per frame
-//   post   : X[k], X[200-k] from Z[k], Z[200-k]; power / phase written time-major -- the frames of a workgroup
-//            are ONE contiguous span of (B, F, K).  The loop contains stores only (all tables live in LDS): a global
-//            load inside it would force vmcnt(0) per iteration, which on gfx950 also drains the previous iteration's
-//            stores (one in-order counter) and serialises the loop on the HBM write latency.
+//   post   : X[k], X[200-k] from Z[k], Z[200-k]; (power, atan2 phase) written IN PLACE into the LDS slots
+//   write  : the frames of a workgroup are ONE contiguous span of (B, F, K) in each plane: streamed out with aligned
+//            16-B stores.  No global load sits in any output loop (all tables live in LDS): a load there would force
+//            vmcnt(0) per iteration, which on gfx950 also drains the previous iteration's stores (one in-order counter)
+//            and serialises the loop on the HBM write latency.
 //   mel    : sparse HTK triangles over the power kept in LDS; the filter table is staged into the unused .y halves
 //            of the power slots; written feature-major (B, n_mels, F)
 // LDS: 30 x 200 float2 + twiddles + window = 51 200 B -> 3 workgroups per CU.  Bound: HBM (2 249 608 B per
 // utterance-channel).
+#include <stdlib.h>
 #include "plan.h"
 #include "prof.h"
 #include "fft200.h"
@@ -58,19 +60,27 @@ __global__ __launch_bounds__(kThreads) void stft_kernel(
     const float* __restrict__ wavs, int C, int T, int channel, int F,
     const float* __restrict__ window, const float2* __restrict__ tw400g,
     const int* __restrict__ mel_start, const int* __restrict__ mel_len, const float* __restrict__ mel_w, int n_mels,
-    float* __restrict__ power, float* __restrict__ phase, float* __restrict__ complx, float* __restrict__ mel) {
+    float* __restrict__ power, float* __restrict__ phase, float* __restrict__ complx, float* __restrict__ mel,
+    unsigned long long* __restrict__ dbgbuf, int vec_ok) {
   __shared__ float2 Y[kFR * kHalf];
   __shared__ float2 tw[kHalf];        // (cos, sin)(2 pi k / 400), k < 200;  W200^t = tw[2t] (t < 100), -tw[2t-200] otherwise
   __shared__ float win[kNfft];
+  __shared__ float2 tail[32];         // (power, phase) of bin 200 per frame
 
   const int tid = threadIdx.x;
   const int b = blockIdx.y;
   const int f0 = blockIdx.x * kFR;
   const int nf = min(kFR, F - f0);
+  // developer stamps (SE_AMD_STFT_DBG=1): thread 0 of workgroups (x = 5, y < 8) records s_memtime at phase boundaries
+  const bool st_on = dbgbuf != nullptr && tid == 0 && blockIdx.x == 5 && b < 8;
+  int st_i = 0;
+#define SE_STAMP() do { if (st_on) dbgbuf[b * 16 + st_i++] = __builtin_amdgcn_s_memtime(); } while (0)
+  SE_STAMP();
   const float* x = wavs + ((size_t)b * C + channel) * (size_t)T;
 
-  if (tid < kHalf) tw[tid] = tw400g[tid];
-  for (int i = tid; i < kNfft; i += kThreads) win[i] = window[i];
+  // table loads are issued together with the frame loads below and written to LDS afterwards (one memory latency)
+  const float2 twv = tw400g[min(tid, kHalf - 1)];
+  const float wv0 = window[tid], wv1 = window[min(tid + kThreads, kNfft - 1)];
 
   // ---- fill: windowed samples as packed complex.  item = tid + 256 r -> (frame, n) advanced incrementally.
   const bool interior = (f0 * kHop - kHalf >= 0) && ((f0 + nf - 1) * kHop + kHalf <= T);
@@ -86,6 +96,9 @@ __global__ __launch_bounds__(kThreads) void stft_kernel(
         if (n >= kHalf) { n -= kHalf; f += 1; }
       }
     }
+    if (tid < kHalf) tw[tid] = twv;
+    win[tid] = wv0;
+    if (tid + kThreads < kNfft) win[tid + kThreads] = wv1;
     __syncthreads();                                      // window table visible
     {
       int f = tid / kHalf, n = tid - f * kHalf;
@@ -101,6 +114,9 @@ __global__ __launch_bounds__(kThreads) void stft_kernel(
       }
     }
   } else {
+    if (tid < kHalf) tw[tid] = twv;
+    win[tid] = wv0;
+    if (tid + kThreads < kNfft) win[tid + kThreads] = wv1;
     __syncthreads();
     for (int it = tid; it < nf * kHalf; it += kThreads) {
       const int f = it / kHalf, n = it - f * kHalf;
@@ -109,6 +125,7 @@ __global__ __launch_bounds__(kThreads) void stft_kernel(
     }
   }
   __syncthreads();
+  SE_STAMP();   // fill done
 
   // ---- pass A (twiddle W200^(j q) from the 400-table)
   for (int it = tid; it < nf * 25; it += kThreads) {
@@ -129,6 +146,7 @@ __global__ __launch_bounds__(kThreads) void stft_kernel(
     for (int q = 0; q < 8; ++q) frame[25 * q + j] = v[q];
   }
   __syncthreads();
+  SE_STAMP();   // pass A done
 
   // ---- pass B (8 items per frame)
   {
@@ -149,8 +167,9 @@ __global__ __launch_bounds__(kThreads) void stft_kernel(
     }
   }
   __syncthreads();
+  SE_STAMP();   // pass B done
 
-  // ---- post: pairs (k, 200-k), k = 0..100; stores only
+  // ---- post: pairs (k, 200-k), k = 0..100, IN PLACE: slot k <- (power, phase) of bin k; bin 200 goes to tail[f]
   const size_t obase = ((size_t)b * F + f0) * kBins;
   {
     int f = tid / 101, k = tid - f * 101;
@@ -167,34 +186,68 @@ __global__ __launch_bounds__(kThreads) void stft_kernel(
         const float2 P = make_float2(O.x * w.x + O.y * w.y, O.y * w.x - O.x * w.y);
         const float2 X1 = make_float2(E.x + P.x, E.y + P.y);          // X[k]
         const float2 X2 = make_float2(E.x - P.x, -(E.y - P.y));       // X[200-k] = conj(E - P)
-        const float p1 = X1.x * X1.x + X1.y * X1.y;
-        const float p2 = X2.x * X2.x + X2.y * X2.y;
-        const size_t o1 = obase + (size_t)f * kBins + k;
-        const size_t o2 = o1 + (kHalf - 2 * k);
-        if (power) {
-          power[o1] = p1;
-          if (k != 100) power[o2] = p2;
-        }
-        if (phase) {
-          phase[o1] = fast_atan2(X1.y, X1.x);
-          if (k != 100) phase[o2] = fast_atan2(X2.y, X2.x);
-        }
-        if (complx) {
+        if (complx) {       // rarely requested ('complx' features): direct 8-B stores (no loads in this loop)
+          const size_t o1 = obase + (size_t)f * kBins + k;
           reinterpret_cast<float2*>(complx)[o1] = X1;
-          if (k != 100) reinterpret_cast<float2*>(complx)[o2] = X2;
+          if (k != 100) reinterpret_cast<float2*>(complx)[o1 + (kHalf - 2 * k)] = X2;
         }
-        // power back into LDS for the mel stage: bin k -> Z[k].x ; bin 200 has zero weight in every HTK filter
-        Z[k].x = p1;
-        if (k != 0 && k != 100) Z[kHalf - k].x = p2;
+        const float2 r1 = make_float2(X1.x * X1.x + X1.y * X1.y, fast_atan2(X1.y, X1.x));
+        const float2 r2 = make_float2(X2.x * X2.x + X2.y * X2.y, fast_atan2(X2.y, X2.x));
+        Z[k] = r1;
+        if (k == 0) tail[f] = r2;
+        else if (k != 100) Z[kHalf - k] = r2;
       }
       k += kThreads - 2 * 101;                              // 256 = 2 * 101 + 54
       f += 2;
       if (k >= 101) { k -= 101; f += 1; }
     }
   }
+  __syncthreads();
+  SE_STAMP();   // post done
+
+  // ---- write-out: the workgroup's nf x 201 outputs are ONE contiguous span of each plane: aligned 16-B stores for the
+  //      body, scalar head / tail (rows of 201 floats are not 16-B multiples, so the span start is arbitrary mod 4)
+  if (power || phase) {
+    const int total = nf * kBins;
+    const int head = vec_ok ? min(total, (int)((4 - (obase & 3)) & 3)) : total;
+    const int nvec = (total - head) >> 2;
+    auto elem = [&](int f, int k) -> float2 { return (k < kHalf) ? Y[f * kHalf + k] : tail[f]; };
+    // head + tail elements (at most 3 + 3 in the vector case; everything in the unaligned-pointer fallback)
+    for (int i = tid; i < total; i += kThreads) {
+      if (i >= head && i < head + 4 * nvec) {
+        if (vec_ok) break;       // body handled below (i only grows)
+      }
+      const int f = i / kBins, k = i - f * kBins;
+      const float2 v = elem(f, k);
+      if (power) power[obase + i] = v.x;
+      if (phase) phase[obase + i] = v.y;
+    }
+    if (vec_ok) {
+      for (int i = head + 4 * nvec + tid; i < total; i += kThreads) {
+        const int f = i / kBins, k = i - f * kBins;
+        const float2 v = elem(f, k);
+        if (power) power[obase + i] = v.x;
+        if (phase) phase[obase + i] = v.y;
+      }
+      for (int v4 = tid; v4 < nvec; v4 += kThreads) {
+        const int i = head + 4 * v4;
+        int f = i / kBins, k = i - f * kBins;
+        float2 e[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          e[j] = elem(f, k);
+          k += 1;
+          if (k == kBins) { k = 0; f += 1; }
+        }
+        if (power) *reinterpret_cast<float4*>(power + obase + i) = make_float4(e[0].x, e[1].x, e[2].x, e[3].x);
+        if (phase) *reinterpret_cast<float4*>(phase + obase + i) = make_float4(e[0].y, e[1].y, e[2].y, e[3].y);
+      }
+    }
+  }
 
   if (mel == nullptr) return;
   __syncthreads();
+  SE_STAMP();
   // ---- mel: stage the sparse filter table into the free .y halves of the power slots (one batched load per thread)
   float* Yf = reinterpret_cast<float*>(Y);
   {
@@ -241,11 +294,17 @@ extern "C" int se_stft_f32(const se_plan* plan, const float* wavs, int B, int C,
   SE_REQUIRE(B <= 65535, "se_stft_f32: B=%d exceeds grid.y limit", B);
   const int F = T / se::kHop + 1;
   dim3 grid((F + se::kFR - 1) / se::kFR, B);
+  const int vec_ok = (((uintptr_t)power | (uintptr_t)phase) % 16) == 0;
+  unsigned long long* dbgbuf = nullptr;
+  if (getenv("SE_AMD_STFT_DBG") && complx) {      // developer stamps ride in the `complx` buffer
+    dbgbuf = reinterpret_cast<unsigned long long*>(complx);
+    complx = nullptr;
+  }
   // algorithmic bytes: 4 T in + 4 F K per written plane
   se::ProfScope prof(se::kProfStft, (double)B * (4.0 * T + 4.0 * F * se::kBins * ((power != nullptr) + (phase != nullptr) + 2 * (complx != nullptr)) + (mel ? 4.0 * F * plan->geom.n_mels : 0.0)), se::as_stream(stream));
   hipLaunchKernelGGL(se::stft_kernel, grid, dim3(se::kThreads), 0, se::as_stream(stream), wavs, C, T, channel, F,
                      plan->d_window, plan->d_tw400, plan->d_mel_start, plan->d_mel_len, plan->d_mel_w,
-                     plan->geom.n_mels, power, phase, complx, mel);
+                     plan->geom.n_mels, power, phase, complx, mel, dbgbuf, vec_ok);
   SE_LAUNCH_CHECK();
   return SE_OK;
 }
