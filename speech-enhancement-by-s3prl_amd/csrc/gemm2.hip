@@ -63,7 +63,7 @@ template <int WR, int STAGES, int PINGPONG, int ACT, int EF>
 __global__ __launch_bounds__(128 * WR) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm2_bf16_kernel(
     const uint16_t* __restrict__ A, int lda, const uint16_t* __restrict__ W, int ldw, const float* __restrict__ bias,
     const float* __restrict__ residual, int M, int N, int K, int act, uint16_t* __restrict__ out_bf16,
-    float* __restrict__ out_f32, int ldc, int tiles_m, int tiles_n, int vec_ok, int dbg) {
+    float* __restrict__ out_f32, int ldc, int tiles_m, int tiles_n, int vec_ok, int dbg, int group_m) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using C = G2<WR, STAGES>;
   constexpr int k2BM = C::BM, k2ABytes = C::ABytes, k2Stage = C::Stage, k2Stages = STAGES, NW = C::NW;
@@ -79,7 +79,13 @@ __global__ __launch_bounds__(128 * WR) __attribute__((amdgpu_waves_per_eu(2, 2))
     const int orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
     id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
   }
-  const int tm = id / tiles_n, tn = id - tm * tiles_n;
+  int tm, tn;          // grouped order inside the XCD's id range (see gemm3.hip)
+  {
+    const int per_group = group_m * tiles_n, grp = id / per_group, first_m = grp * group_m;
+    const int gsz = min(tiles_m - first_m, group_m), in = id - grp * per_group;
+    tn = in / gsz;
+    tm = first_m + (in - tn * gsz);
+  }
   const int m0 = tm * k2BM, n0 = tn * k2BN;
 
   // ---- DMA source pointers.  A stage = BM/8 chunks of 1 KiB (8 rows x 128 B); wave w issues chunks w, w+NW, w+2NW, w+3NW.
@@ -316,7 +322,7 @@ __global__ __launch_bounds__(128 * WR) __attribute__((amdgpu_waves_per_eu(2, 2))
 namespace {
 struct GArgs {
   const uint16_t* A; int lda; const uint16_t* W; int ldw; const float* bias; const float* residual; int M, N, K, act;
-  uint16_t* out_bf16; float* out_f32; int ldc, vec_ok, dbg; hipStream_t st;
+  uint16_t* out_bf16; float* out_f32; int ldc, vec_ok, dbg; hipStream_t st; int group_m;
 };
 
 template <int WR, int STAGES, int PP, int ACT, int EF>
@@ -329,7 +335,7 @@ int launch_one(const GArgs& g) {
     attr_set = true;
   }
   hipLaunchKernelGGL((se::gemm2_bf16_kernel<WR, STAGES, PP, ACT, EF>), dim3(tiles_m * tiles_n), dim3(C::Threads), C::Lds, g.st, g.A, g.lda, g.W,
-                     g.ldw, g.bias, g.residual, g.M, g.N, g.K, g.act, g.out_bf16, g.out_f32, g.ldc, tiles_m, tiles_n, g.vec_ok, g.dbg);
+                     g.ldw, g.bias, g.residual, g.M, g.N, g.K, g.act, g.out_bf16, g.out_f32, g.ldc, tiles_m, tiles_n, g.vec_ok, g.dbg, g.group_m);
   SE_LAUNCH_CHECK();
   return SE_OK;
 }
@@ -358,7 +364,13 @@ extern "C" int se_gemm2_launch(const uint16_t* A, int lda, const uint16_t* W, in
     const char* e = getenv("SE_AMD_GEMM_DBG");     // developer ablation switch (timing only, wrong results)
     dbg = e ? atoi(e) : 0;
   }
-  GArgs g{A, lda, W, ldw, bias, residual_f32, M, N, K, act, out_bf16, out_f32, ldc, vec_ok, dbg, se::as_stream(stream)};
+  static int group_m = 0;
+  if (group_m == 0) {
+    const char* gm = getenv("SE_AMD_GEMM_GROUPM2");
+    group_m = gm ? atoi(gm) : 1;
+    if (group_m < 1) group_m = 1;
+  }
+  GArgs g{A, lda, W, ldw, bias, residual_f32, M, N, K, act, out_bf16, out_f32, ldc, vec_ok, dbg, se::as_stream(stream), group_m};
   se::ProfScope prof(se::kProfGemm, 2.0 * M * (double)N * K, g.st);
   if (variant == 4) return launch_cfg<2, 2, 0>(g);
   if (variant == 3 && K >= 2 * se::k2BK) return launch_cfg<4, 3, 1>(g);

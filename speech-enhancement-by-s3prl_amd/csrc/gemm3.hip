@@ -56,7 +56,7 @@ template <int ACT, int EF, int SCHED>
 __global__ __launch_bounds__(k3Threads) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm3_bf16_kernel(
     const uint16_t* __restrict__ A, int lda, const uint16_t* __restrict__ W, int ldw, const float* __restrict__ bias,
     const float* __restrict__ residual, int M, int N, int K, uint16_t* __restrict__ out_bf16, float* __restrict__ out_f32,
-    int ldc, int tiles_m, int tiles_n, int dbg) {
+    int ldc, int tiles_m, int tiles_n, int dbg, int group_m) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -68,7 +68,15 @@ __global__ __launch_bounds__(k3Threads) __attribute__((amdgpu_waves_per_eu(2, 2)
     const int orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
     id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
   }
-  const int tm = id / tiles_n, tn = id - tm * tiles_n;
+  // grouped order inside the XCD's contiguous id range: GROUP_M tile rows form a super-tile that is swept n-major with
+  // m fastest, so the ~32 workgroups in flight on an XCD share few A panels AND few weight-row slices (both must fit 4 MB)
+  int tm, tn;
+  {
+    const int per_group = group_m * tiles_n, grp = id / per_group, first_m = grp * group_m;
+    const int gsz = min(tiles_m - first_m, group_m), in = id - grp * per_group;
+    tn = in / gsz;
+    tm = first_m + (in - tn * gsz);
+  }
   const int m0 = tm * k3BM, n0 = tn * k3BN;
 
   // ---- DMA sources: a stage half (A or B) = 16 chunks of 1 KiB = 16 rows x 64 B each; wave w issues chunks w, w+8 of A and of B.
@@ -455,10 +463,13 @@ int launch3s(const G3Args& g, int sched);
 template <int ACT, int EF, int SCHED>
 int launch3(const G3Args& g) {
   const int tiles_m = (g.M + se::k3BM - 1) / se::k3BM, tiles_n = (g.N + se::k3BN - 1) / se::k3BN;
-  static int dbg = -1;
+  static int dbg = -1, group_m = 0;
   if (dbg < 0) {
     const char* e = getenv("SE_AMD_GEMM_DBG");
     dbg = e ? atoi(e) : 0;
+    const char* gm = getenv("SE_AMD_GEMM_GROUPM");
+    group_m = gm ? atoi(gm) : 4;
+    if (group_m < 1) group_m = 1;
   }
   static bool attr_set = false;
   if (!attr_set) {
@@ -466,7 +477,7 @@ int launch3(const G3Args& g) {
     attr_set = true;
   }
   hipLaunchKernelGGL((se::gemm3_bf16_kernel<ACT, EF, SCHED>), dim3(tiles_m * tiles_n), dim3(se::k3Threads), se::k3Lds, g.st, g.A, g.lda, g.W, g.ldw,
-                     g.bias, g.residual, g.M, g.N, g.K, g.out_bf16, g.out_f32, g.ldc, tiles_m, tiles_n, dbg);
+                     g.bias, g.residual, g.M, g.N, g.K, g.out_bf16, g.out_f32, g.ldc, tiles_m, tiles_n, dbg, group_m);
   SE_LAUNCH_CHECK();
   return SE_OK;
 }

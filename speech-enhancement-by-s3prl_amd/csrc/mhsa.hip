@@ -41,7 +41,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hh = lane >> 5;
-  const int b = blockIdx.z, head = blockIdx.y, q0 = blockIdx.x * kAQ + wave * 32;
+  // XCD-aware work mapping: workgroups are dealt round-robin to the 8 XCDs (linear id % 8), each with its own L2.  All
+  // query tiles of one (utterance, head) re-read the same K / V, so they are placed on ONE XCD, consecutive in its
+  // dispatch order: workgroup (xcd, i) -> pair 8 (i / nqt) + xcd, query tile i % nqt   [needs pairs % 8 == 0]
+  int b, head, qt;
+  {
+    const int nqt = gridDim.x, pairs = gridDim.y * gridDim.z;
+    const int lin = blockIdx.x + nqt * (blockIdx.y + gridDim.y * blockIdx.z);
+    if ((pairs & 7) == 0) {
+      const int xcd = lin & 7, i = lin >> 3;
+      const int pair = 8 * (i / nqt) + xcd;
+      qt = i % nqt;
+      head = pair % gridDim.y;
+      b = pair / gridDim.y;
+    } else {
+      qt = blockIdx.x; head = blockIdx.y; b = blockIdx.z;
+    }
+  }
+  const int q0 = qt * kAQ + wave * 32;
   const int ld = 3 * H;
   const int len = lengths ? min(max(lengths[b], 1), T) : T;
   const int nkt = (len + kAK - 1) / kAK;
