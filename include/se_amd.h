@@ -227,6 +227,13 @@ int se_valid_lengths_i32(const float* feats, int B, int T, int D, int32_t* lengt
 int se_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias,
                  const float* residual_f32, int M, int N, int K, int act,
                  uint16_t* out_bf16, float* out_f32, int ldc, void* stream);
+/* Row-complete fused form for N = 768 (attention-output and FFN2 projections, rows B2 / B3):
+ *   x = LayerNorm(A[M,K] . W[768,K]^T + bias + residual_f32) * ln_w + ln_b  ->  out_f32 and / or out_bf16 (M, 768)
+ * One workgroup owns 128 complete rows, so the LayerNorm runs on the accumulators (no fp32 round trip, no second launch).
+ * Returns SE_ERR_UNSUPPORTED unless N == 768, K % 32 == 0, K >= 128. */
+int se_gemm_res_ln_bf16(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias, const float* residual_f32,
+                        const float* ln_w, const float* ln_b, float eps, int M, int N, int K,
+                        float* out_f32, uint16_t* out_bf16, void* stream);
 /* qkv (B*T, 3H) bf16 = [Q | K | V] per row, heads of 64 columns; ctx (B*T, H) bf16. */
 int se_mhsa_fwd_bf16(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, void* stream);
 /* y = LN(x) * w + b over the last dim H (TF style, eps inside sqrt); x fp32 (M,H); outputs fp32 and/or bf16. */

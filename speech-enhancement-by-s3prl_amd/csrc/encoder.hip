@@ -11,6 +11,8 @@
 //   o    = h W2^T + b + x_f32          (M, H)  fp32
 //   x    = LayerNorm(o)
 #include <math.h>
+#include <stdlib.h>
+#include <utility>
 #include <vector>
 #include "common.h"
 #include "bf16.h"
@@ -405,18 +407,38 @@ extern "C" int se_encoder_fwd_bf16(const se_encoder* enc, const float* feats, co
   if ((rc = se_gemm_bf16(w.xin, se::kInPad, enc->in_w, se::kInPad, enc->in_b, nullptr, M, H, se::kInPad, SE_ACT_IDENTITY, nullptr, w.tmp, H, stream))) return rc;
   if ((rc = launch_layernorm(w.tmp, enc->pe, T, enc->in_ln_w, enc->in_ln_b, M, H, enc->cfg.ln_eps, w.x_f32, w.x_bf, st))) return rc;
   const int L = enc->cfg.layers;
+  static int fuse_env = -1;
+  if (fuse_env < 0) {
+    const char* e = getenv("SE_AMD_FUSED_LN");
+    fuse_env = e ? atoi(e) : 1;
+  }
+  const bool fused = fuse_env && H == 768 && I % 32 == 0 && I >= 128;
   for (int i = 0; i < L; ++i) {
     const se_encoder::Layer& y = enc->layers[i];
     // B2
     if ((rc = se_gemm_bf16(w.x_bf, H, y.qkv_w, H, y.qkv_b, nullptr, M, 3 * H, H, SE_ACT_IDENTITY, w.qkv, nullptr, 3 * H, stream))) return rc;
     if ((rc = se_mhsa_fwd_bf16(w.qkv, lengths, B, T, enc->cfg.heads, w.ctx, stream))) return rc;
-    if ((rc = se_gemm_bf16(w.ctx, H, y.ao_w, H, y.ao_b, w.x_f32, M, H, H, SE_ACT_IDENTITY, nullptr, w.tmp, H, stream))) return rc;
-    if ((rc = launch_layernorm(w.tmp, nullptr, 1, y.aln_w, y.aln_b, M, H, enc->cfg.ln_eps, w.x_f32, w.x_bf, st))) return rc;
+    // attention output projection + residual + LayerNorm: one fused row-complete kernel when H == 768 (ping-pong x buffers:
+    // the residual is read while the new stream is written), else GEMM + LayerNorm
+    if (fused) {
+      if ((rc = se_gemm_res_ln_bf16(w.ctx, H, y.ao_w, H, y.ao_b, w.x_f32, y.aln_w, y.aln_b, enc->cfg.ln_eps, M, H, H, w.tmp, w.x_bf, stream))) return rc;
+      std::swap(w.x_f32, w.tmp);
+    } else {
+      if ((rc = se_gemm_bf16(w.ctx, H, y.ao_w, H, y.ao_b, w.x_f32, M, H, H, SE_ACT_IDENTITY, nullptr, w.tmp, H, stream))) return rc;
+      if ((rc = launch_layernorm(w.tmp, nullptr, 1, y.aln_w, y.aln_b, M, H, enc->cfg.ln_eps, w.x_f32, w.x_bf, st))) return rc;
+    }
     // B3
     if ((rc = se_gemm_bf16(w.x_bf, H, y.ff1_w, H, y.ff1_b, nullptr, M, I, H, SE_ACT_GELU, w.h, nullptr, I, stream))) return rc;
-    if ((rc = se_gemm_bf16(w.h, I, y.ff2_w, I, y.ff2_b, w.x_f32, M, H, I, SE_ACT_IDENTITY, nullptr, w.tmp, H, stream))) return rc;
-    float* xo = (i == L - 1) ? hidden : w.x_f32;
-    if ((rc = launch_layernorm(w.tmp, nullptr, 1, y.oln_w, y.oln_b, M, H, enc->cfg.ln_eps, xo, (i == L - 1) ? nullptr : w.x_bf, st))) return rc;
+    if (fused) {
+      float* xo = (i == L - 1) ? hidden : w.tmp;
+      if ((rc = se_gemm_res_ln_bf16(w.h, I, y.ff2_w, I, y.ff2_b, w.x_f32, y.oln_w, y.oln_b, enc->cfg.ln_eps, M, H, I, xo,
+                                    (i == L - 1) ? nullptr : w.x_bf, stream))) return rc;
+      if (i != L - 1) std::swap(w.x_f32, w.tmp);
+    } else {
+      if ((rc = se_gemm_bf16(w.h, I, y.ff2_w, I, y.ff2_b, w.x_f32, M, H, I, SE_ACT_IDENTITY, nullptr, w.tmp, H, stream))) return rc;
+      float* xo = (i == L - 1) ? hidden : w.x_f32;
+      if ((rc = launch_layernorm(w.tmp, nullptr, 1, y.oln_w, y.oln_b, M, H, enc->cfg.ln_eps, xo, (i == L - 1) ? nullptr : w.x_bf, st))) return rc;
+    }
   }
   return SE_OK;
 }

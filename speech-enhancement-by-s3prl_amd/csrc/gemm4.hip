@@ -1,0 +1,275 @@
+// gemm4.hip -- row-complete GEMM + bias + fp32 residual + LayerNorm for the encoder's H = 768 projections
+// (attention output and FFN2: rows B2 / B3 "Linear -> +residual -> LayerNorm"):
+//      x = LayerNorm(A[M,K] . W[768,K]^T + bias + residual) * ln_w + ln_b   ->  x_f32 (M,768) and x_bf16 (M,768)
+//
+// Why: with N = 768 a 256 x 256 tiling gives 378 workgroups (1.5 rounds of 256 CUs) and the LayerNorm needs whole rows,
+// so the unfused path writes an fp32 (M,768) tensor, reads it back in a separate LayerNorm launch and runs its GEMM at
+// 0.5-0.7 PFLOP/s.  Here one workgroup owns 128 COMPLETE rows: M = 32 032 -> 251 workgroups ~ one per CU (no wave
+// quantisation), the LayerNorm runs on the accumulators, and 196 MB of HBM traffic + one launch disappear per call.
+//
+//   tile     : 128 x 768, 32-deep K-steps; 512 threads = 8 waves as 2 (M) x 4 (N); wave tile 64 x 192 = 4 x 12 MFMA tiles
+//              (v_mfma_f32_16x16x32_bf16, 192 accumulator registers)
+//   LDS      : the weight K-step (768 x 32 bf16 = 48 KiB) does not fit a 3-deep ring, so it is split by the three
+//              64-column groups a wave walks: a ring of SIX 16 KiB weight pieces refilled at sub-step granularity (five
+//              pieces in flight), plus a 4-deep ring of 8 KiB A pieces: 96 + 32 KiB; 64-B rows, chunk ^ ((-(row>>2))&3)
+//   schedule : per K-step three {LDS reads + DMA issue + waits | barrier | 16 MFMAs | barrier} sub-steps, waves 4-7 one
+//              barrier behind waves 0-3 (ping-pong); counted vmcnt (9 / 10 DMAs younger than the piece needed next)
+//   epilogue : swapped operands (C^T accumulators, initialised with bias + residual before the K loop); ln_w / ln_b staged
+//              in the (then dead) ring; exact two-pass mean / variance per row (lane group -> wave -> LDS across the 4 column waves);
+//              fp32 and bf16 rows stored straight from registers
+#include <stdlib.h>
+#include "common.h"
+#include "bf16.h"
+#include "prof.h"
+
+namespace se {
+
+constexpr int k4BM = 128, k4N = 768, k4BK = 32, k4Threads = 512;
+constexpr int k4WPiece = 256 * 64, k4WSlots = 6, k4APiece = 128 * 64, k4ASlots = 4;
+constexpr int k4WBytes = k4WPiece * k4WSlots;                 // 98 304
+constexpr int k4ABytes = k4APiece * k4ASlots;                 // 32 768
+constexpr int k4RedOff = k4WBytes + k4ABytes;                 // LN partial sums: float [2 passes][2 wr][4 wc][64 rows] = 4 KiB
+constexpr int k4Lds = k4RedOff + 2 * 2 * 4 * 64 * 4;          // 135 168 B
+
+typedef __attribute__((address_space(3))) void* lds4_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb4_ptr_t;
+
+__device__ __forceinline__ int swz4_f(int row) { return (-(row >> 2)) & 3; }
+__device__ __forceinline__ int swz4(int row, int chunk) { return row * 64 + ((chunk ^ swz4_f(row)) << 4); }
+
+__global__ __launch_bounds__(k4Threads) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm4_res_ln_kernel(
+    const uint16_t* __restrict__ A, int lda, const uint16_t* __restrict__ W, int ldw, const float* __restrict__ bias,
+    const float* __restrict__ residual, const float* __restrict__ ln_w, const float* __restrict__ ln_b, float eps, int M, int K,
+    float* __restrict__ out_f32, uint16_t* __restrict__ out_bf16, int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+
+  int id;
+  {
+    const int orig = blockIdx.x, xcd = orig & 7, q = ntiles >> 3, r = ntiles & 7;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+  }
+  const int m0 = id * k4BM;
+
+  // ---- DMA sources.  Weight piece (g, j) = rows {wcc*192 + j*64 + 0..63 : wcc = 0..3} = 16 chunks of 16 rows x 64 B;
+  //      wave w issues chunks w and w+8.  chunk c -> wcc = c >> 2, piece-local rows 16 c + (lane >> 2).
+  const int r16 = lane >> 2, pos = lane & 3;
+  const uint16_t* w_src[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = wave + 8 * i, prow = 16 * c + r16;
+    const int grow = (c >> 2) * 192 + (c & 3) * 16 + r16;          // + 64 j per piece
+    w_src[i] = W + (size_t)grow * ldw + ((pos ^ swz4_f(prow)) << 3);
+  }
+  const uint16_t* a_src;
+  {
+    const int prow = 16 * wave + r16;
+    a_src = A + (size_t)min(m0 + prow, M - 1) * lda + ((pos ^ swz4_f(prow)) << 3);
+  }
+  const size_t w_jstep = (size_t)64 * ldw;
+#define SE4_ISSUE_W(g, j, slot)                                                                                              \
+  do {                                                                                                                       \
+    char* sb_ = smem + (slot) * k4WPiece + wave * 1024;                                                                      \
+    __builtin_amdgcn_global_load_lds((glb4_ptr_t)(w_src[0] + (j) * w_jstep + (g) * k4BK), (lds4_ptr_t)(sb_), 16, 0, 0);      \
+    __builtin_amdgcn_global_load_lds((glb4_ptr_t)(w_src[1] + (j) * w_jstep + (g) * k4BK), (lds4_ptr_t)(sb_ + 8192), 16, 0, 0); \
+  } while (0)
+#define SE4_ISSUE_A(g)                                                                                                       \
+  do {                                                                                                                       \
+    __builtin_amdgcn_global_load_lds((glb4_ptr_t)(a_src + (g) * k4BK),                                                       \
+                                     (lds4_ptr_t)(smem + k4WBytes + ((g) & 3) * k4APiece + wave * 1024), 16, 0, 0);         \
+  } while (0)
+
+  // C^T accumulators: acc[i][t][r] = C[row wr*64 + 16 i + (lane & 15)][col wc*192 + 16 t + 4 (lane >> 4) + r].
+  // They are INITIALISED with bias + residual (the registers are free now and the loads overlap the DMA prologue); adding
+  // them in the epilogue, next to 192 live accumulators, spilled ~1 KB per lane.
+  const int mrow = lane & 15, cq = lane >> 4;
+  const int col0 = wc * 192 + 4 * cq;
+  f32x4 acc[4][12];
+  {
+    float4 bb[12];
+#pragma unroll
+    for (int t = 0; t < 12; ++t) bb[t] = bias ? *reinterpret_cast<const float4*>(bias + col0 + 16 * t) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int gm = min(m0 + wr * 64 + i * 16 + mrow, M - 1);
+      const float* rp = residual + (size_t)gm * k4N + col0;
+#pragma unroll
+      for (int t = 0; t < 12; ++t) {
+        const float4 rr = *reinterpret_cast<const float4*>(rp + 16 * t);
+        acc[i][t] = (f32x4){rr.x + bb[t].x, rr.y + bb[t].y, rr.z + bb[t].z, rr.w + bb[t].w};
+      }
+    }
+  }
+
+  const int frow = lane & 15, fch = lane >> 4;
+  int a_off[4], b_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a_off[i] = k4WBytes + swz4(wr * 64 + i * 16 + frow, fch);
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj) b_off[jj] = swz4(wc * 64 + jj * 16 + frow, fch);
+
+  const int nk = K / k4BK;                 // >= 4 (launcher)
+  // prologue: pieces 0..4 = (0,0) (0,1) (0,2) (1,0) (1,1), A steps 0..2
+  SE4_ISSUE_A(0);
+  SE4_ISSUE_W(0, 0, 0);
+  SE4_ISSUE_A(1);
+  SE4_ISSUE_A(2);
+  SE4_ISSUE_W(0, 1, 1);
+  SE4_ISSUE_W(0, 2, 2);
+  SE4_ISSUE_W(1, 0, 3);
+  SE4_ISSUE_W(1, 1, 4);
+  const bool late = wave >= 4;
+  asm volatile("s_waitcnt vmcnt(10)" ::: "memory");        // A(0), W piece 0 landed
+  __builtin_amdgcn_s_barrier();
+  if (late) __builtin_amdgcn_s_barrier();                   // stagger: waves 4-7 one barrier behind
+
+  int wslot = 0;                            // ring slot of the piece being multiplied
+  for (int g = 0; g < nk; ++g) {
+    const char* a_s = smem + (g & 3) * k4APiece;
+    bf16x8 af[4];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const char* w_s = smem + wslot * k4WPiece;
+      bf16x8 bfr[4];
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) bfr[jj] = *reinterpret_cast<const bf16x8*>(w_s + b_off[jj]);
+      if (j == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(a_s + a_off[i]);
+      }
+      // refill: piece s+5 goes to the slot of piece s-1, whose last readers (waves 4-7) completed their reads
+      // (lgkmcnt(0) below) before the barrier that this wave passed at the end of the previous sub-step
+      {
+        const int g5 = g + (j == 0 ? 1 : 2), j5 = (j + 2) % 3;
+        int slot5 = wslot + 5;
+        if (slot5 >= k4WSlots) slot5 -= k4WSlots;
+        if (g5 < nk) SE4_ISSUE_W(g5, j5, slot5);
+        if (j == 0 && g + 3 < nk) SE4_ISSUE_A(g + 3);
+      }
+      // piece s+1 must have landed.  DMAs younger than its two, in issue order: four pieces (8) + the A pieces issued
+      // in those sub-steps: 2 when j != 2, 1 when j == 2 (one fewer during the first K-step and once A issue stops)
+      if (g + 2 >= nk) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      } else if (g == 0 || g + 3 >= nk) {
+        if (j == 2 && g != 0) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory");
+      } else {
+        if (j == 2) asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+          acc[i][4 * j + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[jj], af[i], acc[i][4 * j + jj], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      wslot = (wslot + 1 == k4WSlots) ? 0 : wslot + 1;
+    }
+  }
+  if (!late) __builtin_amdgcn_s_barrier();                  // re-align the two groups
+  __syncthreads();                                          // ring is dead: reuse it for the per-column vectors
+
+  // ---- epilogue: LayerNorm on the accumulators (which already hold A.W^T + bias + residual)
+  float* colv = reinterpret_cast<float*>(smem);             // [2][768]: ln_w, ln_b staged in the dead ring
+  for (int c = tid; c < k4N; c += k4Threads) {
+    colv[c] = ln_w[c];
+    colv[k4N + c] = ln_b[c];
+  }
+  float* red = reinterpret_cast<float*>(smem + k4RedOff);   // [pass][wr][wc][64]
+  // pass 1: row means
+  float mean[4], rstd[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < 12; ++t) s += (acc[i][t][0] + acc[i][t][1]) + (acc[i][t][2] + acc[i][t][3]);
+    s += __shfl_xor(s, 16);
+    s += __shfl_xor(s, 32);
+    if (cq == 0) red[(wr * 4 + wc) * 64 + i * 16 + mrow] = s;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float* rp = red + wr * 256 + i * 16 + mrow;
+    mean[i] = (rp[0] + rp[64] + rp[128] + rp[192]) * (1.0f / k4N);
+  }
+  // pass 2: variance around the mean (exact two-pass, as the stand-alone LayerNorm kernel)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float q = 0.f;
+#pragma unroll
+    for (int t = 0; t < 12; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float d = acc[i][t][r] - mean[i];
+        q = fmaf(d, d, q);
+      }
+    q += __shfl_xor(q, 16);
+    q += __shfl_xor(q, 32);
+    if (cq == 0) red[512 + (wr * 4 + wc) * 64 + i * 16 + mrow] = q;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float* rp = red + 512 + wr * 256 + i * 16 + mrow;
+    rstd[i] = 1.0f / sqrtf((rp[0] + rp[64] + rp[128] + rp[192]) * (1.0f / k4N) + eps);
+  }
+  // normalise + store (stores only in this loop; the per-column vectors come from LDS)
+  const bool interior = m0 + k4BM <= M;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int gm = m0 + wr * 64 + i * 16 + mrow;
+    const bool ok = interior || gm < M;
+    const size_t o = (size_t)min(gm, M - 1) * k4N + col0;
+#pragma unroll
+    for (int t = 0; t < 12; ++t) {
+      if ((t & 3) == 0) __builtin_amdgcn_sched_barrier(0);
+      const float4 lw = *reinterpret_cast<const float4*>(colv + col0 + 16 * t);
+      const float4 lb = *reinterpret_cast<const float4*>(colv + k4N + col0 + 16 * t);
+      const float y0 = lw.x * ((acc[i][t][0] - mean[i]) * rstd[i]) + lb.x;
+      const float y1 = lw.y * ((acc[i][t][1] - mean[i]) * rstd[i]) + lb.y;
+      const float y2 = lw.z * ((acc[i][t][2] - mean[i]) * rstd[i]) + lb.z;
+      const float y3 = lw.w * ((acc[i][t][3] - mean[i]) * rstd[i]) + lb.w;
+      if (ok) {
+        if (out_f32) *reinterpret_cast<float4*>(out_f32 + o + 16 * t) = make_float4(y0, y1, y2, y3);
+        if (out_bf16) *reinterpret_cast<uint2*>(out_bf16 + o + 16 * t) = make_uint2(pack_bf16x2(y0, y1), pack_bf16x2(y2, y3));
+      }
+    }
+  }
+}
+
+}  // namespace se
+
+extern "C" int se_gemm_res_ln_bf16(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias, const float* residual_f32,
+                                   const float* ln_w, const float* ln_b, float eps, int M, int N, int K,
+                                   float* out_f32, uint16_t* out_bf16, void* stream) {
+  SE_REQUIRE(A && W && residual_f32 && ln_w && ln_b && (out_f32 || out_bf16), "se_gemm_res_ln_bf16: null argument");
+  if (N != se::k4N || K % se::k4BK != 0 || K < 4 * se::k4BK) {
+    se::set_error("se_gemm_res_ln_bf16: the fused kernel is specialised for N = 768 and K a multiple of 32, K >= 128 (got N=%d K=%d)", N, K);
+    return SE_ERR_UNSUPPORTED;
+  }
+  SE_REQUIRE(M > 0 && lda >= K && ldw >= K && lda % 8 == 0 && ldw % 8 == 0, "se_gemm_res_ln_bf16: bad leading dimensions");
+  SE_REQUIRE((((uintptr_t)A | (uintptr_t)W | (uintptr_t)residual_f32 | (uintptr_t)out_f32 | (uintptr_t)out_bf16 | (uintptr_t)bias |
+               (uintptr_t)ln_w | (uintptr_t)ln_b) % 16) == 0, "se_gemm_res_ln_bf16: pointers must be 16-B aligned");
+  static bool attr_set = false;
+  if (!attr_set) {
+    SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::gemm4_res_ln_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, se::k4Lds));
+    attr_set = true;
+  }
+  const int ntiles = (M + se::k4BM - 1) / se::k4BM;
+  hipStream_t st = se::as_stream(stream);
+  se::ProfScope prof(se::kProfGemm, 2.0 * M * (double)N * K, st);
+  hipLaunchKernelGGL(se::gemm4_res_ln_kernel, dim3(ntiles), dim3(se::k4Threads), se::k4Lds, st, A, lda, W, ldw, bias, residual_f32, ln_w, ln_b,
+                     eps, M, K, out_f32, out_bf16, ntiles);
+  SE_LAUNCH_CHECK();
+  return SE_OK;
+}

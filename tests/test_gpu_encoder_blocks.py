@@ -33,7 +33,8 @@ def test_gemm_identity_asymmetric(gpu):
     A = torch.zeros(256, K, device=gpu)
     A[:K, :K] = torch.eye(K, device=gpu)
     W = (torch.arange(200 * K, device=gpu).reshape(200, K) % 97 - 40).float()   # W[n][k]
-    o32, _ = gemm(A.bfloat16(), W.bfloat16())
+    A16, W16 = A.bfloat16(), W.bfloat16()
+    o32, _ = gemm(A16, W16)
     assert torch.equal(o32[:K].cpu(), W.T.cpu())
     assert torch.count_nonzero(o32[K:]) == 0
 
@@ -92,7 +93,8 @@ def test_mhsa_exact_integers(gpu):
     qkv[:, 128:] = V
     qkv[:, 64:128] = torch.randn(T, 64, device=gpu)                                  # K irrelevant when Q = 0
     ctx = torch.empty(T, 64, device=gpu, dtype=torch.bfloat16)
-    L.check(lib.se_mhsa_fwd_bf16(L.ptr(qkv.bfloat16()), None, B, T, heads, L.ptr(ctx), L.stream()), 'se_mhsa_fwd_bf16')
+    qkv16 = qkv.bfloat16()
+    L.check(lib.se_mhsa_fwd_bf16(L.ptr(qkv16), None, B, T, heads, L.ptr(ctx), L.stream()), 'se_mhsa_fwd_bf16')
     ref = V.mean(dim=0, keepdim=True).expand(T, 64)
     assert (ctx.float() - ref).abs().max().item() < 2e-2
 
@@ -131,3 +133,43 @@ def test_layernorm(gpu, M, H):
     ref = torch.nn.functional.layer_norm(x.double(), (H,), w.double(), b.double(), 1e-12)
     assert (o32.double() - ref).abs().max().item() < 2e-5
     assert (o16.double() - ref).abs().max().item() < 4e-2
+
+
+@pytest.mark.parametrize('M,K', [(1001, 768), (300, 3072), (129, 128), (32032, 768)])
+def test_gemm_res_ln_vs_torch(gpu, M, K):
+    """row-complete GEMM + bias + residual + LayerNorm (N = 768) vs fp64 on the same bf16 operands"""
+    L = _lib()
+    lib = L.load()
+    torch.manual_seed(M + K)
+    N = 768
+    A = torch.randn(M, K, device=gpu).bfloat16()
+    W = (torch.randn(N, K, device=gpu) * 0.03).bfloat16()
+    bias, res = torch.randn(N, device=gpu) * 0.1, torch.randn(M, N, device=gpu)
+    lw, lb = 1 + 0.1 * torch.randn(N, device=gpu), 0.1 * torch.randn(N, device=gpu)
+    o32 = torch.empty(M, N, device=gpu)
+    o16 = torch.empty(M, N, device=gpu, dtype=torch.bfloat16)
+    L.check(lib.se_gemm_res_ln_bf16(L.ptr(A), K, L.ptr(W), K, L.ptr(bias), L.ptr(res), L.ptr(lw), L.ptr(lb), 1e-12, M, N, K,
+                                    L.ptr(o32), L.ptr(o16), L.stream()), 'se_gemm_res_ln_bf16')
+    x = A.double() @ W.double().T + bias.double() + res.double()
+    ref = torch.nn.functional.layer_norm(x, (N,), lw.double(), lb.double(), 1e-12)
+    assert (o32.double() - ref).abs().max().item() < 5e-5
+    assert (o16.double() - ref).abs().max().item() < 4e-2
+
+
+def test_gemm_res_ln_exact_rows(gpu):
+    """A = one-hot rows selecting weight rows (exact in bf16): catches row / column mapping errors before the LayerNorm"""
+    L = _lib()
+    lib = L.load()
+    M, K, N = 256, 128, 768
+    A = torch.zeros(M, K, device=gpu)
+    A[torch.arange(M), torch.arange(M) % K] = 1.0
+    W = ((torch.arange(N * K, device=gpu).reshape(N, K) * 7 % 61) - 30).float()
+    res = torch.zeros(M, N, device=gpu)
+    ones, zeros = torch.ones(N, device=gpu), torch.zeros(N, device=gpu)
+    o32 = torch.empty(M, N, device=gpu)
+    A16, W16 = A.bfloat16(), W.bfloat16()        # keep the operands alive: a temporary's memory is recycled before the launch
+    L.check(lib.se_gemm_res_ln_bf16(L.ptr(A16), K, L.ptr(W16), K, L.ptr(zeros), L.ptr(res), L.ptr(ones), L.ptr(zeros), 1e-12,
+                                    M, N, K, L.ptr(o32), None, L.stream()), 'se_gemm_res_ln_bf16')
+    x = W.T[torch.arange(M) % K].double()                      # row m of the product = column (m % K) of W^T
+    ref = (x - x.mean(-1, keepdim=True)) / x.var(-1, unbiased=False, keepdim=True).sqrt()
+    assert (o32.double() - ref).abs().max().item() < 1e-5

@@ -54,6 +54,23 @@ def bench_gemm():
         print(f'gemm M={M} N={N} K={K} act={act} res={res}: {ms*1e3:8.1f} us  {2.0*M*N*K/ms/1e9:8.1f} TF/s  relerr {err:.1e}', flush=True)
 
 
+def bench_gemm_ln():
+    M, N = 32 * 1001, 768
+    for K in (768, 3072):
+        A = torch.randn(M, K, device=dev).bfloat16()
+        W = (torch.randn(N, K, device=dev) * 0.05).bfloat16()
+        bias, res = torch.randn(N, device=dev), torch.randn(M, N, device=dev)
+        lw, lb = torch.ones(N, device=dev), torch.zeros(N, device=dev)
+        o32 = torch.empty(M, N, device=dev)
+        o16 = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+
+        def run():
+            L.check(lib.se_gemm_res_ln_bf16(L.ptr(A), K, L.ptr(W), K, L.ptr(bias), L.ptr(res), L.ptr(lw), L.ptr(lb), 1e-12, M, N, K,
+                                            L.ptr(o32), L.ptr(o16), L.stream()), 'gemm_ln')
+        ms = timeit(run)
+        print(f'gemm+res+LN M={M} N={N} K={K}: {ms*1e3:8.1f} us  {2.0*M*N*K/ms/1e9:8.1f} TF/s', flush=True)
+
+
 def bench_mhsa():
     B, T, heads = 32, 1001, 12
     qkv = (torch.randn(B * T, 3 * 768, device=dev)).bfloat16()
@@ -83,6 +100,8 @@ if __name__ == '__main__':
     what = sys.argv[1] if len(sys.argv) > 1 else 'all'
     if what in ('gemm', 'all'):
         bench_gemm()
+    if what in ('gemmln', 'all'):
+        bench_gemm_ln()
     if what in ('mhsa', 'all'):
         bench_mhsa()
     if what in ('stft', 'all'):
