@@ -123,21 +123,23 @@ __global__ __launch_bounds__(256) void cast_pad_kernel(const float* __restrict__
   }
 }
 
-// lengths[b] = #frames whose feature sum != 0 (S3PRL process_input_data)
+// lengths[b] = #frames whose feature sum != 0 (S3PRL process_input_data).  One wave per frame (coalesced row read,
+// shuffle reduction), 4 frames per workgroup pass; per-utterance counts by one integer atomic per workgroup.
 __global__ __launch_bounds__(256) void valid_lengths_kernel(const float* __restrict__ feats, int T, int D, int32_t* __restrict__ lengths) {
   __shared__ int red[4];
-  const int b = blockIdx.x, tid = threadIdx.x;
+  const int b = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   int cnt = 0;
-  for (int t = tid; t < T; t += 256) {
+  for (int t = blockIdx.x * 4 + wv; t < T; t += gridDim.x * 4) {
     const float* fr = feats + ((size_t)b * T + t) * D;
     float s = 0.f;
-    for (int d = 0; d < D; ++d) s += fr[d];
+    for (int d = lane; d < D; d += 64) s += fr[d];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
     cnt += (s != 0.f) ? 1 : 0;
   }
-  for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off);
-  if ((tid & 63) == 0) red[tid >> 6] = cnt;
+  if (lane == 0) red[wv] = cnt;
   __syncthreads();
-  if (tid == 0) lengths[b] = red[0] + red[1] + red[2] + red[3];
+  if (threadIdx.x == 0) atomicAdd(&lengths[b], red[0] + red[1] + red[2] + red[3]);
 }
 
 // SpecHead.forward epilogue (model.py:121-125)
@@ -219,7 +221,8 @@ extern "C" int se_cast_f32_bf16(const float* x, size_t n, uint16_t* out, void* s
 
 extern "C" int se_valid_lengths_i32(const float* feats, int B, int T, int D, int32_t* lengths, void* stream) {
   SE_REQUIRE(feats && lengths && B > 0 && T > 0 && D > 0, "se_valid_lengths_i32: bad argument");
-  hipLaunchKernelGGL(se::valid_lengths_kernel, dim3(B), dim3(256), 0, se::as_stream(stream), feats, T, D, lengths);
+  SE_HIP(hipMemsetAsync(lengths, 0, sizeof(int32_t) * B, se::as_stream(stream)));
+  hipLaunchKernelGGL(se::valid_lengths_kernel, dim3(std::min(32, (T + 3) / 4), B), dim3(256), 0, se::as_stream(stream), feats, T, D, lengths);
   SE_LAUNCH_CHECK();
   return SE_OK;
 }
