@@ -99,16 +99,23 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    distributed = world > 1
+    distributed = world > 1 or 'RANK' in os.environ      # under torchrun always go through RCCL (also at N = 1)
     if not torch.cuda.is_available():
         print('bench.py needs an MI355X: the hot path has no CPU fallback', file=sys.stderr)
         sys.exit(2)
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
+    # RCCL prints a version banner on stdout at communicator creation; the contract is ONE JSON line on stdout, so
+    # everything before the final print goes to stderr at the file-descriptor level.
+    sys.stdout.flush()
+    saved_stdout_fd = os.dup(1)
+    os.dup2(2, 1)
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
         dist.init_process_group('nccl', device_id=dev)
+        dist.barrier()                      # creates the communicator now (not inside the timed region)
 
     from speech_enhancement_by_s3prl_amd import _lib, pipeline, synth
     lib = _lib.load()
@@ -197,8 +204,11 @@ def main():
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
+    sys.stdout.flush()
+    os.dup2(saved_stdout_fd, 1)
+    os.close(saved_stdout_fd)
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == '__main__':
