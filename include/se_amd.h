@@ -242,6 +242,33 @@ int se_layernorm_f32(const float* x, const float* w, const float* b, int M, int 
 int se_cast_f32_bf16(const float* x, size_t n, uint16_t* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Backward building blocks (row E2 beyond the linear heads: autograd through TransformerSpecPredictionHead /
+ * SpecHead, model.py:94-126, runner.py:459).  Mixed precision as the forward: bf16 GEMM operands, fp32 sums.
+ * The input gradient dX = dY . W is se_gemm_bf16 on a transposed bf16 weight copy (se_transpose_*).
+ * ---------------------------------------------------------------------------------------------- */
+/* out[c][r] = in[r][c], r < rows; out rows are ld_out long, zero filled for rows <= r < ld_out */
+int se_transpose_bf16(const uint16_t* in, int rows, int cols, int ld_in, uint16_t* out, int ld_out, void* stream);
+int se_transpose_f32_bf16(const float* in, int rows, int cols, int ld_in, uint16_t* out, int ld_out, void* stream);
+/* weight gradient dW[N,K] (+)= dY^T . X from the TRANSPOSED operands dYt (N, Mp), Xt (K, Mp) bf16 (reduction dim contiguous):
+ * split-K over Mp on the forward GEMM kernel + slab reduce.  Mp % splits == 0, (Mp / splits) % 64 == 0 and >= 128;
+ * workspace >= splits * N * K * 4 bytes. */
+int se_wgrad_bf16(const uint16_t* dYt, const uint16_t* Xt, int Mp, int N, int K, int splits, float* dW, int accumulate,
+                  void* workspace, size_t workspace_bytes, void* stream);
+/* bias gradient: out[c] (+)= sum_r x[r][c] */
+int se_colsum_f32(const float* x, int rows, int cols, int ld, float* out, int accumulate, void* stream);
+/* LayerNorm backward (TF style).  x_in = LayerNorm input (gelu_in: its pre-GELU value, i.e. y = LN(gelu(x_in)), and
+ * the returned gradient is wrt x_in).  dx / dx_bf16 (M, H); dgamma, dbeta (H) accumulated by atomics.  H = 768. */
+int se_layernorm_bwd_f32(const float* x_in, const float* dy, const float* w, int M, int H, float eps, int gelu_in,
+                         float* dx, uint16_t* dx_bf16, float* dgamma, float* dbeta, int accumulate, void* stream);
+/* y = LayerNorm(gelu(pre)) (spec-head transform, training path keeps `pre`).  H = 768. */
+int se_gelu_layernorm_f32(const float* pre, const float* w, const float* b, int M, int H, float eps,
+                          float* out_f32, uint16_t* out_bf16, void* stream);
+/* SpecHead.forward's epilogue (model.py:121-125) on a raw linear output p (n elements) and its backward wrt p */
+int se_spec_epilogue_f32(const float* p, size_t n, int log_target, int act, float eps, float* predicted, float* log_predicted, void* stream);
+int se_spec_epilogue_bwd_f32(const float* p, const float* d_pred, const float* d_logp, int M, int N, int ldp, int log_target,
+                             int act, float eps, float* dp_f32, uint16_t* dp_bf16, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Optional in-library timing for bench.py's roofline leg: HIP events recorded on the launch stream around
  * every kernel of a family while enabled.  kind: 0 = bf16 GEMM (work = 2MNK flop), 1 = MHSA (4 B h T^2 64 flop),
  * 2 = STFT, 3 = iSTFT (work = algorithmic bytes).  se_prof_read synchronises on the recorded events.

@@ -72,6 +72,14 @@ SIGNATURES = {
     'se_mhsa_fwd_bf16': (c_int, [_P, _P, c_int, c_int, c_int, _P, _P]),
     'se_layernorm_f32': (c_int, [_P, _P, _P, c_int, c_int, c_float, _P, _P, _P]),
     'se_cast_f32_bf16': (c_int, [_P, c_size_t, _P, _P]),
+    'se_transpose_bf16': (c_int, [_P, c_int, c_int, c_int, _P, c_int, _P]),
+    'se_transpose_f32_bf16': (c_int, [_P, c_int, c_int, c_int, _P, c_int, _P]),
+    'se_wgrad_bf16': (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, c_int, _P, c_size_t, _P]),
+    'se_colsum_f32': (c_int, [_P, c_int, c_int, c_int, _P, c_int, _P]),
+    'se_layernorm_bwd_f32': (c_int, [_P, _P, _P, c_int, c_int, c_float, c_int, _P, _P, _P, _P, c_int, _P]),
+    'se_gelu_layernorm_f32': (c_int, [_P, _P, _P, c_int, c_int, c_float, _P, _P, _P]),
+    'se_spec_epilogue_f32': (c_int, [_P, c_size_t, c_int, c_int, c_float, _P, _P, _P]),
+    'se_spec_epilogue_bwd_f32': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_float, _P, _P, _P]),
     'se_prof_enable': (c_int, [c_int]),
     'se_prof_reset': (c_int, []),
     'se_prof_read': (c_int, [c_int, POINTER(c_double), POINTER(c_double), POINTER(ctypes.c_longlong)]),

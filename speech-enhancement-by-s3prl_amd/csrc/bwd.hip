@@ -1,0 +1,226 @@
+// bwd.hip -- building blocks of the backward pass through the bf16 encoder / spec head (row E2 for C3 / C4):
+//   se_transpose_bf16     (rows, cols) -> (cols, ld_out) zero padded           operand layouts for the two GEMM forms below
+//   se_wgrad_bf16         dW[N,K] (+)= dY[M,N]^T . X[M,K]   weight gradient: both operands transposed so the reduction
+//                         dim (M = B*T) is contiguous, split-K over M on the forward GEMM kernel (gemm2), slab reduce
+//   se_colsum_f32         db[N] = sum_rows dY                bias gradient
+//   se_layernorm_bwd_f32  dx, dgamma, dbeta of the TF-style LayerNorm; optional GELU on the way in (spec head:
+//                         LN(gelu(pre))) with gelu' applied on the way out
+// The input gradient dX = dY . W needs no kernel of its own: it is se_gemm_bf16 on W^T (transposed bf16 weight copy).
+// Mixed precision as the forward: bf16 GEMM operands, fp32 accumulation / reductions.
+#include "common.h"
+#include "bf16.h"
+
+extern "C" int se_gemm2_splitk_launch(const uint16_t* A, int lda, const uint16_t* W, int ldw, int M, int N, int Kc, int splits,
+                                      float* partials, void* stream);
+
+namespace se {
+
+// out[c][r] = in[r][c] for r < rows, 0 for rows <= r < ld_out.  64 x 64 tiles through LDS.
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const uint16_t* __restrict__ in, int rows, int cols, int ld_in,
+                                                             uint16_t* __restrict__ out, int ld_out) {
+  __shared__ uint16_t tile[64][66];
+  const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    const int r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < rows && c < cols) ? in[(size_t)r * ld_in + c] : (uint16_t)0;
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < cols && r < ld_out) out[(size_t)c * ld_out + r] = tile[tx][i];
+  }
+}
+
+// same from an fp32 source (casts on the way): out[c][r] = bf16(in[r][c])
+__global__ __launch_bounds__(256) void transpose_f32_bf16_kernel(const float* __restrict__ in, int rows, int cols, int ld_in,
+                                                                 uint16_t* __restrict__ out, int ld_out) {
+  __shared__ uint16_t tile[64][66];
+  const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    const int r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < rows && c < cols) ? f2bf(in[(size_t)r * ld_in + c]) : (uint16_t)0;
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < cols && r < ld_out) out[(size_t)c * ld_out + r] = tile[tx][i];
+  }
+}
+
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ partials, int splits, size_t n, int accumulate,
+                                                          float* __restrict__ out) {
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    float s = accumulate ? out[i] : 0.f;
+    for (int k = 0; k < splits; ++k) s += partials[(size_t)k * n + i];
+    out[i] = s;
+  }
+}
+
+// colsum[c] += sum_r x[r][c]; grid.x over row chunks, 256 threads = 256 columns per grid.y
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int rows, int cols, int ld, int rows_per_block,
+                                                     float* __restrict__ out) {
+  const int c = blockIdx.y * 256 + threadIdx.x;
+  if (c >= cols) return;
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  float s = 0.f;
+  for (int r = r0; r < r1; ++r) s += x[(size_t)r * ld + c];
+  atomicAdd(&out[c], s);
+}
+
+__device__ __forceinline__ float gelu_grad(float x) {
+  // d/dx [x Phi(x)] = Phi(x) + x phi(x)
+  const float cdf = 0.5f * (1.0f + erf_as(x * 0.70710678118654752f));
+  const float pdf = 0.3989422804014327f * __builtin_amdgcn_exp2f(-0.72134752044448170f * x * x);   // exp(-x^2/2)/sqrt(2 pi)
+  return fmaf(x, pdf, cdf);
+}
+
+// One wave per row, H = 256 NV.  x_in: LayerNorm input (or its pre-GELU value when GELU_IN); dy: gradient of the output.
+// dx (fp32) and / or dx_bf16 written; dgamma / dbeta accumulated with one atomic per column per workgroup.
+template <int NV, int GELU_IN>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x_in, const float* __restrict__ dy,
+                                                            const float* __restrict__ w, int M, float eps, float* __restrict__ dx,
+                                                            uint16_t* __restrict__ dx_bf16, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, int rows_per_wave) {
+  constexpr int H = 256 * NV;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float4 gsum[NV], bsum[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) { gsum[i] = make_float4(0.f, 0.f, 0.f, 0.f); bsum[i] = make_float4(0.f, 0.f, 0.f, 0.f); }
+  float4 ww[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) ww[i] = *reinterpret_cast<const float4*>(w + (i * 64 + lane) * 4);
+  const int row0 = (blockIdx.x * 4 + wv) * rows_per_wave;
+  for (int row = row0; row < min(M, row0 + rows_per_wave); ++row) {
+    float4 pre[NV], v[NV], g[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      pre[i] = *reinterpret_cast<const float4*>(x_in + (size_t)row * H + (i * 64 + lane) * 4);
+      g[i] = *reinterpret_cast<const float4*>(dy + (size_t)row * H + (i * 64 + lane) * 4);
+      v[i] = pre[i];
+      if (GELU_IN) { v[i].x = gelu_erf(v[i].x); v[i].y = gelu_erf(v[i].y); v[i].z = gelu_erf(v[i].z); v[i].w = gelu_erf(v[i].w); }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    const float mean = s * (1.0f / H);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+      q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off);
+    const float rstd = 1.0f / sqrtf(q * (1.0f / H) + eps);
+    // xhat = v * rstd ; gh = dy * w ; dx = rstd (gh - mean(gh) - xhat mean(gh xhat))
+    float a = 0.f, bq = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      v[i].x *= rstd; v[i].y *= rstd; v[i].z *= rstd; v[i].w *= rstd;
+      gsum[i].x += g[i].x * v[i].x; gsum[i].y += g[i].y * v[i].y; gsum[i].z += g[i].z * v[i].z; gsum[i].w += g[i].w * v[i].w;
+      bsum[i].x += g[i].x; bsum[i].y += g[i].y; bsum[i].z += g[i].z; bsum[i].w += g[i].w;
+      g[i].x *= ww[i].x; g[i].y *= ww[i].y; g[i].z *= ww[i].z; g[i].w *= ww[i].w;
+      a += (g[i].x + g[i].y) + (g[i].z + g[i].w);
+      bq += (g[i].x * v[i].x + g[i].y * v[i].y) + (g[i].z * v[i].z + g[i].w * v[i].w);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off); bq += __shfl_xor(bq, off); }
+    a *= (1.0f / H);
+    bq *= (1.0f / H);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      float4 d;
+      d.x = rstd * (g[i].x - a - v[i].x * bq); d.y = rstd * (g[i].y - a - v[i].y * bq);
+      d.z = rstd * (g[i].z - a - v[i].z * bq); d.w = rstd * (g[i].w - a - v[i].w * bq);
+      if (GELU_IN) { d.x *= gelu_grad(pre[i].x); d.y *= gelu_grad(pre[i].y); d.z *= gelu_grad(pre[i].z); d.w *= gelu_grad(pre[i].w); }
+      const size_t o = (size_t)row * H + (i * 64 + lane) * 4;
+      if (dx) *reinterpret_cast<float4*>(dx + o) = d;
+      if (dx_bf16) *reinterpret_cast<uint2*>(dx_bf16 + o) = make_uint2(pack_bf16x2(d.x, d.y), pack_bf16x2(d.z, d.w));
+    }
+  }
+  // dgamma / dbeta: reduce the 4 waves through LDS, then one atomic per column per workgroup
+  __shared__ float red[2][4][H];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    *reinterpret_cast<float4*>(&red[0][wv][(i * 64 + lane) * 4]) = gsum[i];
+    *reinterpret_cast<float4*>(&red[1][wv][(i * 64 + lane) * 4]) = bsum[i];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < H; c += 256) {
+    if (dgamma) atomicAdd(&dgamma[c], red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
+    if (dbeta) atomicAdd(&dbeta[c], red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+  }
+}
+
+}  // namespace se
+
+extern "C" int se_transpose_bf16(const uint16_t* in, int rows, int cols, int ld_in, uint16_t* out, int ld_out, void* stream) {
+  SE_REQUIRE(in && out && rows > 0 && cols > 0 && ld_in >= cols && ld_out >= rows, "se_transpose_bf16: bad argument");
+  dim3 grid((ld_out + 63) / 64, (cols + 63) / 64);
+  SE_REQUIRE(grid.y <= 65535, "se_transpose_bf16: too many columns");
+  hipLaunchKernelGGL(se::transpose_bf16_kernel, grid, dim3(256), 0, se::as_stream(stream), in, rows, cols, ld_in, out, ld_out);
+  SE_LAUNCH_CHECK();
+  return SE_OK;
+}
+
+extern "C" int se_transpose_f32_bf16(const float* in, int rows, int cols, int ld_in, uint16_t* out, int ld_out, void* stream) {
+  SE_REQUIRE(in && out && rows > 0 && cols > 0 && ld_in >= cols && ld_out >= rows, "se_transpose_f32_bf16: bad argument");
+  dim3 grid((ld_out + 63) / 64, (cols + 63) / 64);
+  SE_REQUIRE(grid.y <= 65535, "se_transpose_f32_bf16: too many columns");
+  hipLaunchKernelGGL(se::transpose_f32_bf16_kernel, grid, dim3(256), 0, se::as_stream(stream), in, rows, cols, ld_in, out, ld_out);
+  SE_LAUNCH_CHECK();
+  return SE_OK;
+}
+
+// dW[N,K] (+)= dYt[N,Mp] . Xt[K,Mp]^T ; Mp = splits * Mc, Mc % 64 == 0, Mc >= 128 ; workspace >= splits * N * K floats
+extern "C" int se_wgrad_bf16(const uint16_t* dYt, const uint16_t* Xt, int Mp, int N, int K, int splits, float* dW, int accumulate,
+                             void* workspace, size_t workspace_bytes, void* stream) {
+  SE_REQUIRE(dYt && Xt && dW && workspace, "se_wgrad_bf16: null argument");
+  SE_REQUIRE(splits >= 1 && Mp % splits == 0, "se_wgrad_bf16: Mp must be a multiple of splits");
+  const int Mc = Mp / splits;
+  SE_REQUIRE(Mc % 64 == 0 && Mc >= 128, "se_wgrad_bf16: Mp / splits = %d must be a multiple of 64 and >= 128", Mc);
+  SE_REQUIRE(workspace_bytes >= (size_t)splits * N * K * sizeof(float), "se_wgrad_bf16: workspace too small");
+  SE_REQUIRE((((uintptr_t)dYt | (uintptr_t)Xt | (uintptr_t)workspace) % 16) == 0, "se_wgrad_bf16: operands must be 16-B aligned");
+  float* partials = reinterpret_cast<float*>(workspace);
+  int rc = se_gemm2_splitk_launch(dYt, Mp, Xt, Mp, N, K, Mc, splits, partials, stream);
+  if (rc) return rc;
+  const size_t n = (size_t)N * K;
+  hipLaunchKernelGGL(se::slab_reduce_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, se::as_stream(stream),
+                     partials, splits, n, accumulate, dW);
+  SE_LAUNCH_CHECK();
+  return SE_OK;
+}
+
+extern "C" int se_colsum_f32(const float* x, int rows, int cols, int ld, float* out, int accumulate, void* stream) {
+  SE_REQUIRE(x && out && rows > 0 && cols > 0 && ld >= cols, "se_colsum_f32: bad argument");
+  hipStream_t st = se::as_stream(stream);
+  if (!accumulate) SE_HIP(hipMemsetAsync(out, 0, sizeof(float) * cols, st));
+  const int rpb = 256;
+  dim3 grid((rows + rpb - 1) / rpb, (cols + 255) / 256);
+  hipLaunchKernelGGL(se::colsum_kernel, grid, dim3(256), 0, st, x, rows, cols, ld, rpb, out);
+  SE_LAUNCH_CHECK();
+  return SE_OK;
+}
+
+extern "C" int se_layernorm_bwd_f32(const float* x_in, const float* dy, const float* w, int M, int H, float eps, int gelu_in,
+                                    float* dx, uint16_t* dx_bf16, float* dgamma, float* dbeta, int accumulate, void* stream) {
+  SE_REQUIRE(x_in && dy && w && (dx || dx_bf16) && M > 0, "se_layernorm_bwd_f32: bad argument");
+  SE_REQUIRE(H == 768, "se_layernorm_bwd_f32: only H = 768 is built (got %d)", H);
+  hipStream_t st = se::as_stream(stream);
+  if (!accumulate) {
+    if (dgamma) SE_HIP(hipMemsetAsync(dgamma, 0, sizeof(float) * H, st));
+    if (dbeta) SE_HIP(hipMemsetAsync(dbeta, 0, sizeof(float) * H, st));
+  }
+  const int rows_per_wave = 16;
+  const int grid = (M + 4 * rows_per_wave - 1) / (4 * rows_per_wave);
+  if (gelu_in)
+    hipLaunchKernelGGL((se::layernorm_bwd_kernel<3, 1>), dim3(grid), dim3(256), 0, st, x_in, dy, w, M, eps, dx, dx_bf16, dgamma, dbeta, rows_per_wave);
+  else
+    hipLaunchKernelGGL((se::layernorm_bwd_kernel<3, 0>), dim3(grid), dim3(256), 0, st, x_in, dy, w, M, eps, dx, dx_bf16, dgamma, dbeta, rows_per_wave);
+  SE_LAUNCH_CHECK();
+  return SE_OK;
+}

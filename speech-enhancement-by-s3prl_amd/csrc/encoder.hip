@@ -23,7 +23,7 @@ constexpr int kMaxPos = 5008;     // 50 s of 10 ms frames (MAX_POSITIONS_LEN = 1
 constexpr int kInPad = 128;       // input feature dim padded to a multiple of the GEMM K tile
 
 // one wave per row; H = 64 * 4 * NV
-template <int NV>
+template <int NV, int GELU_IN = 0>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ pe, int T,
                                                         const float* __restrict__ w, const float* __restrict__ b, int M, float eps,
                                                         float* __restrict__ out_f32, uint16_t* __restrict__ out_bf16) {
@@ -35,6 +35,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   float4 v[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const float4*>(xr + (i * 64 + lane) * 4);
+  if (GELU_IN) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { v[i].x = gelu_erf(v[i].x); v[i].y = gelu_erf(v[i].y); v[i].z = gelu_erf(v[i].z); v[i].w = gelu_erf(v[i].w); }
+  }
   if (pe) {
     const float* pr = pe + (size_t)(row % T) * H;
 #pragma unroll
@@ -162,6 +166,36 @@ __global__ __launch_bounds__(256) void spec_epilogue_kernel(const float* __restr
   }
 }
 
+// backward of SpecHead.forward's epilogue (model.py:121-125) wrt the raw linear output p:
+//   log_target: predicted = act(exp(p)), log_predicted = p      -> dp = d_logp + d_pred act'(exp p) exp(p)
+//   else      : predicted = act(p),      log_predicted = log(p+eps) -> dp = d_pred act'(p) + d_logp / (p + eps)
+// writes dp as fp32 (M, N) and as bf16 (M, ldp) with columns N..ldp-1 zeroed (GEMM operand padding)
+__global__ __launch_bounds__(256) void spec_epilogue_bwd_kernel(const float* __restrict__ p, const float* __restrict__ d_pred,
+                                                                const float* __restrict__ d_logp, int M, int N, int ldp, int log_target,
+                                                                int act, float eps, float* __restrict__ dp_f32, uint16_t* __restrict__ dp_bf16) {
+  const size_t n = (size_t)M * ldp;
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const size_t r = i / ldp;
+    const int c = (int)(i - r * ldp);
+    float g = 0.f;
+    if (c < N) {
+      const size_t j = r * N + c;
+      const float v = p[j];
+      const float gp = d_pred ? d_pred[j] : 0.f, gl = d_logp ? d_logp[j] : 0.f;
+      if (log_target) {
+        const float e = expf(v);
+        const float da = (act == SE_ACT_RELU) ? (e > 0.f ? 1.f : 0.f) : 1.f;
+        g = gl + gp * da * e;
+      } else {
+        const float da = (act == SE_ACT_RELU) ? (v > 0.f ? 1.f : 0.f) : 1.f;
+        g = gp * da + gl / (v + eps);
+      }
+      if (dp_f32) dp_f32[j] = g;
+    }
+    if (dp_bf16) dp_bf16[i] = f2bf(g);
+  }
+}
+
 }  // namespace se
 
 struct se_encoder {
@@ -208,6 +242,36 @@ extern "C" int se_layernorm_f32(const float* x, const float* w, const float* b, 
                                 float* out_f32, uint16_t* out_bf16, void* stream) {
   SE_REQUIRE(x && w && b && (out_f32 || out_bf16) && M > 0 && H > 0, "se_layernorm_f32: bad argument");
   return launch_layernorm(x, nullptr, 1, w, b, M, H, eps, out_f32, out_bf16, se::as_stream(stream));
+}
+
+extern "C" int se_gelu_layernorm_f32(const float* pre, const float* w, const float* b, int M, int H, float eps,
+                                     float* out_f32, uint16_t* out_bf16, void* stream) {
+  SE_REQUIRE(pre && w && b && (out_f32 || out_bf16) && M > 0, "se_gelu_layernorm_f32: bad argument");
+  SE_REQUIRE(H == 768, "se_gelu_layernorm_f32: only H = 768 is built (got %d)", H);
+  hipLaunchKernelGGL((se::layernorm_kernel<3, 1>), dim3((M + 3) / 4), dim3(256), 0, se::as_stream(stream), pre, nullptr, 1, w, b, M, eps, out_f32, out_bf16);
+  SE_LAUNCH_CHECK();
+  return SE_OK;
+}
+
+extern "C" int se_spec_epilogue_f32(const float* p, size_t n, int log_target, int act, float eps, float* predicted, float* log_predicted,
+                                    void* stream) {
+  SE_REQUIRE(p && n > 0 && (predicted || log_predicted), "se_spec_epilogue_f32: bad argument");
+  const int grid = (int)std::min<size_t>((n + 255) / 256, 8192);
+  hipLaunchKernelGGL(se::spec_epilogue_kernel, dim3(grid), dim3(256), 0, se::as_stream(stream), p, n, log_target, act, eps, predicted, log_predicted);
+  SE_LAUNCH_CHECK();
+  return SE_OK;
+}
+
+extern "C" int se_spec_epilogue_bwd_f32(const float* p, const float* d_pred, const float* d_logp, int M, int N, int ldp, int log_target,
+                                        int act, float eps, float* dp_f32, uint16_t* dp_bf16, void* stream) {
+  SE_REQUIRE(p && (d_pred || d_logp) && (dp_f32 || dp_bf16) && M > 0 && N > 0 && ldp >= N, "se_spec_epilogue_bwd_f32: bad argument");
+  SE_REQUIRE(act == SE_ACT_RELU || act == SE_ACT_IDENTITY, "se_spec_epilogue_bwd_f32: activation must be ReLU or Identity");
+  const size_t n = (size_t)M * ldp;
+  const int grid = (int)std::min<size_t>((n + 255) / 256, 8192);
+  hipLaunchKernelGGL(se::spec_epilogue_bwd_kernel, dim3(grid), dim3(256), 0, se::as_stream(stream), p, d_pred, d_logp, M, N, ldp, log_target,
+                     act, eps, dp_f32, dp_bf16);
+  SE_LAUNCH_CHECK();
+  return SE_OK;
 }
 
 extern "C" int se_cast_f32_bf16(const float* x, size_t n, uint16_t* out, void* stream) {

@@ -63,7 +63,7 @@ template <int WR, int STAGES, int PINGPONG, int ACT, int EF>
 __global__ __launch_bounds__(128 * WR) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm2_bf16_kernel(
     const uint16_t* __restrict__ A, int lda, const uint16_t* __restrict__ W, int ldw, const float* __restrict__ bias,
     const float* __restrict__ residual, int M, int N, int K, int act, uint16_t* __restrict__ out_bf16,
-    float* __restrict__ out_f32, int ldc, int tiles_m, int tiles_n, int vec_ok, int dbg, int group_m) {
+    float* __restrict__ out_f32, int ldc, int tiles_m, int tiles_n, int vec_ok, int dbg, int group_m, size_t split_out_stride) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using C = G2<WR, STAGES>;
   constexpr int k2BM = C::BM, k2ABytes = C::ABytes, k2Stage = C::Stage, k2Stages = STAGES, NW = C::NW;
@@ -72,6 +72,13 @@ __global__ __launch_bounds__(128 * WR) __attribute__((amdgpu_waves_per_eu(2, 2))
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
+  // split-K (weight-gradient GEMMs reduce over B*T ~ 32 000 rows into a small output): blockIdx.y walks K chunks of
+  // length K (the kernel's K argument is the CHUNK length); each split writes its own fp32 partial slab
+  if (gridDim.y > 1) {
+    A += (size_t)blockIdx.y * K;
+    W += (size_t)blockIdx.y * K;
+    if (out_f32) out_f32 += (size_t)blockIdx.y * split_out_stride;
+  }
 
   const int nwg = tiles_m * tiles_n;
   int id;
@@ -322,7 +329,7 @@ __global__ __launch_bounds__(128 * WR) __attribute__((amdgpu_waves_per_eu(2, 2))
 namespace {
 struct GArgs {
   const uint16_t* A; int lda; const uint16_t* W; int ldw; const float* bias; const float* residual; int M, N, K, act;
-  uint16_t* out_bf16; float* out_f32; int ldc, vec_ok, dbg; hipStream_t st; int group_m;
+  uint16_t* out_bf16; float* out_f32; int ldc, vec_ok, dbg; hipStream_t st; int group_m; int splits; size_t split_stride;
 };
 
 template <int WR, int STAGES, int PP, int ACT, int EF>
@@ -334,8 +341,8 @@ int launch_one(const GArgs& g) {
     SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::gemm2_bf16_kernel<WR, STAGES, PP, ACT, EF>), hipFuncAttributeMaxDynamicSharedMemorySize, C::Lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL((se::gemm2_bf16_kernel<WR, STAGES, PP, ACT, EF>), dim3(tiles_m * tiles_n), dim3(C::Threads), C::Lds, g.st, g.A, g.lda, g.W,
-                     g.ldw, g.bias, g.residual, g.M, g.N, g.K, g.act, g.out_bf16, g.out_f32, g.ldc, tiles_m, tiles_n, g.vec_ok, g.dbg, g.group_m);
+  hipLaunchKernelGGL((se::gemm2_bf16_kernel<WR, STAGES, PP, ACT, EF>), dim3(tiles_m * tiles_n, g.splits), dim3(C::Threads), C::Lds, g.st, g.A, g.lda, g.W,
+                     g.ldw, g.bias, g.residual, g.M, g.N, g.K, g.act, g.out_bf16, g.out_f32, g.ldc, tiles_m, tiles_n, g.vec_ok, g.dbg, g.group_m, g.split_stride);
   SE_LAUNCH_CHECK();
   return SE_OK;
 }
@@ -370,9 +377,18 @@ extern "C" int se_gemm2_launch(const uint16_t* A, int lda, const uint16_t* W, in
     group_m = gm ? atoi(gm) : 1;
     if (group_m < 1) group_m = 1;
   }
-  GArgs g{A, lda, W, ldw, bias, residual_f32, M, N, K, act, out_bf16, out_f32, ldc, vec_ok, dbg, se::as_stream(stream), group_m};
+  GArgs g{A, lda, W, ldw, bias, residual_f32, M, N, K, act, out_bf16, out_f32, ldc, vec_ok, dbg, se::as_stream(stream), group_m, 1, 0};
   se::ProfScope prof(se::kProfGemm, 2.0 * M * (double)N * K, g.st);
   if (variant == 4) return launch_cfg<2, 2, 0>(g);
   if (variant == 3 && K >= 2 * se::k2BK) return launch_cfg<4, 3, 1>(g);
+  return launch_cfg<4, 3, 0>(g);
+}
+
+// split-K launcher for the weight-gradient GEMM (bwd.hip): C_s[M,N] = A[:, s*Kc:(s+1)*Kc] . W[:, s*Kc:(s+1)*Kc]^T, fp32 slabs
+extern "C" int se_gemm2_splitk_launch(const uint16_t* A, int lda, const uint16_t* W, int ldw, int M, int N, int Kc, int splits,
+                                      float* partials, void* stream) {
+  GArgs g{A, lda, W, ldw, nullptr, nullptr, M, N, Kc, SE_ACT_IDENTITY, nullptr, partials, N, (N % 4 == 0) ? 1 : 0, 0,
+          se::as_stream(stream), 1, splits, (size_t)M * N};
+  if (Kc >= 2 * se::k2BK) return launch_cfg<4, 3, 1>(g);
   return launch_cfg<4, 3, 0>(g);
 }

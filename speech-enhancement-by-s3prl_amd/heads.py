@@ -119,8 +119,15 @@ class SpecHead(nn.Module):
                     nn.init.constant_(param.data, 0)
 
     def forward(self, features, **kwargs):
-        predicted, log_predicted = self.spechead._engine.spechead(self.spechead, None, features, mode='full',
-                                                                  log_target=self.log, act=self.activation, eps=self.eps)
+        sh = self.spechead
+        if sh._needs_grad():
+            # fine-tuning the head on (frozen) upstream features: forward keeps intermediates, backward on the HIP kernels
+            from .spechead_train import SpecHeadTrainFn
+            predicted, log_predicted = SpecHeadTrainFn.apply(features, sh.dense.weight, sh.dense.bias, sh.LayerNorm.weight, sh.LayerNorm.bias,
+                                                             sh.output.weight, sh.output.bias, sh.LayerNorm.variance_epsilon, self.log,
+                                                             _act_id(self.activation), self.eps)
+            return predicted, {'log_predicted': log_predicted}
+        predicted, log_predicted = sh._engine.spechead(sh, None, features, mode='full', log_target=self.log, act=self.activation, eps=self.eps)
         return predicted, {'log_predicted': log_predicted}
 
 

@@ -102,7 +102,16 @@ class TransformerSpecPredictionHead(nn.Module):
             raise NotImplementedError("only hidden_act 'gelu' (config/pretrain_sample.yaml:8) is supported")
         self._engine = _Engine()
 
+    def _needs_grad(self):
+        return torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+
     def forward(self, hidden_states):
+        if self._needs_grad():
+            # training path (kept intermediates + HIP backward); `raw` = log_predicted of a log-target, identity-activation epilogue
+            from .spechead_train import SpecHeadTrainFn
+            _, raw = SpecHeadTrainFn.apply(hidden_states, self.dense.weight, self.dense.bias, self.LayerNorm.weight, self.LayerNorm.bias,
+                                           self.output.weight, self.output.bias, self.LayerNorm.variance_epsilon, True, 0, 0.0)
+            return raw, None
         raw = self._engine.spechead(self, None, hidden_states, mode='raw')
         return raw, None
 
