@@ -269,9 +269,43 @@ int se_spec_epilogue_bwd_f32(const float* p, const float* d_pred, const float* d
                              int act, float eps, float* dp_f32, uint16_t* dp_bf16, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Training path of the encoder (rows B1-B3 under autograd; C4 `Mockingjay` fine-tune and E2: model.py:163-171,
+ * runner.py:453-471).  Replaces what torch autograd records / replays through TRANSFORMER.forward.
+ * Dropout is not applied.  hidden_size must be 768 (256 is also built, for small-size parity tests).
+ * ---------------------------------------------------------------------------------------------- */
+/* flash MHSA forward that also stores the per-(utterance, head, query) log-sum-exp (log2 domain), (B, heads, T) fp32 */
+int se_mhsa_fwd_lse_bf16(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, float* lse, void* stream);
+/* flash MHSA backward: d_ctx (B*T, H) bf16 -> dqkv (B*T, 3H) bf16 = [dQ | dK | dV]; dvec (B, heads, T) fp32 scratch */
+int se_mhsa_bwd_bf16(const uint16_t* qkv, const uint16_t* ctx, const uint16_t* d_ctx, const float* lse, const int32_t* lengths,
+                     int B, int T, int heads, uint16_t* dqkv, float* dvec, void* stream);
+/* y = gelu(x) and dx = dy * gelu'(x), bf16 arrays of n elements (n % 8 == 0) */
+int se_gelu_bf16(const uint16_t* x, size_t n, uint16_t* y, void* stream);
+int se_gelu_bwd_bf16(const uint16_t* dy, const uint16_t* x, size_t n, uint16_t* dx, void* stream);
+
+/* DEVICE pointers to the fp32 gradients, same members / layouts as se_encoder_weights (without the spec head) */
+typedef struct se_encoder_grads {
+  float *in_w, *in_b, *in_ln_w, *in_ln_b;
+  float* const *q_w, * const *q_b, * const *k_w, * const *k_b, * const *v_w, * const *v_b;
+  float* const *ao_w, * const *ao_b, * const *aln_w, * const *aln_b;
+  float* const *ff1_w, * const *ff1_b, * const *ff2_w, * const *ff2_b, * const *oln_w, * const *oln_b;
+} se_encoder_grads;
+
+/* re-pack the encoder's bf16 operand copies from DEVICE fp32 master weights (after each optimizer step; the spec-head
+ * members of `w` are ignored) */
+int se_encoder_refresh_bf16(se_encoder* enc, const se_encoder_weights* w, void* stream);
+size_t se_encoder_saved_bytes(const se_encoder* enc, int B, int T);
+size_t se_encoder_train_workspace_bytes(const se_encoder* enc, int B, int T);
+/* forward that keeps the activations the backward needs in `saved` (caller-owned, se_encoder_saved_bytes) */
+int se_encoder_fwd_train_bf16(const se_encoder* enc, const float* feats, const int32_t* lengths, int B, int T, float* hidden,
+                              void* saved, size_t saved_bytes, void* workspace, size_t workspace_bytes, void* stream);
+/* backward: d_hidden (B, T, H) fp32 -> every parameter gradient (overwritten, not accumulated) */
+int se_encoder_bwd_bf16(const se_encoder* enc, const int32_t* lengths, int B, int T, const float* d_hidden, const void* saved,
+                        size_t saved_bytes, const se_encoder_grads* grads, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Optional in-library timing for bench.py's roofline leg: HIP events recorded on the launch stream around
  * every kernel of a family while enabled.  kind: 0 = bf16 GEMM (work = 2MNK flop), 1 = MHSA (4 B h T^2 64 flop),
- * 2 = STFT, 3 = iSTFT (work = algorithmic bytes).  se_prof_read synchronises on the recorded events.
+ * 2 = STFT, 3 = iSTFT (work = algorithmic bytes), 4 = LayerNorm, 5 = head, 6 = MHSA backward (14 B h T^2 64 flop).  se_prof_read synchronises on the recorded events.
  * ---------------------------------------------------------------------------------------------- */
 int se_prof_enable(int on);
 int se_prof_reset(void);

@@ -40,6 +40,12 @@ class EncoderWeights(ctypes.Structure):
                 [(n, _FP) for n in ('sh_dense_w', 'sh_dense_b', 'sh_ln_w', 'sh_ln_b', 'sh_out_w', 'sh_out_b')])
 
 
+class EncoderGrads(ctypes.Structure):
+    _fields_ = ([(n, _FP) for n in ('in_w', 'in_b', 'in_ln_w', 'in_ln_b')] +
+                [(n, _FPP) for n in ('q_w', 'q_b', 'k_w', 'k_b', 'v_w', 'v_b', 'ao_w', 'ao_b', 'aln_w', 'aln_b',
+                                     'ff1_w', 'ff1_b', 'ff2_w', 'ff2_b', 'oln_w', 'oln_b')])
+
+
 _P = c_void_p
 # name -> (restype, argtypes); mirrors include/se_amd.h one to one
 SIGNATURES = {
@@ -80,6 +86,15 @@ SIGNATURES = {
     'se_gelu_layernorm_f32': (c_int, [_P, _P, _P, c_int, c_int, c_float, _P, _P, _P]),
     'se_spec_epilogue_f32': (c_int, [_P, c_size_t, c_int, c_int, c_float, _P, _P, _P]),
     'se_spec_epilogue_bwd_f32': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_float, _P, _P, _P]),
+    'se_mhsa_fwd_lse_bf16': (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P]),
+    'se_mhsa_bwd_bf16': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P]),
+    'se_gelu_bf16': (c_int, [_P, c_size_t, _P, _P]),
+    'se_gelu_bwd_bf16': (c_int, [_P, _P, c_size_t, _P, _P]),
+    'se_encoder_refresh_bf16': (c_int, [_P, POINTER(EncoderWeights), _P]),
+    'se_encoder_saved_bytes': (c_size_t, [_P, c_int, c_int]),
+    'se_encoder_train_workspace_bytes': (c_size_t, [_P, c_int, c_int]),
+    'se_encoder_fwd_train_bf16': (c_int, [_P, _P, _P, c_int, c_int, _P, _P, c_size_t, _P, c_size_t, _P]),
+    'se_encoder_bwd_bf16': (c_int, [_P, _P, c_int, c_int, _P, _P, c_size_t, POINTER(EncoderGrads), _P, c_size_t, _P]),
     'se_prof_enable': (c_int, [c_int]),
     'se_prof_reset': (c_int, []),
     'se_prof_read': (c_int, [c_int, POINTER(c_double), POINTER(c_double), POINTER(ctypes.c_longlong)]),

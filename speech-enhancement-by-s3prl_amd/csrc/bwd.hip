@@ -9,6 +9,7 @@
 // Mixed precision as the forward: bf16 GEMM operands, fp32 accumulation / reductions.
 #include "common.h"
 #include "bf16.h"
+#include "encoder_impl.h"
 
 extern "C" int se_gemm2_splitk_launch(const uint16_t* A, int lda, const uint16_t* W, int ldw, int M, int N, int Kc, int splits,
                                       float* partials, void* stream);
@@ -69,6 +70,17 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
   atomicAdd(&out[c], s);
 }
 
+// bf16 source: one thread per column, 64 rows per workgroup row-chunk
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const uint16_t* __restrict__ x, int rows, int cols, int ld, int rows_per_block,
+                                                          float* __restrict__ out) {
+  const int c = blockIdx.y * 256 + threadIdx.x;
+  if (c >= cols) return;
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  float s = 0.f;
+  for (int r = r0; r < r1; ++r) s += bf2f(x[(size_t)r * ld + c]);
+  atomicAdd(&out[c], s);
+}
+
 __device__ __forceinline__ float gelu_grad(float x) {
   // d/dx [x Phi(x)] = Phi(x) + x phi(x)
   const float cdf = 0.5f * (1.0f + erf_as(x * 0.70710678118654752f));
@@ -76,10 +88,39 @@ __device__ __forceinline__ float gelu_grad(float x) {
   return fmaf(x, pdf, cdf);
 }
 
+// y = gelu(x), bf16 -> bf16, 8 elements per thread (FFN activation of the training forward, which keeps x)
+__global__ __launch_bounds__(256) void gelu_bf16_kernel(const uint16_t* __restrict__ x, size_t n8, uint16_t* __restrict__ y) {
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+    const uint4 v = reinterpret_cast<const uint4*>(x)[i];
+    const uint32_t in[4] = {v.x, v.y, v.z, v.w};
+    uint32_t o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = pack_bf16x2(gelu_erf(bf2f((uint16_t)(in[k] & 0xffffu))), gelu_erf(bf2f((uint16_t)(in[k] >> 16))));
+    reinterpret_cast<uint4*>(y)[i] = make_uint4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+// dx = dy * gelu'(x), all bf16
+__global__ __launch_bounds__(256) void gelu_bwd_bf16_kernel(const uint16_t* __restrict__ dy, const uint16_t* __restrict__ x, size_t n8,
+                                                            uint16_t* __restrict__ dx) {
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+    const uint4 g = reinterpret_cast<const uint4*>(dy)[i];
+    const uint4 v = reinterpret_cast<const uint4*>(x)[i];
+    const uint32_t gi[4] = {g.x, g.y, g.z, g.w}, vi[4] = {v.x, v.y, v.z, v.w};
+    uint32_t o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      o[k] = pack_bf16x2(bf2f((uint16_t)(gi[k] & 0xffffu)) * gelu_grad(bf2f((uint16_t)(vi[k] & 0xffffu))),
+                         bf2f((uint16_t)(gi[k] >> 16)) * gelu_grad(bf2f((uint16_t)(vi[k] >> 16))));
+    reinterpret_cast<uint4*>(dx)[i] = make_uint4(o[0], o[1], o[2], o[3]);
+  }
+}
+
 // One wave per row, H = 256 NV.  x_in: LayerNorm input (or its pre-GELU value when GELU_IN); dy: gradient of the output.
 // dx (fp32) and / or dx_bf16 written; dgamma / dbeta accumulated with one atomic per column per workgroup.
 template <int NV, int GELU_IN>
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x_in, const float* __restrict__ dy,
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x_in, const float* __restrict__ pe, int T,
+                                                            const float* __restrict__ dy,
                                                             const float* __restrict__ w, int M, float eps, float* __restrict__ dx,
                                                             uint16_t* __restrict__ dx_bf16, float* __restrict__ dgamma,
                                                             float* __restrict__ dbeta, int rows_per_wave) {
@@ -98,6 +139,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     for (int i = 0; i < NV; ++i) {
       pre[i] = *reinterpret_cast<const float4*>(x_in + (size_t)row * H + (i * 64 + lane) * 4);
       g[i] = *reinterpret_cast<const float4*>(dy + (size_t)row * H + (i * 64 + lane) * 4);
+      if (pe) {               // input stage: LayerNorm(x W^T + b + positional encoding)
+        const float4 pp = *reinterpret_cast<const float4*>(pe + (size_t)(row % T) * H + (i * 64 + lane) * 4);
+        pre[i].x += pp.x; pre[i].y += pp.y; pre[i].z += pp.z; pre[i].w += pp.w;
+      }
       v[i] = pre[i];
       if (GELU_IN) { v[i].x = gelu_erf(v[i].x); v[i].y = gelu_erf(v[i].y); v[i].z = gelu_erf(v[i].z); v[i].w = gelu_erf(v[i].w); }
     }
@@ -206,21 +251,57 @@ extern "C" int se_colsum_f32(const float* x, int rows, int cols, int ld, float* 
   return SE_OK;
 }
 
-extern "C" int se_layernorm_bwd_f32(const float* x_in, const float* dy, const float* w, int M, int H, float eps, int gelu_in,
-                                    float* dx, uint16_t* dx_bf16, float* dgamma, float* dbeta, int accumulate, void* stream) {
-  SE_REQUIRE(x_in && dy && w && (dx || dx_bf16) && M > 0, "se_layernorm_bwd_f32: bad argument");
-  SE_REQUIRE(H == 768, "se_layernorm_bwd_f32: only H = 768 is built (got %d)", H);
-  hipStream_t st = se::as_stream(stream);
+int se::launch_layernorm_bwd(const float* x_in, const float* pe, int T, const float* dy, const float* w, int M, int H, float eps, int gelu_in,
+                             float* dx, uint16_t* dx_bf16, float* dgamma, float* dbeta, int accumulate, hipStream_t st) {
+  SE_REQUIRE(H == 768 || H == 256, "layernorm backward: only H = 768 / 256 are built (got %d)", H);
   if (!accumulate) {
     if (dgamma) SE_HIP(hipMemsetAsync(dgamma, 0, sizeof(float) * H, st));
     if (dbeta) SE_HIP(hipMemsetAsync(dbeta, 0, sizeof(float) * H, st));
   }
   const int rows_per_wave = 16;
   const int grid = (M + 4 * rows_per_wave - 1) / (4 * rows_per_wave);
-  if (gelu_in)
-    hipLaunchKernelGGL((se::layernorm_bwd_kernel<3, 1>), dim3(grid), dim3(256), 0, st, x_in, dy, w, M, eps, dx, dx_bf16, dgamma, dbeta, rows_per_wave);
-  else
-    hipLaunchKernelGGL((se::layernorm_bwd_kernel<3, 0>), dim3(grid), dim3(256), 0, st, x_in, dy, w, M, eps, dx, dx_bf16, dgamma, dbeta, rows_per_wave);
+  if (H == 768) {
+    if (gelu_in)
+      hipLaunchKernelGGL((se::layernorm_bwd_kernel<3, 1>), dim3(grid), dim3(256), 0, st, x_in, pe, T, dy, w, M, eps, dx, dx_bf16, dgamma, dbeta, rows_per_wave);
+    else
+      hipLaunchKernelGGL((se::layernorm_bwd_kernel<3, 0>), dim3(grid), dim3(256), 0, st, x_in, pe, T, dy, w, M, eps, dx, dx_bf16, dgamma, dbeta, rows_per_wave);
+  } else {
+    if (gelu_in)
+      hipLaunchKernelGGL((se::layernorm_bwd_kernel<1, 1>), dim3(grid), dim3(256), 0, st, x_in, pe, T, dy, w, M, eps, dx, dx_bf16, dgamma, dbeta, rows_per_wave);
+    else
+      hipLaunchKernelGGL((se::layernorm_bwd_kernel<1, 0>), dim3(grid), dim3(256), 0, st, x_in, pe, T, dy, w, M, eps, dx, dx_bf16, dgamma, dbeta, rows_per_wave);
+  }
+  SE_LAUNCH_CHECK();
+  return SE_OK;
+}
+
+extern "C" int se_layernorm_bwd_f32(const float* x_in, const float* dy, const float* w, int M, int H, float eps, int gelu_in,
+                                    float* dx, uint16_t* dx_bf16, float* dgamma, float* dbeta, int accumulate, void* stream) {
+  SE_REQUIRE(x_in && dy && w && (dx || dx_bf16) && M > 0, "se_layernorm_bwd_f32: bad argument");
+  return se::launch_layernorm_bwd(x_in, nullptr, 1, dy, w, M, H, eps, gelu_in, dx, dx_bf16, dgamma, dbeta, accumulate, se::as_stream(stream));
+}
+
+int se::launch_colsum_bf16(const uint16_t* x, int rows, int cols, int ld, float* out, hipStream_t st) {
+  SE_HIP(hipMemsetAsync(out, 0, sizeof(float) * cols, st));
+  const int rpb = 256;
+  dim3 grid((rows + rpb - 1) / rpb, (cols + 255) / 256);
+  hipLaunchKernelGGL(se::colsum_bf16_kernel, grid, dim3(256), 0, st, x, rows, cols, ld, rpb, out);
+  SE_LAUNCH_CHECK();
+  return SE_OK;
+}
+
+extern "C" int se_gelu_bf16(const uint16_t* x, size_t n, uint16_t* y, void* stream) {
+  SE_REQUIRE(x && y && n > 0 && n % 8 == 0, "se_gelu_bf16: n must be a positive multiple of 8");
+  const size_t n8 = n / 8;
+  hipLaunchKernelGGL(se::gelu_bf16_kernel, dim3((unsigned)std::min<size_t>((n8 + 255) / 256, 16384)), dim3(256), 0, se::as_stream(stream), x, n8, y);
+  SE_LAUNCH_CHECK();
+  return SE_OK;
+}
+
+extern "C" int se_gelu_bwd_bf16(const uint16_t* dy, const uint16_t* x, size_t n, uint16_t* dx, void* stream) {
+  SE_REQUIRE(dy && x && dx && n > 0 && n % 8 == 0, "se_gelu_bwd_bf16: n must be a positive multiple of 8");
+  const size_t n8 = n / 8;
+  hipLaunchKernelGGL(se::gelu_bwd_bf16_kernel, dim3((unsigned)std::min<size_t>((n8 + 255) / 256, 16384)), dim3(256), 0, se::as_stream(stream), dy, x, n8, dx);
   SE_LAUNCH_CHECK();
   return SE_OK;
 }

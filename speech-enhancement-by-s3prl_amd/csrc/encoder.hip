@@ -16,11 +16,9 @@
 #include <vector>
 #include "common.h"
 #include "bf16.h"
+#include "encoder_impl.h"
 
 namespace se {
-
-constexpr int kMaxPos = 5008;     // 50 s of 10 ms frames (MAX_POSITIONS_LEN = 16000*50 samples, runner.py:32)
-constexpr int kInPad = 128;       // input feature dim padded to a multiple of the GEMM K tile
 
 // one wave per row; H = 64 * 4 * NV
 template <int NV, int GELU_IN = 0>
@@ -198,22 +196,6 @@ __global__ __launch_bounds__(256) void spec_epilogue_bwd_kernel(const float* __r
 
 }  // namespace se
 
-struct se_encoder {
-  se_encoder_config cfg;
-  void* blob;          // one device allocation
-  size_t blob_bytes;
-  // device views
-  uint16_t* in_w;      // (H, kInPad) bf16
-  float *in_b, *in_ln_w, *in_ln_b, *pe;
-  struct Layer {
-    uint16_t *qkv_w, *ao_w, *ff1_w, *ff2_w;
-    float *qkv_b, *ao_b, *aln_w, *aln_b, *ff1_b, *ff2_b, *oln_w, *oln_b;
-  };
-  std::vector<Layer> layers;
-  uint16_t *sh_dense_w, *sh_out_w;
-  float *sh_dense_b, *sh_ln_w, *sh_ln_b, *sh_out_b;
-};
-
 static inline uint16_t host_f2bf(float f) {   // round to nearest even, NaN kept quiet
   uint32_t u;
   memcpy(&u, &f, 4);
@@ -221,8 +203,15 @@ static inline uint16_t host_f2bf(float f) {   // round to nearest even, NaN kept
   return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
 }
 
-static int launch_layernorm(const float* x, const float* pe, int T, const float* w, const float* b, int M, int H, float eps,
-                            float* out_f32, uint16_t* out_bf16, hipStream_t st) {
+int se::launch_cast_pad(const float* x, size_t rows, int cols, int ld_out, uint16_t* out, hipStream_t st) {
+  const int grid = (int)std::min<size_t>((rows * (size_t)(ld_out / 4) + 255) / 256, 8192);
+  hipLaunchKernelGGL(se::cast_pad_kernel, dim3(grid), dim3(256), 0, st, x, rows, cols, ld_out, out);
+  SE_LAUNCH_CHECK();
+  return SE_OK;
+}
+
+int se::launch_layernorm(const float* x, const float* pe, int T, const float* w, const float* b, int M, int H, float eps,
+                         float* out_f32, uint16_t* out_bf16, hipStream_t st) {
   if (H == 768) {
     hipLaunchKernelGGL((se::layernorm_kernel<3>), dim3((M + 3) / 4), dim3(256), 0, st, x, pe, T, w, b, M, eps, out_f32, out_bf16);
   } else if (H == 256) {
@@ -241,14 +230,17 @@ static int launch_layernorm(const float* x, const float* pe, int T, const float*
 extern "C" int se_layernorm_f32(const float* x, const float* w, const float* b, int M, int H, float eps,
                                 float* out_f32, uint16_t* out_bf16, void* stream) {
   SE_REQUIRE(x && w && b && (out_f32 || out_bf16) && M > 0 && H > 0, "se_layernorm_f32: bad argument");
-  return launch_layernorm(x, nullptr, 1, w, b, M, H, eps, out_f32, out_bf16, se::as_stream(stream));
+  return se::launch_layernorm(x, nullptr, 1, w, b, M, H, eps, out_f32, out_bf16, se::as_stream(stream));
 }
 
 extern "C" int se_gelu_layernorm_f32(const float* pre, const float* w, const float* b, int M, int H, float eps,
                                      float* out_f32, uint16_t* out_bf16, void* stream) {
   SE_REQUIRE(pre && w && b && (out_f32 || out_bf16) && M > 0, "se_gelu_layernorm_f32: bad argument");
-  SE_REQUIRE(H == 768, "se_gelu_layernorm_f32: only H = 768 is built (got %d)", H);
-  hipLaunchKernelGGL((se::layernorm_kernel<3, 1>), dim3((M + 3) / 4), dim3(256), 0, se::as_stream(stream), pre, nullptr, 1, w, b, M, eps, out_f32, out_bf16);
+  SE_REQUIRE(H == 768 || H == 256, "se_gelu_layernorm_f32: only H = 768 / 256 are built (got %d)", H);
+  if (H == 768)
+    hipLaunchKernelGGL((se::layernorm_kernel<3, 1>), dim3((M + 3) / 4), dim3(256), 0, se::as_stream(stream), pre, nullptr, 1, w, b, M, eps, out_f32, out_bf16);
+  else
+    hipLaunchKernelGGL((se::layernorm_kernel<1, 1>), dim3((M + 3) / 4), dim3(256), 0, se::as_stream(stream), pre, nullptr, 1, w, b, M, eps, out_f32, out_bf16);
   SE_LAUNCH_CHECK();
   return SE_OK;
 }
@@ -429,7 +421,7 @@ struct Ws {
   float *x_f32, *tmp;
   size_t total;
 };
-inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+using se::al256;
 Ws carve(const se_encoder* e, size_t M, char* base) {
   const size_t H = e->cfg.hidden, I = e->cfg.intermediate;
   Ws w;
@@ -472,7 +464,7 @@ extern "C" int se_encoder_fwd_bf16(const se_encoder* enc, const float* feats, co
     SE_LAUNCH_CHECK();
   }
   if ((rc = se_gemm_bf16(w.xin, se::kInPad, enc->in_w, se::kInPad, enc->in_b, nullptr, M, H, se::kInPad, SE_ACT_IDENTITY, nullptr, w.tmp, H, stream))) return rc;
-  if ((rc = launch_layernorm(w.tmp, enc->pe, T, enc->in_ln_w, enc->in_ln_b, M, H, enc->cfg.ln_eps, w.x_f32, w.x_bf, st))) return rc;
+  if ((rc = se::launch_layernorm(w.tmp, enc->pe, T, enc->in_ln_w, enc->in_ln_b, M, H, enc->cfg.ln_eps, w.x_f32, w.x_bf, st))) return rc;
   const int L = enc->cfg.layers;
   static int fuse_env = -1;
   if (fuse_env < 0) {
@@ -492,7 +484,7 @@ extern "C" int se_encoder_fwd_bf16(const se_encoder* enc, const float* feats, co
       std::swap(w.x_f32, w.tmp);
     } else {
       if ((rc = se_gemm_bf16(w.ctx, H, y.ao_w, H, y.ao_b, w.x_f32, M, H, H, SE_ACT_IDENTITY, nullptr, w.tmp, H, stream))) return rc;
-      if ((rc = launch_layernorm(w.tmp, nullptr, 1, y.aln_w, y.aln_b, M, H, enc->cfg.ln_eps, w.x_f32, w.x_bf, st))) return rc;
+      if ((rc = se::launch_layernorm(w.tmp, nullptr, 1, y.aln_w, y.aln_b, M, H, enc->cfg.ln_eps, w.x_f32, w.x_bf, st))) return rc;
     }
     // B3
     if ((rc = se_gemm_bf16(w.x_bf, H, y.ff1_w, H, y.ff1_b, nullptr, M, I, H, SE_ACT_GELU, w.h, nullptr, I, stream))) return rc;
@@ -504,7 +496,7 @@ extern "C" int se_encoder_fwd_bf16(const se_encoder* enc, const float* feats, co
     } else {
       if ((rc = se_gemm_bf16(w.h, I, y.ff2_w, I, y.ff2_b, w.x_f32, M, H, I, SE_ACT_IDENTITY, nullptr, w.tmp, H, stream))) return rc;
       float* xo = (i == L - 1) ? hidden : w.x_f32;
-      if ((rc = launch_layernorm(w.tmp, nullptr, 1, y.oln_w, y.oln_b, M, H, enc->cfg.ln_eps, xo, (i == L - 1) ? nullptr : w.x_bf, st))) return rc;
+      if ((rc = se::launch_layernorm(w.tmp, nullptr, 1, y.oln_w, y.oln_b, M, H, enc->cfg.ln_eps, xo, (i == L - 1) ? nullptr : w.x_bf, st))) return rc;
     }
   }
   return SE_OK;
@@ -529,7 +521,7 @@ extern "C" int se_spechead_fwd_bf16(const se_encoder* enc, const float* hidden, 
     SE_LAUNCH_CHECK();
   }
   if ((rc = se_gemm_bf16(w.x_bf, H, enc->sh_dense_w, H, enc->sh_dense_b, nullptr, M, H, H, SE_ACT_GELU, nullptr, w.tmp, H, stream))) return rc;
-  if ((rc = launch_layernorm(w.tmp, nullptr, 1, enc->sh_ln_w, enc->sh_ln_b, M, H, enc->cfg.ln_eps, nullptr, w.ctx, st))) return rc;
+  if ((rc = se::launch_layernorm(w.tmp, nullptr, 1, enc->sh_ln_w, enc->sh_ln_b, M, H, enc->cfg.ln_eps, nullptr, w.ctx, st))) return rc;
   // raw linear output p (M, N) fp32: into `raw` if given, else the (free) x_f32 workspace
   float* p = raw ? raw : w.x_f32;
   if ((rc = se_gemm_bf16(w.ctx, H, enc->sh_out_w, H, enc->sh_out_b, nullptr, M, N, H, SE_ACT_IDENTITY, nullptr, p, N, stream))) return rc;

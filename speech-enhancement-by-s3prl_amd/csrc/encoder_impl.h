@@ -1,0 +1,34 @@
+// encoder_impl.h -- internals shared by encoder.hip (inference path), encoder_train.hip (training path) and bwd.hip.
+#pragma once
+#include <vector>
+#include "common.h"
+
+namespace se {
+constexpr int kMaxPos = 5008;     // 50 s of 10 ms frames (MAX_POSITIONS_LEN = 16000*50 samples, runner.py:32)
+constexpr int kInPad = 128;       // input feature dim padded to a multiple of the GEMM K tile
+
+// host launchers of kernels that live in encoder.hip / bwd.hip
+int launch_layernorm(const float* x, const float* pe, int T, const float* w, const float* b, int M, int H, float eps,
+                     float* out_f32, uint16_t* out_bf16, hipStream_t st);
+int launch_cast_pad(const float* x, size_t rows, int cols, int ld_out, uint16_t* out, hipStream_t st);
+int launch_layernorm_bwd(const float* x_in, const float* pe, int T, const float* dy, const float* w, int M, int H, float eps, int gelu_in,
+                         float* dx, uint16_t* dx_bf16, float* dgamma, float* dbeta, int accumulate, hipStream_t st);
+int launch_colsum_bf16(const uint16_t* x, int rows, int cols, int ld, float* out, hipStream_t st);
+inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+}  // namespace se
+
+struct se_encoder {
+  se_encoder_config cfg;
+  void* blob;          // one device allocation
+  size_t blob_bytes;
+  // device views
+  uint16_t* in_w;      // (H, kInPad) bf16
+  float *in_b, *in_ln_w, *in_ln_b, *pe;
+  struct Layer {
+    uint16_t *qkv_w, *ao_w, *ff1_w, *ff2_w;
+    float *qkv_b, *ao_b, *aln_w, *aln_b, *ff1_b, *ff2_b, *oln_w, *oln_b;
+  };
+  std::vector<Layer> layers;
+  uint16_t *sh_dense_w, *sh_out_w;
+  float *sh_dense_b, *sh_ln_w, *sh_ln_b, *sh_out_b;
+};

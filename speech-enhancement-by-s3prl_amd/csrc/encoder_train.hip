@@ -1,0 +1,280 @@
+// encoder_train.hip -- training path of the TRANSFORMER encoder (rows B1-B3 under autograd: C4 `Mockingjay` fine-tune,
+// E2; model.py:163-171, runner.py:453-471).  Forward keeps what the backward needs in a caller-owned `saved` buffer,
+// backward walks the layers in reverse on the building blocks:
+//   LayerNorm'            bwd.hip  (TF LayerNorm backward, dgamma / dbeta)
+//   weight gradients      bwd.hip  (se_wgrad_bf16: operands transposed so M = B*T is the contiguous reduction dim, split-K)
+//   input gradients       gemm*.hip (se_gemm_bf16 on a transposed bf16 copy of the weight; the residual branch's gradient
+//                         rides the GEMM's fp32 residual input)
+//   attention             mhsa_bwd.hip (flash backward from the stored log-sum-exp)
+//   gelu'                 bwd.hip
+// Mixed precision as the forward: bf16 GEMM operands, fp32 accumulation, fp32 residual-stream gradient, fp32 parameter
+// gradients.  Dropout is not applied (hidden_dropout_prob / attention_probs_dropout_prob are treated as 0).
+#include <stdlib.h>
+#include <algorithm>
+#include "common.h"
+#include "encoder_impl.h"
+
+namespace {
+
+using se::al256;
+constexpr int kSplits = 8;
+
+inline int padded_rows(int M) {                 // rows of the transposed operands: splits x (multiple of 64, >= 128)
+  int mc = (M + kSplits - 1) / kSplits;
+  mc = std::max(128, (mc + 63) / 64 * 64);
+  return mc * kSplits;
+}
+
+struct SavedLayer {
+  uint16_t *x0_bf, *qkv, *ctx, *x1_bf, *hpre, *h;
+  float *lse, *pre1, *pre2;
+};
+struct Saved {
+  uint16_t* xin;
+  float* pre0;
+  std::vector<SavedLayer> l;
+  size_t total;
+};
+
+Saved carve_saved(const se_encoder* e, int B, int T, char* base) {
+  const size_t M = (size_t)B * T, H = e->cfg.hidden, I = e->cfg.intermediate, heads = e->cfg.heads;
+  Saved s;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += al256(bytes); return p; };
+  s.xin = (uint16_t*)take(M * se::kInPad * 2);
+  s.pre0 = (float*)take(M * H * 4);
+  for (int i = 0; i < e->cfg.layers; ++i) {
+    SavedLayer y;
+    y.x0_bf = (uint16_t*)take(M * H * 2);
+    y.qkv = (uint16_t*)take(M * 3 * H * 2);
+    y.lse = (float*)take((size_t)B * heads * T * 4);
+    y.ctx = (uint16_t*)take(M * H * 2);
+    y.pre1 = (float*)take(M * H * 4);
+    y.x1_bf = (uint16_t*)take(M * H * 2);
+    y.hpre = (uint16_t*)take(M * I * 2);
+    y.h = (uint16_t*)take(M * I * 2);
+    y.pre2 = (float*)take(M * H * 4);
+    s.l.push_back(y);
+  }
+  s.total = off;
+  return s;
+}
+
+struct TrainWs {
+  float *fa, *fb;                    // fp32 (M, H): gradient of the residual stream / pre-LayerNorm gradient
+  uint16_t *b1, *b2;                 // bf16 (M, H)
+  uint16_t *bi;                      // bf16 (M, I)
+  uint16_t *b3;                      // bf16 (M, 3H)
+  float* dvec;                       // (B, heads, T)
+  uint16_t *ta, *tb;                 // transposed operands (max(I, 3H), Mp)
+  uint16_t* wt;                      // transposed weight copy (max 3H*H, I*H)
+  float* partials;                   // split-K slabs
+  float* gfused;                     // fused qkv weight gradient (3H, H) / padded input weight gradient (H, kInPad)
+  float* bfused;                     // fused qkv bias gradient (3H)
+  size_t total;
+};
+
+TrainWs carve_ws(const se_encoder* e, int B, int T, char* base) {
+  const size_t M = (size_t)B * T, H = e->cfg.hidden, I = e->cfg.intermediate, heads = e->cfg.heads;
+  const size_t Mp = padded_rows((int)M);
+  const size_t wide = std::max(I, 3 * H);
+  TrainWs w;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += al256(bytes); return p; };
+  w.fa = (float*)take(M * H * 4);
+  w.fb = (float*)take(M * H * 4);
+  w.b1 = (uint16_t*)take(M * H * 2);
+  w.b2 = (uint16_t*)take(M * H * 2);
+  w.bi = (uint16_t*)take(M * I * 2);
+  w.b3 = (uint16_t*)take(M * 3 * H * 2);
+  w.dvec = (float*)take((size_t)B * heads * T * 4);
+  w.ta = (uint16_t*)take(wide * Mp * 2);
+  w.tb = (uint16_t*)take(wide * Mp * 2);
+  w.wt = (uint16_t*)take(wide * H * 2);
+  w.partials = (float*)take((size_t)kSplits * wide * H * 4);
+  w.gfused = (float*)take(std::max(3 * H * H, H * (size_t)se::kInPad) * 4);
+  w.bfused = (float*)take(3 * H * 4);
+  w.total = off;
+  return w;
+}
+
+int cast_mat(const float* src, int rows, int cols, int ld, uint16_t* dst, hipStream_t st) {
+  return se::launch_cast_pad(src, (size_t)rows, cols, ld, dst, st);
+}
+int copy_vec(const float* src, size_t n, float* dst, hipStream_t st) {
+  SE_HIP(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+  return SE_OK;
+}
+
+}  // namespace
+
+#define SE_TRY(call)                 \
+  do {                               \
+    const int rc_ = (call);          \
+    if (rc_) return rc_;             \
+  } while (0)
+
+// device fp32 master weights -> the encoder's bf16 / fp32 blob (after every optimizer step)
+extern "C" int se_encoder_refresh_bf16(se_encoder* enc, const se_encoder_weights* w, void* stream) {
+  SE_REQUIRE(enc && w, "se_encoder_refresh_bf16: null argument");
+  const int H = enc->cfg.hidden, I = enc->cfg.intermediate, D = enc->cfg.input_dim, L = enc->cfg.layers;
+  hipStream_t st = se::as_stream(stream);
+  SE_TRY(cast_mat(w->in_w, H, D, se::kInPad, enc->in_w, st));
+  SE_TRY(copy_vec(w->in_b, H, enc->in_b, st));
+  SE_TRY(copy_vec(w->in_ln_w, H, enc->in_ln_w, st));
+  SE_TRY(copy_vec(w->in_ln_b, H, enc->in_ln_b, st));
+  for (int i = 0; i < L; ++i) {
+    se_encoder::Layer& y = enc->layers[i];
+    SE_TRY(cast_mat(w->q_w[i], H, H, H, y.qkv_w, st));
+    SE_TRY(cast_mat(w->k_w[i], H, H, H, y.qkv_w + (size_t)H * H, st));
+    SE_TRY(cast_mat(w->v_w[i], H, H, H, y.qkv_w + (size_t)2 * H * H, st));
+    SE_TRY(copy_vec(w->q_b[i], H, y.qkv_b, st));
+    SE_TRY(copy_vec(w->k_b[i], H, y.qkv_b + H, st));
+    SE_TRY(copy_vec(w->v_b[i], H, y.qkv_b + 2 * H, st));
+    SE_TRY(cast_mat(w->ao_w[i], H, H, H, y.ao_w, st));
+    SE_TRY(copy_vec(w->ao_b[i], H, y.ao_b, st));
+    SE_TRY(copy_vec(w->aln_w[i], H, y.aln_w, st));
+    SE_TRY(copy_vec(w->aln_b[i], H, y.aln_b, st));
+    SE_TRY(cast_mat(w->ff1_w[i], I, H, H, y.ff1_w, st));
+    SE_TRY(copy_vec(w->ff1_b[i], I, y.ff1_b, st));
+    SE_TRY(cast_mat(w->ff2_w[i], H, I, I, y.ff2_w, st));
+    SE_TRY(copy_vec(w->ff2_b[i], H, y.ff2_b, st));
+    SE_TRY(copy_vec(w->oln_w[i], H, y.oln_w, st));
+    SE_TRY(copy_vec(w->oln_b[i], H, y.oln_b, st));
+  }
+  return SE_OK;
+}
+
+extern "C" size_t se_encoder_saved_bytes(const se_encoder* enc, int B, int T) {
+  if (!enc || B <= 0 || T <= 0) return 0;
+  return carve_saved(enc, B, T, nullptr).total + 256;
+}
+
+extern "C" size_t se_encoder_train_workspace_bytes(const se_encoder* enc, int B, int T) {
+  if (!enc || B <= 0 || T <= 0) return 0;
+  return std::max(carve_ws(enc, B, T, nullptr).total, (size_t)B * T * enc->cfg.hidden * 4) + 256;
+}
+
+static int check_train_shape(const se_encoder* enc, int B, int T, const char* who) {
+  SE_REQUIRE(B > 0 && B <= 65535 && T > 0 && T <= se::kMaxPos, "%s: bad shape B=%d T=%d (T <= %d)", who, B, T, se::kMaxPos);
+  SE_REQUIRE((size_t)B * T <= 0x7fffffff / 4, "%s: B*T too large", who);
+  if ((enc->cfg.hidden != 768 && enc->cfg.hidden != 256) || enc->cfg.intermediate % 64 != 0) {
+    se::set_error("%s: the training kernels are built for hidden_size 768 (and 256 for tests), got %d", who, enc->cfg.hidden);
+    return SE_ERR_UNSUPPORTED;
+  }
+  return SE_OK;
+}
+
+extern "C" int se_encoder_fwd_train_bf16(const se_encoder* enc, const float* feats, const int32_t* lengths, int B, int T, float* hidden,
+                                         void* saved, size_t saved_bytes, void* workspace, size_t workspace_bytes, void* stream) {
+  SE_REQUIRE(enc && feats && hidden && saved && workspace, "se_encoder_fwd_train_bf16: null argument");
+  SE_TRY(check_train_shape(enc, B, T, "se_encoder_fwd_train_bf16"));
+  SE_REQUIRE(saved_bytes >= se_encoder_saved_bytes(enc, B, T), "se_encoder_fwd_train_bf16: saved buffer too small");
+  SE_REQUIRE(workspace_bytes >= (size_t)B * T * enc->cfg.hidden * 4, "se_encoder_fwd_train_bf16: workspace too small");
+  SE_REQUIRE(((uintptr_t)saved % 256 == 0) && ((uintptr_t)workspace % 256 == 0) && ((uintptr_t)hidden % 16 == 0),
+             "se_encoder_fwd_train_bf16: buffers must be 256-B aligned");
+  const int H = enc->cfg.hidden, I = enc->cfg.intermediate, D = enc->cfg.input_dim, L = enc->cfg.layers;
+  const size_t Mz = (size_t)B * T;
+  const int M = (int)Mz;
+  hipStream_t st = se::as_stream(stream);
+  Saved s = carve_saved(enc, B, T, reinterpret_cast<char*>(saved));
+  float* x_f32 = reinterpret_cast<float*>(workspace);          // running residual stream (LayerNorm outputs)
+  const float eps = enc->cfg.ln_eps;
+  // B1
+  SE_TRY(se::launch_cast_pad(feats, Mz, D, se::kInPad, s.xin, st));
+  SE_TRY(se_gemm_bf16(s.xin, se::kInPad, enc->in_w, se::kInPad, enc->in_b, nullptr, M, H, se::kInPad, SE_ACT_IDENTITY, nullptr, s.pre0, H, stream));
+  SE_TRY(se::launch_layernorm(s.pre0, enc->pe, T, enc->in_ln_w, enc->in_ln_b, M, H, eps, x_f32, s.l[0].x0_bf, st));
+  for (int i = 0; i < L; ++i) {
+    const se_encoder::Layer& y = enc->layers[i];
+    SavedLayer& a = s.l[i];
+    // B2
+    SE_TRY(se_gemm_bf16(a.x0_bf, H, y.qkv_w, H, y.qkv_b, nullptr, M, 3 * H, H, SE_ACT_IDENTITY, a.qkv, nullptr, 3 * H, stream));
+    SE_TRY(se_mhsa_fwd_lse_bf16(a.qkv, lengths, B, T, enc->cfg.heads, a.ctx, a.lse, stream));
+    SE_TRY(se_gemm_bf16(a.ctx, H, y.ao_w, H, y.ao_b, x_f32, M, H, H, SE_ACT_IDENTITY, nullptr, a.pre1, H, stream));
+    SE_TRY(se::launch_layernorm(a.pre1, nullptr, 1, y.aln_w, y.aln_b, M, H, eps, x_f32, a.x1_bf, st));
+    // B3 (the pre-activation is kept for gelu')
+    SE_TRY(se_gemm_bf16(a.x1_bf, H, y.ff1_w, H, y.ff1_b, nullptr, M, I, H, SE_ACT_IDENTITY, a.hpre, nullptr, I, stream));
+    SE_TRY(se_gelu_bf16(a.hpre, Mz * I, a.h, stream));
+    SE_TRY(se_gemm_bf16(a.h, I, y.ff2_w, I, y.ff2_b, x_f32, M, H, I, SE_ACT_IDENTITY, nullptr, a.pre2, H, stream));
+    const bool last = i == L - 1;
+    SE_TRY(se::launch_layernorm(a.pre2, nullptr, 1, y.oln_w, y.oln_b, M, H, eps, last ? hidden : x_f32, last ? nullptr : s.l[i + 1].x0_bf, st));
+  }
+  return SE_OK;
+}
+
+namespace {
+
+// dW (N, K) = dY^T X from row-major bf16 dY (M, N) [ld ldy] and X (M, K) [ld ldx]; bias gradient by the caller
+int weight_grad(const uint16_t* dY, int ldy, const uint16_t* X, int ldx, int M, int Mp, int N, int K, float* dW, const TrainWs& w, void* stream) {
+  SE_TRY(se_transpose_bf16(dY, M, N, ldy, w.ta, Mp, stream));
+  SE_TRY(se_transpose_bf16(X, M, K, ldx, w.tb, Mp, stream));
+  return se_wgrad_bf16(w.ta, w.tb, Mp, N, K, kSplits, dW, 0, w.partials, (size_t)kSplits * N * K * sizeof(float), stream);
+}
+
+// dX (M, K) = dY (M, N) . W (N, K) [+ residual]   through the forward GEMM on W^T (K, N)
+int input_grad(const uint16_t* dY, const uint16_t* W, int M, int N, int K, const float* residual, uint16_t* out_bf16, float* out_f32,
+               const TrainWs& w, void* stream) {
+  SE_TRY(se_transpose_bf16(W, N, K, K, w.wt, N, stream));
+  return se_gemm_bf16(dY, N, w.wt, N, nullptr, residual, M, K, N, SE_ACT_IDENTITY, out_bf16, out_f32, K, stream);
+}
+
+}  // namespace
+
+extern "C" int se_encoder_bwd_bf16(const se_encoder* enc, const int32_t* lengths, int B, int T, const float* d_hidden, const void* saved,
+                                   size_t saved_bytes, const se_encoder_grads* g, void* workspace, size_t workspace_bytes, void* stream) {
+  SE_REQUIRE(enc && d_hidden && saved && g && workspace, "se_encoder_bwd_bf16: null argument");
+  SE_TRY(check_train_shape(enc, B, T, "se_encoder_bwd_bf16"));
+  SE_REQUIRE(saved_bytes >= se_encoder_saved_bytes(enc, B, T), "se_encoder_bwd_bf16: saved buffer too small");
+  SE_REQUIRE(workspace_bytes >= se_encoder_train_workspace_bytes(enc, B, T), "se_encoder_bwd_bf16: workspace too small");
+  SE_REQUIRE(((uintptr_t)saved % 256 == 0) && ((uintptr_t)workspace % 256 == 0), "se_encoder_bwd_bf16: buffers must be 256-B aligned");
+  const int H = enc->cfg.hidden, I = enc->cfg.intermediate, D = enc->cfg.input_dim, L = enc->cfg.layers;
+  const size_t Mz = (size_t)B * T;
+  const int M = (int)Mz, Mp = padded_rows(M);
+  hipStream_t st = se::as_stream(stream);
+  const Saved s = carve_saved(enc, B, T, reinterpret_cast<char*>(const_cast<void*>(saved)));
+  const TrainWs w = carve_ws(enc, B, T, reinterpret_cast<char*>(workspace));
+  const float eps = enc->cfg.ln_eps;
+  const float* gy = d_hidden;            // gradient wrt the current layer's output
+  for (int i = L - 1; i >= 0; --i) {
+    const se_encoder::Layer& y = enc->layers[i];
+    const SavedLayer& a = s.l[i];
+    // ---- output LayerNorm:  x2 = LN(pre2)
+    SE_TRY(se::launch_layernorm_bwd(a.pre2, nullptr, 1, gy, y.oln_w, M, H, eps, 0, w.fa, w.b1, g->oln_w[i], g->oln_b[i], 0, st));
+    // ---- FFN output linear:  pre2 = h W2^T + b2 + x1
+    SE_TRY(weight_grad(w.b1, H, a.h, I, M, Mp, H, I, g->ff2_w[i], w, stream));
+    SE_TRY(se_colsum_f32(w.fa, M, H, H, g->ff2_b[i], 0, stream));
+    SE_TRY(input_grad(w.b1, y.ff2_w, M, H, I, nullptr, w.bi, nullptr, w, stream));                 // dh (M, I)
+    SE_TRY(se_gelu_bwd_bf16(w.bi, a.hpre, Mz * I, w.bi, stream));                                  // dhpre
+    // ---- FFN input linear:  hpre = x1 W1^T + b1
+    SE_TRY(weight_grad(w.bi, I, a.x1_bf, H, M, Mp, I, H, g->ff1_w[i], w, stream));
+    SE_TRY(se::launch_colsum_bf16(w.bi, M, I, I, g->ff1_b[i], st));
+    SE_TRY(input_grad(w.bi, y.ff1_w, M, I, H, w.fa, nullptr, w.fb, w, stream));                    // dx1 = dhpre W1 + dpre2
+    // ---- attention-output LayerNorm:  x1 = LN(pre1)
+    SE_TRY(se::launch_layernorm_bwd(a.pre1, nullptr, 1, w.fb, y.aln_w, M, H, eps, 0, w.fa, w.b1, g->aln_w[i], g->aln_b[i], 0, st));
+    // ---- attention output linear:  pre1 = ctx Wo^T + bo + x0
+    SE_TRY(weight_grad(w.b1, H, a.ctx, H, M, Mp, H, H, g->ao_w[i], w, stream));
+    SE_TRY(se_colsum_f32(w.fa, M, H, H, g->ao_b[i], 0, stream));
+    SE_TRY(input_grad(w.b1, y.ao_w, M, H, H, nullptr, w.b2, nullptr, w, stream));                  // dctx (M, H)
+    // ---- attention core
+    SE_TRY(se_mhsa_bwd_bf16(a.qkv, a.ctx, w.b2, a.lse, lengths, B, T, enc->cfg.heads, w.b3, w.dvec, stream));
+    // ---- fused QKV linear:  qkv = x0 Wqkv^T + b
+    SE_TRY(weight_grad(w.b3, 3 * H, a.x0_bf, H, M, Mp, 3 * H, H, w.gfused, w, stream));
+    SE_TRY(se::launch_colsum_bf16(w.b3, M, 3 * H, 3 * H, w.bfused, st));
+    {
+      float* wdst[3] = {g->q_w[i], g->k_w[i], g->v_w[i]};
+      float* bdst[3] = {g->q_b[i], g->k_b[i], g->v_b[i]};
+      for (int p = 0; p < 3; ++p) {
+        SE_HIP(hipMemcpyAsync(wdst[p], w.gfused + (size_t)p * H * H, (size_t)H * H * 4, hipMemcpyDeviceToDevice, st));
+        SE_HIP(hipMemcpyAsync(bdst[p], w.bfused + (size_t)p * H, (size_t)H * 4, hipMemcpyDeviceToDevice, st));
+      }
+    }
+    SE_TRY(input_grad(w.b3, y.qkv_w, M, 3 * H, H, w.fa, nullptr, w.fb, w, stream));                // dx0 = dqkv Wqkv + dpre1
+    gy = w.fb;
+  }
+  // ---- input stage:  x = LN(xin Win^T + b + PE)
+  SE_TRY(se::launch_layernorm_bwd(s.pre0, enc->pe, T, gy, enc->in_ln_w, M, H, eps, 0, w.fa, w.b1, g->in_ln_w, g->in_ln_b, 0, st));
+  SE_TRY(weight_grad(w.b1, H, s.xin, se::kInPad, M, Mp, H, se::kInPad, w.gfused, w, stream));
+  SE_HIP(hipMemcpy2DAsync(g->in_w, (size_t)D * 4, w.gfused, (size_t)se::kInPad * 4, (size_t)D * 4, H, hipMemcpyDeviceToDevice, st));
+  SE_TRY(se_colsum_f32(w.fa, M, H, H, g->in_b, 0, stream));
+  return SE_OK;
+}

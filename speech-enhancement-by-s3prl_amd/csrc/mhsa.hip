@@ -18,25 +18,14 @@
 #include "common.h"
 #include "prof.h"
 #include "bf16.h"
+#include "mhsa_tile.h"
 
 namespace se {
 
-constexpr int kAQ = 128;        // query rows per workgroup
-constexpr int kAK = 64;         // keys per tile
-constexpr int kHD = 64;         // head dim
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-
-// byte offset of 16-B chunk `ch` (8 bf16) of row `key` inside a [64][64] bf16 tile; f is a bit permutation of
-// (key>>1)&7 chosen so that (a) 16 rows at one chunk hit 16 distinct 16-B slots (b128 reads of K) and
-// (b) 4 consecutive keys land in 4 distinct 64-B quarters of the 256-B bank row (tr_b16 reads of V)
-__device__ __forceinline__ int kv_off(int key, int ch) {
-  const int f = (((key >> 1) & 1) << 2) | ((key >> 2) & 3);
-  return key * 128 + ((ch ^ f) << 4);
-}
-
 template <int OCC>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void mhsa_fwd_kernel(
-    const uint16_t* __restrict__ qkv, const int32_t* __restrict__ lengths, int T, int H, uint16_t* __restrict__ ctx) {
+    const uint16_t* __restrict__ qkv, const int32_t* __restrict__ lengths, int T, int H, uint16_t* __restrict__ ctx,
+    float* __restrict__ lse) {
   __shared__ __attribute__((aligned(16))) char smem[2 * 2 * kAK * kHD * 2];   // 2 buffers x (K, V) x 8 KiB = 32 KiB
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -203,6 +192,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
   const float l_tot = l_run + __shfl_xor(l_run, 32);
   const float inv = 1.0f / l_tot;
   const int q = q0 + l31;
+  // training: log2-domain log-sum-exp of the scaled scores, P = exp2(c s - lse) in the backward kernels
+  if (lse && q < T && hh == 0) lse[((size_t)b * (H / kHD) + head) * T + q] = fmaf(m_run, c, __builtin_amdgcn_logf(l_tot));
   if (q < T) {
     uint16_t* op = ctx + ((size_t)b * T + q) * H + head * kHD + 4 * hh;
 #pragma unroll
@@ -217,7 +208,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
 
 }  // namespace se
 
-extern "C" int se_mhsa_fwd_bf16(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, void* stream) {
+static int mhsa_fwd_launch(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, float* lse, void* stream) {
   SE_REQUIRE(qkv && ctx, "se_mhsa_fwd_bf16: null argument");
   SE_REQUIRE(B > 0 && B <= 65535 && T > 0 && heads > 0 && heads <= 65535, "se_mhsa_fwd_bf16: bad shape B=%d T=%d heads=%d", B, T, heads);
   const int H = heads * se::kHD;
@@ -228,8 +219,18 @@ extern "C" int se_mhsa_fwd_bf16(const uint16_t* qkv, const int32_t* lengths, int
     const char* e = getenv("SE_AMD_MHSA_OCC");
     occ = e ? atoi(e) : 3;
   }
-  if (occ == 2) hipLaunchKernelGGL(se::mhsa_fwd_kernel<2>, grid, dim3(256), 0, se::as_stream(stream), qkv, lengths, T, H, ctx);
-  else hipLaunchKernelGGL(se::mhsa_fwd_kernel<3>, grid, dim3(256), 0, se::as_stream(stream), qkv, lengths, T, H, ctx);
+  if (occ == 2) hipLaunchKernelGGL(se::mhsa_fwd_kernel<2>, grid, dim3(256), 0, se::as_stream(stream), qkv, lengths, T, H, ctx, lse);
+  else hipLaunchKernelGGL(se::mhsa_fwd_kernel<3>, grid, dim3(256), 0, se::as_stream(stream), qkv, lengths, T, H, ctx, lse);
   SE_LAUNCH_CHECK();
   return SE_OK;
+}
+
+extern "C" int se_mhsa_fwd_bf16(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, void* stream) {
+  return mhsa_fwd_launch(qkv, lengths, B, T, heads, ctx, nullptr, stream);
+}
+
+extern "C" int se_mhsa_fwd_lse_bf16(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, float* lse,
+                                    void* stream) {
+  SE_REQUIRE(lse, "se_mhsa_fwd_lse_bf16: null lse");
+  return mhsa_fwd_launch(qkv, lengths, B, T, heads, ctx, lse, stream);
 }

@@ -3,7 +3,7 @@
 #include <hip/hip_runtime.h>
 
 namespace se {
-enum ProfKind { kProfGemm = 0, kProfMhsa = 1, kProfStft = 2, kProfIstft = 3, kProfLayerNorm = 4, kProfHead = 5, kProfKinds = 6 };
+enum ProfKind { kProfGemm = 0, kProfMhsa = 1, kProfStft = 2, kProfIstft = 3, kProfLayerNorm = 4, kProfHead = 5, kProfMhsaBwd = 6, kProfKinds = 7 };
 bool prof_on();
 // records a start event; returns a slot (or -1 when profiling is off / the pool is full)
 int prof_begin(int kind, double work, hipStream_t st);

@@ -133,7 +133,7 @@ class SpecHead(nn.Module):
 
 class Mockingjay(nn.Module):
     """model.py:129-171: the whole upstream encoder + spec head as the downstream model (ignores `linears`).
-    Forward only this round (no backward through the encoder yet)."""
+    With gradients enabled both parts run their training paths (activations kept, backward on the HIP kernels)."""
 
     def __init__(self, dckpt, activation='ReLU', eps=1e-6, **kwargs):
         super().__init__()
@@ -162,6 +162,12 @@ class Mockingjay(nn.Module):
 
     def forward(self, features, **kwargs):
         features = self.mockingjay(features)
-        predicted, log_predicted = self.spechead._engine.spechead(self.spechead, None, features, mode='full',
-                                                                  log_target=self.log, act=self.activation, eps=self.eps)
+        sh = self.spechead
+        if sh._needs_grad() or features.requires_grad:
+            from .spechead_train import SpecHeadTrainFn
+            predicted, log_predicted = SpecHeadTrainFn.apply(features, sh.dense.weight, sh.dense.bias, sh.LayerNorm.weight, sh.LayerNorm.bias,
+                                                             sh.output.weight, sh.output.bias, sh.LayerNorm.variance_epsilon, self.log,
+                                                             _act_id(self.activation), self.eps)
+            return predicted, {'log_predicted': log_predicted}
+        predicted, log_predicted = sh._engine.spechead(sh, None, features, mode='full', log_target=self.log, act=self.activation, eps=self.eps)
         return predicted, {'log_predicted': log_predicted}

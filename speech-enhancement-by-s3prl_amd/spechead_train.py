@@ -10,7 +10,7 @@ backward (mixed precision as the forward: bf16 GEMM operands, fp32 sums):
     dxn  = dp Wo     (se_gemm_bf16 on the transposed weight)
     dpre = LayerNorm'(gelu(pre)) . gelu'(pre)        (+ dgamma, dbeta)
     dWd  = dpre^T x  (wgrad)                                            dbd = colsum(dpre)
-The input features are the frozen upstream's output (no gradient is returned for them).
+    dx   = dpre Wd   (only when the input requires a gradient: Mockingjay, where the encoder below is trained too)
 """
 import torch
 
@@ -91,7 +91,7 @@ class SpecHeadTrainFn(torch.autograd.Function):
         lead = hidden.shape[:-1]
         H = hidden.shape[-1]
         N = out_w.shape[0]
-        if H != 768:
+        if H not in (768, 256):
             raise NotImplementedError('the spec-head training kernels are built for hidden_size 768; for inference at other sizes call the head under '
                                       'torch.no_grad() (as Runner.evaluate does, runner.py:547)')
         x = hidden.reshape(-1, H)
@@ -107,14 +107,14 @@ class SpecHeadTrainFn(torch.autograd.Function):
         logp = torch.empty(M, N, device=x.device, dtype=torch.float32)
         _lib.check(lib.se_spec_epilogue_f32(_lib.ptr(p), M * N, int(bool(log_target)), act, float(eps), _lib.ptr(pred), _lib.ptr(logp),
                                             _lib.stream()), 'se_spec_epilogue_f32')
-        ctx.save_for_backward(x16, pre, xn16, p, ln_w, out_w)
+        ctx.save_for_backward(x16, pre, xn16, p, ln_w, out_w, dense_w)
         ctx.meta = (float(ln_eps), int(bool(log_target)), act, float(eps), lead)
         return pred.reshape(*lead, N), logp.reshape(*lead, N)
 
     @staticmethod
     def backward(ctx, d_pred, d_logp):
         lib = _lib.load()
-        x16, pre, xn16, p, ln_w, out_w = ctx.saved_tensors
+        x16, pre, xn16, p, ln_w, out_w, dense_w = ctx.saved_tensors
         ln_eps, log_target, act, eps, lead = ctx.meta
         M, H = pre.shape
         N = p.shape[1]
@@ -147,4 +147,8 @@ class SpecHeadTrainFn(torch.autograd.Function):
         xt = transpose_bf16(x16, Mp)
         d_dense_w = wgrad(dpret, xt, H, H)
         d_dense_b = colsum(dpre32)
-        return None, d_dense_w, d_dense_b, d_ln_w, d_ln_b, d_out_w, d_out_b, None, None, None, None
+        d_hidden = None
+        if ctx.needs_input_grad[0]:
+            wdt = transpose_f32_bf16(dense_w.contiguous().float(), H)       # (H_in, H_out) = Wd^T
+            d_hidden = _gemm(dpre16, wdt, None, M, H, H).reshape(*lead, H)
+        return d_hidden, d_dense_w, d_dense_b, d_ln_w, d_ln_b, d_out_w, d_out_b, None, None, None, None

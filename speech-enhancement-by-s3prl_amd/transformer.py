@@ -10,8 +10,9 @@ Checkpoint layout consumed (the S3PRL one the reference reads): ckpt['Settings']
 ckpt['Transformer'] (state_dict of TransformerModel), ckpt['SpecHead'] (state_dict of the head).
 
 The forward pass runs on libse_amd.so only (bf16 MFMA GEMMs + flash MHSA, fp32 residual stream); there is no
-CPU fallback.  Inference / no_grad use (the reference's upstream role, runner.py:273-284) is what this round
-implements; a backward pass through the encoder (Mockingjay fine-tuning) is not available yet and raises.
+CPU fallback.  Under torch.no_grad() (the reference's upstream role, runner.py:273-284) the fused inference path runs;
+with gradients enabled (Mockingjay fine-tuning, model.py:163-171) the training path keeps the activations and the
+backward pass runs on the HIP kernels too (se_encoder_fwd_train_bf16 / se_encoder_bwd_bf16).  Dropout is not applied.
 """
 import ctypes
 import warnings
@@ -116,8 +117,102 @@ class TransformerSpecPredictionHead(nn.Module):
         return raw, None
 
 
+_TRUNK_FIELDS = ('q_w', 'q_b', 'k_w', 'k_b', 'v_w', 'v_b', 'ao_w', 'ao_b', 'aln_w', 'aln_b', 'ff1_w', 'ff1_b', 'ff2_w', 'ff2_b',
+                 'oln_w', 'oln_b')
+
+
+def _trunk_tensors(model):
+    """(scalar fields, per-layer fields) of se_encoder_weights -> the parameters that fill them."""
+    ir = model.input_representations
+    head = {'in_w': ir.spec_transform.weight, 'in_b': ir.spec_transform.bias, 'in_ln_w': ir.LayerNorm.weight, 'in_ln_b': ir.LayerNorm.bias}
+    Ls = list(model.encoder.layer)
+    per = {'q_w': [l.attention.self.query.weight for l in Ls], 'q_b': [l.attention.self.query.bias for l in Ls],
+           'k_w': [l.attention.self.key.weight for l in Ls], 'k_b': [l.attention.self.key.bias for l in Ls],
+           'v_w': [l.attention.self.value.weight for l in Ls], 'v_b': [l.attention.self.value.bias for l in Ls],
+           'ao_w': [l.attention.output.dense.weight for l in Ls], 'ao_b': [l.attention.output.dense.bias for l in Ls],
+           'aln_w': [l.attention.output.LayerNorm.weight for l in Ls], 'aln_b': [l.attention.output.LayerNorm.bias for l in Ls],
+           'ff1_w': [l.intermediate.dense.weight for l in Ls], 'ff1_b': [l.intermediate.dense.bias for l in Ls],
+           'ff2_w': [l.output.dense.weight for l in Ls], 'ff2_b': [l.output.dense.bias for l in Ls],
+           'oln_w': [l.output.LayerNorm.weight for l in Ls], 'oln_b': [l.output.LayerNorm.bias for l in Ls]}
+    return head, per
+
+
+def _trunk_param_list(model):
+    head, per = _trunk_tensors(model)
+    out = [head[k] for k in ('in_w', 'in_b', 'in_ln_w', 'in_ln_b')]
+    for k in _TRUNK_FIELDS:
+        out.extend(per[k])
+    return out
+
+
+def _device_struct(cls, scalars, per, keep):
+    """Fills a ctypes struct (EncoderWeights / EncoderGrads) with DEVICE pointers of contiguous fp32 tensors."""
+    FP = ctypes.POINTER(ctypes.c_float)
+
+    def fp(t):
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+        keep.append(t)
+        return ctypes.cast(ctypes.c_void_p(t.data_ptr()), FP)
+    st = cls()
+    for k, t in scalars.items():
+        setattr(st, k, fp(t))
+    for k, ts in per.items():
+        arr = (FP * len(ts))(*[fp(t) for t in ts])
+        keep.append(arr)
+        setattr(st, k, ctypes.cast(arr, ctypes.POINTER(FP)))
+    return st
+
+
+class _EncoderTrainFn(torch.autograd.Function):
+    """TRANSFORMER.forward under autograd: the forward keeps the activations in one `saved` buffer, the backward fills one
+    gradient tensor per parameter through se_encoder_bwd_bf16 (the input features get no gradient: they come from the
+    preprocessor)."""
+
+    @staticmethod
+    def forward(ctx, engine, model, feats, lengths, *params):
+        lib = _lib.load()
+        B, T, D = feats.shape
+        dev = feats.device
+        h = engine._ensure(model, None, dev)
+        H = model.config.hidden_size
+        nsaved = lib.se_encoder_saved_bytes(h, B, T)
+        nws = B * T * H * 4 + 256
+        saved = torch.empty(nsaved, device=dev, dtype=torch.uint8)
+        ws = torch.empty(nws, device=dev, dtype=torch.uint8)
+        hidden = torch.empty(B, T, H, device=dev, dtype=torch.float32)
+        _lib.check(lib.se_encoder_fwd_train_bf16(h, _lib.ptr(feats), _lib.ptr(lengths), B, T, _lib.ptr(hidden), _lib.ptr(saved), nsaved,
+                                                 _lib.ptr(ws), nws, _lib.stream()), 'se_encoder_fwd_train_bf16')
+        ctx.engine, ctx.model, ctx.buf, ctx.lengths, ctx.shape, ctx.handle = engine, model, saved, lengths, (B, T), h
+        return hidden
+
+    @staticmethod
+    def backward(ctx, d_hidden):
+        lib = _lib.load()
+        B, T = ctx.shape
+        model, saved, h = ctx.model, ctx.buf, ctx.handle
+        if h != ctx.engine.handle:
+            raise _lib.SEError('the encoder was re-created between forward and backward')
+        d_hidden = d_hidden.contiguous().float()
+        dev = d_hidden.device
+        head, per = _trunk_tensors(model)
+        ghead = {k: torch.empty_like(v, dtype=torch.float32) for k, v in head.items()}
+        gper = {k: [torch.empty_like(v, dtype=torch.float32) for v in vs] for k, vs in per.items()}
+        keep = []
+        gs = _device_struct(_lib.EncoderGrads, ghead, gper, keep)
+        nws = lib.se_encoder_train_workspace_bytes(h, B, T)
+        ws = torch.empty(nws, device=dev, dtype=torch.uint8)
+        _lib.check(lib.se_encoder_bwd_bf16(h, _lib.ptr(ctx.lengths), B, T, _lib.ptr(d_hidden), _lib.ptr(saved), saved.numel(), gs,
+                                           _lib.ptr(ws), nws, _lib.stream()), 'se_encoder_bwd_bf16')
+        ctx.buf = None
+        grads = [ghead[k] for k in ('in_w', 'in_b', 'in_ln_w', 'in_ln_b')]
+        for k in _TRUNK_FIELDS:
+            grads.extend(gper[k])
+        return (None, None, None, None) + tuple(grads)
+
+
 class _Engine:
-    """Owns the se_encoder handle for a parameter set; re-packs when any parameter changed (version counters)."""
+    """Owns the se_encoder handle for a parameter set; re-packs when any parameter changed (version counters): on the device
+    (se_encoder_refresh_bf16) when only the values changed -- every optimizer step of a fine-tune -- else by re-creating it."""
 
     def __init__(self):
         self.handle = None
@@ -205,9 +300,31 @@ class _Engine:
         params = ([p for p in model.parameters()] if model is not None else []) + ([p for p in head.parameters()] if head is not None else [])
         key = (device.index, tuple((p.data_ptr(), p._version) for p in params))
         if self.handle is None or key != self.key:
-            self._build(model, head, device)
+            same_storage = (self.handle is not None and self.key is not None and self.key[0] == key[0] and head is None and
+                            tuple(a for a, _ in self.key[1]) == tuple(a for a, _ in key[1]) and
+                            all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in params))
+            if same_storage:
+                keep = []
+                hd, per = _trunk_tensors(model)
+                w = _device_struct(_lib.EncoderWeights, {k: v.detach() for k, v in hd.items()}, {k: [t.detach() for t in v] for k, v in per.items()}, keep)
+                with torch.cuda.device(device):
+                    _lib.check(_lib.load().se_encoder_refresh_bf16(self.handle, w, _lib.stream()), 'se_encoder_refresh_bf16')
+            else:
+                self._build(model, head, device)
             self.key = key
         return self.handle
+
+    def encode_train(self, model, feats, lengths=None):
+        """Autograd-recording forward (Mockingjay fine-tune, model.py:164): returns hidden with a grad_fn."""
+        if not feats.is_cuda:
+            raise _lib.SEError('TRANSFORMER runs on MI355X only (no CPU fallback): move the module and inputs to the GPU')
+        lib = _lib.load()
+        feats = feats.detach().contiguous().float()
+        B, T, D = feats.shape
+        if lengths is None:
+            lengths = torch.empty(B, device=feats.device, dtype=torch.int32)
+            _lib.check(lib.se_valid_lengths_i32(_lib.ptr(feats), B, T, D, _lib.ptr(lengths), _lib.stream()), 'se_valid_lengths_i32')
+        return _EncoderTrainFn.apply(self, model, feats, lengths, *_trunk_param_list(model))
 
     def _workspace(self, handle, B, T, device):
         lib = _lib.load()
@@ -305,17 +422,19 @@ class TRANSFORMER(nn.Module):
 
     def forward(self, x):
         if self.training and not self._warned and self.model_config.hidden_dropout_prob > 0:
-            warnings.warn('TRANSFORMER.forward in training mode: dropout is not applied by the MI355X encoder (inference path)')
+            warnings.warn('TRANSFORMER.forward in training mode: dropout is not applied by the MI355X encoder')
             self._warned = True
-        if torch.is_grad_enabled() and not self.no_grad and any(p.requires_grad for p in self.model.parameters()) and x.requires_grad:
-            raise NotImplementedError('backward through the MI355X encoder is not implemented yet (inference / no_grad only)')
+        train = torch.is_grad_enabled() and not self.no_grad and any(p.requires_grad for p in self.model.parameters())
         if self.permute_input:
             x = x.permute(1, 0, 2)
         if hasattr(self, 'preprocessor') and x.size(-1) != self.inp_dim:
             # waveform input (B, T, C): the internal preprocessor extracts the pre-training input feature
             x = self.preprocessor(x.transpose(1, 2).contiguous())[0]
-        with torch.no_grad():
-            out = self._engine.encode(self.model, None, x)
+        if train:
+            out = self._engine.encode_train(self.model, x)
+        else:
+            with torch.no_grad():
+                out = self._engine.encode(self.model, None, x)
         if self.permute_input:
             out = out.permute(1, 0, 2)
         return out

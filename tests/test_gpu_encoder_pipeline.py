@@ -45,7 +45,7 @@ def test_encoder_small_vs_oracle(gpu, small, B, T, lens):
     assert hidden.shape == ref.shape == (B, T, 256)
     assert rel_l2(hidden, ref) < 2e-2
     assert (hidden.cpu() - ref).abs().max().item() < 5e-2 * ref.abs().max().item()
-    with torch.no_grad():                          # inference (the training path keeps intermediates and needs hidden 768)
+    with torch.no_grad():                          # inference path (with gradients enabled the head takes its training path)
         pred, res = up.SpecHead(hidden)
     rpred, rres = oheads.spec_head(ref, ckpt['SpecHead'], ocfg, log=True)
     assert rel_l2(res['log_predicted'], rres['log_predicted']) < 3e-2
