@@ -92,6 +92,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=32, help='utterances per GPU per step (configs[1]: 32)')
     ap.add_argument('--layers', type=int, default=6, help='encoder depth (6 = config/pretrain_sample.yaml; 3 = "base")')
+    ap.add_argument('--workload', choices=('enhance', 'finetune'), default='enhance',
+                    help="enhance = configs[1] (the headline metric); finetune = configs[3]'s Mockingjay training step "
+                         '(fwd + L1 + bwd + gradient all-reduce + clip + BertAdam), reported as a side measurement')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     args = ap.parse_args()
@@ -124,6 +127,18 @@ def main():
     upstream = pipeline.build_upstream(ckpt, dev)
     pre = pipeline.build_preprocessor(cfg, dev)
     step = pipeline.UpstreamEnhanceStep(pre, upstream)
+    if args.workload == 'finetune':
+        import warnings
+        warnings.simplefilter('ignore')
+        from speech_enhancement_by_s3prl_amd.solver import get_optimizer
+        del upstream
+        model = pipeline.build_mockingjay(ckpt, dev)
+        opt = get_optimizer(list(model.named_parameters()), lr=4e-5, warmup_proportion=0.07, training_steps=100000)
+        ft = pipeline.MockingjayFinetuneStep(pre, model, opt)
+
+        def step(wavs, lengths, max_len):          # same call shape as the enhance step
+            loss, gn, skipped = ft(wavs, lengths)
+            return loss.reshape(1), loss, None
     lengths, wavs = synth.fast_batch(args.batch, 160000, seed=1000 + rank, device=dev)   # resident in HBM before timing
     max_len = 160000
 
@@ -150,7 +165,7 @@ def main():
 
     total_utts = args.batch * world * args.steps
     out = {
-        'metric': 'enhanced 10s utts/sec', 'value': total_utts / elapsed, 'unit': 'utt/s', 'n_gpus': world,
+        'metric': 'enhanced 10s utts/sec' if args.workload == 'enhance' else 'fine-tuned 10s utts/sec (Mockingjay training step)', 'value': total_utts / elapsed, 'unit': 'utt/s', 'n_gpus': world,
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1000.0 * elapsed / args.steps,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
         'config': {'workload': 'configs[1]: TERA/Mockingjay upstream (6x768x12x3072, pretrain_sample.yaml) + '
@@ -159,6 +174,10 @@ def main():
                    'frames': 1001, 'parallelism': f'dp{world} (utterance-sharded inference, no data-path collective)',
                    'weights': 'seeded random, real sizes'},
     }
+    if args.workload == 'finetune':
+        out['config']['workload'] = ('configs[3]: Mockingjay fine-tune step (6x768x12x3072 encoder + spec head, 43 M params): STFT/features, '
+                                     'forward, masked log-L1, backward, flat-buffer gradient all-reduce, clip 1.0, BertAdam; dropout off')
+        out['config']['parallelism'] = f'dp{world} (replicated parameters, one gradient all-reduce per step)'
 
     if rank == 0 and not args.no_roofline:
         # roofline leg: the same K steps with HIP events recorded (in-library, on the launch stream) around every
@@ -170,7 +189,7 @@ def main():
         torch.cuda.synchronize()
         lib.se_prof_enable(0)
         fam = {}
-        for kind, name in ((0, 'gemm_bf16'), (1, 'mhsa_fwd'), (2, 'stft'), (3, 'istft')):
+        for kind, name in ((0, 'gemm_bf16'), (1, 'mhsa_fwd'), (2, 'stft'), (3, 'istft'), (6, 'mhsa_bwd')):
             ms, work, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_longlong()
             lib.se_prof_read(kind, ctypes.byref(ms), ctypes.byref(work), ctypes.byref(n))
             fam[name] = (ms.value, work.value, n.value)
@@ -186,6 +205,11 @@ def main():
             a = m_flop / (m_ms * 1e-3) / 1e12
             others['mhsa_fwd_kernel'] = {'bound': 'mfma', 'achieved': a, 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                                          'frac': a / MFMA_BF16_PEAK_TFLOPS, 'avg_launch_ms': m_ms / m_n, 'share_of_step_ms': m_ms / args.steps}
+        b_ms, b_flop, b_n = fam['mhsa_bwd']
+        if b_ms > 0:
+            a = b_flop / (b_ms * 1e-3) / 1e12
+            others['mhsa_bwd_kernels'] = {'bound': 'mfma', 'achieved': a, 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                                          'frac': a / MFMA_BF16_PEAK_TFLOPS, 'avg_launch_ms': b_ms / b_n, 'share_of_step_ms': b_ms / args.steps}
         for name in ('stft', 'istft'):
             ms, byts, n = fam[name]
             if ms > 0:
@@ -195,7 +219,7 @@ def main():
         others['gemm_share_of_step_ms'] = g_ms / args.steps
         out['roofline_other_kernels'] = others
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == 'enhance':
         try:
             out['cpu_baseline'] = cpu_baseline(batch=4, layers=args.layers)
         except Exception as e:      # the baseline is a reported extra; never lose the GPU line

@@ -303,6 +303,20 @@ int se_encoder_bwd_bf16(const se_encoder* enc, const int32_t* lengths, int B, in
                         size_t saved_bytes, const se_encoder_grads* grads, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Optimizer side of row E2 (runner.py:463-471): gradient norms and BertAdam for all parameter tensors in two launches.
+ * The pointer / size arrays are HOST arrays of n_tensors entries (device pointers inside); they are consumed during the
+ * call (copied into kernel arguments), the launches themselves are asynchronous.
+ * ---------------------------------------------------------------------------------------------- */
+/* sumsq[t] = sum of squares of gradient tensor t  (device double[n_tensors], overwritten) */
+int se_multi_sumsq_f32(const float* const* grads, const uint64_t* sizes, int n_tensors, double* sumsq, void* stream);
+/* BertAdam (S3PRL downstream.solver.get_optimizer, runner.py:110-113,470): Adam without bias correction, decoupled weight
+ * decay (per tensor), per-tensor gradient clip at max_grad_norm, preceded by the runner's global clip_grad_norm_ at
+ * global_max_norm (runner.py:464; <= 0 disables either).  sumsq from se_multi_sumsq_f32 on the same gradients. */
+int se_bertadam_step_f32(float* const* params, const float* const* grads, float* const* m, float* const* v, const uint64_t* sizes,
+                         const float* weight_decay, int n_tensors, const double* sumsq, double lr_t, double b1, double b2, double e,
+                         double max_grad_norm, double global_max_norm, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Optional in-library timing for bench.py's roofline leg: HIP events recorded on the launch stream around
  * every kernel of a family while enabled.  kind: 0 = bf16 GEMM (work = 2MNK flop), 1 = MHSA (4 B h T^2 64 flop),
  * 2 = STFT, 3 = iSTFT (work = algorithmic bytes), 4 = LayerNorm, 5 = head, 6 = MHSA backward (14 B h T^2 64 flop).  se_prof_read synchronises on the recorded events.

@@ -70,17 +70,6 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
   atomicAdd(&out[c], s);
 }
 
-// bf16 source: one thread per column, 64 rows per workgroup row-chunk
-__global__ __launch_bounds__(256) void colsum_bf16_kernel(const uint16_t* __restrict__ x, int rows, int cols, int ld, int rows_per_block,
-                                                          float* __restrict__ out) {
-  const int c = blockIdx.y * 256 + threadIdx.x;
-  if (c >= cols) return;
-  const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
-  float s = 0.f;
-  for (int r = r0; r < r1; ++r) s += bf2f(x[(size_t)r * ld + c]);
-  atomicAdd(&out[c], s);
-}
-
 __device__ __forceinline__ float gelu_grad(float x) {
   // d/dx [x Phi(x)] = Phi(x) + x phi(x)
   const float cdf = 0.5f * (1.0f + erf_as(x * 0.70710678118654752f));
@@ -116,6 +105,57 @@ __global__ __launch_bounds__(256) void gelu_bwd_bf16_kernel(const uint16_t* __re
   }
 }
 
+// Column sums of a bf16 matrix (bias gradients), optionally fused with gelu': GELU_BWD: dx = dy * gelu'(pre) is written and
+// summed in the same pass.  Lane = 8 consecutive columns (16-B loads), wave = 512 columns of one row, the 4 waves of a
+// workgroup interleave rows; per-workgroup LDS reduction, then one atomic per column.  cols % 8 == 0.
+template <int GELU_BWD>
+__global__ __launch_bounds__(256) void colsum8_bf16_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ pre,
+                                                           uint16_t* __restrict__ dx, int rows, int cols, int ld, int rows_per_block,
+                                                           float* __restrict__ out) {
+  __shared__ float red[4][512];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int c = blockIdx.y * 512 + lane * 8;
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  float acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+  if (c < cols) {
+    for (int r = r0 + wv; r < r1; r += 4) {
+      const size_t o = (size_t)r * ld + c;
+      const uint4 v = *reinterpret_cast<const uint4*>(x + o);
+      const uint32_t vi[4] = {v.x, v.y, v.z, v.w};
+      if (GELU_BWD) {
+        const uint4 pz = *reinterpret_cast<const uint4*>(pre + o);
+        const uint32_t pi[4] = {pz.x, pz.y, pz.z, pz.w};
+        uint32_t ov[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float d0 = bf2f((uint16_t)(vi[k] & 0xffffu)) * gelu_grad(bf2f((uint16_t)(pi[k] & 0xffffu)));
+          const float d1 = bf2f((uint16_t)(vi[k] >> 16)) * gelu_grad(bf2f((uint16_t)(pi[k] >> 16)));
+          ov[k] = pack_bf16x2(d0, d1);
+          // sum what is stored (the bf16-rounded gradient the weight-gradient GEMM will also see)
+          acc[2 * k] += bf2f((uint16_t)(ov[k] & 0xffffu));
+          acc[2 * k + 1] += bf2f((uint16_t)(ov[k] >> 16));
+        }
+        *reinterpret_cast<uint4*>(dx + o) = make_uint4(ov[0], ov[1], ov[2], ov[3]);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          acc[2 * k] += bf2f((uint16_t)(vi[k] & 0xffffu));
+          acc[2 * k + 1] += bf2f((uint16_t)(vi[k] >> 16));
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) red[wv][lane * 8 + k] = acc[k];
+  __syncthreads();
+  for (int j = threadIdx.x; j < 512; j += 256) {
+    const int cc = blockIdx.y * 512 + j;
+    if (cc < cols) atomicAdd(&out[cc], (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]));
+  }
+}
+
 // One wave per row, H = 256 NV.  x_in: LayerNorm input (or its pre-GELU value when GELU_IN); dy: gradient of the output.
 // dx (fp32) and / or dx_bf16 written; dgamma / dbeta accumulated with one atomic per column per workgroup.
 template <int NV, int GELU_IN>
@@ -123,12 +163,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             const float* __restrict__ dy,
                                                             const float* __restrict__ w, int M, float eps, float* __restrict__ dx,
                                                             uint16_t* __restrict__ dx_bf16, float* __restrict__ dgamma,
-                                                            float* __restrict__ dbeta, int rows_per_wave) {
+                                                            float* __restrict__ dbeta, float* __restrict__ dbias, int rows_per_wave) {
   constexpr int H = 256 * NV;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  float4 gsum[NV], bsum[NV];
+  float4 gsum[NV], bsum[NV], xsum[NV];     // column sums of dy xhat (dgamma), dy (dbeta), dx (bias gradient of the producing linear)
 #pragma unroll
-  for (int i = 0; i < NV; ++i) { gsum[i] = make_float4(0.f, 0.f, 0.f, 0.f); bsum[i] = make_float4(0.f, 0.f, 0.f, 0.f); }
+  for (int i = 0; i < NV; ++i) { gsum[i] = make_float4(0.f, 0.f, 0.f, 0.f); bsum[i] = make_float4(0.f, 0.f, 0.f, 0.f); xsum[i] = make_float4(0.f, 0.f, 0.f, 0.f); }
   float4 ww[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) ww[i] = *reinterpret_cast<const float4*>(w + (i * 64 + lane) * 4);
@@ -183,21 +223,24 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
       d.z = rstd * (g[i].z - a - v[i].z * bq); d.w = rstd * (g[i].w - a - v[i].w * bq);
       if (GELU_IN) { d.x *= gelu_grad(pre[i].x); d.y *= gelu_grad(pre[i].y); d.z *= gelu_grad(pre[i].z); d.w *= gelu_grad(pre[i].w); }
       const size_t o = (size_t)row * H + (i * 64 + lane) * 4;
+      xsum[i].x += d.x; xsum[i].y += d.y; xsum[i].z += d.z; xsum[i].w += d.w;
       if (dx) *reinterpret_cast<float4*>(dx + o) = d;
       if (dx_bf16) *reinterpret_cast<uint2*>(dx_bf16 + o) = make_uint2(pack_bf16x2(d.x, d.y), pack_bf16x2(d.z, d.w));
     }
   }
   // dgamma / dbeta: reduce the 4 waves through LDS, then one atomic per column per workgroup
-  __shared__ float red[2][4][H];
+  __shared__ float red[3][4][H];
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     *reinterpret_cast<float4*>(&red[0][wv][(i * 64 + lane) * 4]) = gsum[i];
     *reinterpret_cast<float4*>(&red[1][wv][(i * 64 + lane) * 4]) = bsum[i];
+    *reinterpret_cast<float4*>(&red[2][wv][(i * 64 + lane) * 4]) = xsum[i];
   }
   __syncthreads();
   for (int c = threadIdx.x; c < H; c += 256) {
     if (dgamma) atomicAdd(&dgamma[c], red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
     if (dbeta) atomicAdd(&dbeta[c], red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+    if (dbias) atomicAdd(&dbias[c], red[2][0][c] + red[2][1][c] + red[2][2][c] + red[2][3][c]);
   }
 }
 
@@ -252,24 +295,25 @@ extern "C" int se_colsum_f32(const float* x, int rows, int cols, int ld, float* 
 }
 
 int se::launch_layernorm_bwd(const float* x_in, const float* pe, int T, const float* dy, const float* w, int M, int H, float eps, int gelu_in,
-                             float* dx, uint16_t* dx_bf16, float* dgamma, float* dbeta, int accumulate, hipStream_t st) {
+                             float* dx, uint16_t* dx_bf16, float* dgamma, float* dbeta, float* dbias, int accumulate, hipStream_t st) {
   SE_REQUIRE(H == 768 || H == 256, "layernorm backward: only H = 768 / 256 are built (got %d)", H);
   if (!accumulate) {
     if (dgamma) SE_HIP(hipMemsetAsync(dgamma, 0, sizeof(float) * H, st));
     if (dbeta) SE_HIP(hipMemsetAsync(dbeta, 0, sizeof(float) * H, st));
+    if (dbias) SE_HIP(hipMemsetAsync(dbias, 0, sizeof(float) * H, st));
   }
   const int rows_per_wave = 16;
   const int grid = (M + 4 * rows_per_wave - 1) / (4 * rows_per_wave);
   if (H == 768) {
     if (gelu_in)
-      hipLaunchKernelGGL((se::layernorm_bwd_kernel<3, 1>), dim3(grid), dim3(256), 0, st, x_in, pe, T, dy, w, M, eps, dx, dx_bf16, dgamma, dbeta, rows_per_wave);
+      hipLaunchKernelGGL((se::layernorm_bwd_kernel<3, 1>), dim3(grid), dim3(256), 0, st, x_in, pe, T, dy, w, M, eps, dx, dx_bf16, dgamma, dbeta, dbias, rows_per_wave);
     else
-      hipLaunchKernelGGL((se::layernorm_bwd_kernel<3, 0>), dim3(grid), dim3(256), 0, st, x_in, pe, T, dy, w, M, eps, dx, dx_bf16, dgamma, dbeta, rows_per_wave);
+      hipLaunchKernelGGL((se::layernorm_bwd_kernel<3, 0>), dim3(grid), dim3(256), 0, st, x_in, pe, T, dy, w, M, eps, dx, dx_bf16, dgamma, dbeta, dbias, rows_per_wave);
   } else {
     if (gelu_in)
-      hipLaunchKernelGGL((se::layernorm_bwd_kernel<1, 1>), dim3(grid), dim3(256), 0, st, x_in, pe, T, dy, w, M, eps, dx, dx_bf16, dgamma, dbeta, rows_per_wave);
+      hipLaunchKernelGGL((se::layernorm_bwd_kernel<1, 1>), dim3(grid), dim3(256), 0, st, x_in, pe, T, dy, w, M, eps, dx, dx_bf16, dgamma, dbeta, dbias, rows_per_wave);
     else
-      hipLaunchKernelGGL((se::layernorm_bwd_kernel<1, 0>), dim3(grid), dim3(256), 0, st, x_in, pe, T, dy, w, M, eps, dx, dx_bf16, dgamma, dbeta, rows_per_wave);
+      hipLaunchKernelGGL((se::layernorm_bwd_kernel<1, 0>), dim3(grid), dim3(256), 0, st, x_in, pe, T, dy, w, M, eps, dx, dx_bf16, dgamma, dbeta, dbias, rows_per_wave);
   }
   SE_LAUNCH_CHECK();
   return SE_OK;
@@ -278,14 +322,26 @@ int se::launch_layernorm_bwd(const float* x_in, const float* pe, int T, const fl
 extern "C" int se_layernorm_bwd_f32(const float* x_in, const float* dy, const float* w, int M, int H, float eps, int gelu_in,
                                     float* dx, uint16_t* dx_bf16, float* dgamma, float* dbeta, int accumulate, void* stream) {
   SE_REQUIRE(x_in && dy && w && (dx || dx_bf16) && M > 0, "se_layernorm_bwd_f32: bad argument");
-  return se::launch_layernorm_bwd(x_in, nullptr, 1, dy, w, M, H, eps, gelu_in, dx, dx_bf16, dgamma, dbeta, accumulate, se::as_stream(stream));
+  return se::launch_layernorm_bwd(x_in, nullptr, 1, dy, w, M, H, eps, gelu_in, dx, dx_bf16, dgamma, dbeta, nullptr, accumulate, se::as_stream(stream));
 }
 
 int se::launch_colsum_bf16(const uint16_t* x, int rows, int cols, int ld, float* out, hipStream_t st) {
+  SE_REQUIRE(cols % 8 == 0 && ld % 8 == 0, "bf16 column sum: cols and ld must be multiples of 8");
   SE_HIP(hipMemsetAsync(out, 0, sizeof(float) * cols, st));
-  const int rpb = 256;
-  dim3 grid((rows + rpb - 1) / rpb, (cols + 255) / 256);
-  hipLaunchKernelGGL(se::colsum_bf16_kernel, grid, dim3(256), 0, st, x, rows, cols, ld, rpb, out);
+  const int rpb = 128;
+  dim3 grid((rows + rpb - 1) / rpb, (cols + 511) / 512);
+  hipLaunchKernelGGL((se::colsum8_bf16_kernel<0>), grid, dim3(256), 0, st, x, nullptr, nullptr, rows, cols, ld, rpb, out);
+  SE_LAUNCH_CHECK();
+  return SE_OK;
+}
+
+// dx = dy * gelu'(pre) (bf16, in place allowed) and colsum[c] = sum_rows dx  (FFN: activation backward + bias gradient)
+int se::launch_gelu_bwd_colsum(const uint16_t* dy, const uint16_t* pre, uint16_t* dx, int rows, int cols, float* colsum, hipStream_t st) {
+  SE_REQUIRE(cols % 8 == 0, "gelu backward: cols must be a multiple of 8");
+  SE_HIP(hipMemsetAsync(colsum, 0, sizeof(float) * cols, st));
+  const int rpb = 128;
+  dim3 grid((rows + rpb - 1) / rpb, (cols + 511) / 512);
+  hipLaunchKernelGGL((se::colsum8_bf16_kernel<1>), grid, dim3(256), 0, st, dy, pre, dx, rows, cols, cols, rpb, colsum);
   SE_LAUNCH_CHECK();
   return SE_OK;
 }

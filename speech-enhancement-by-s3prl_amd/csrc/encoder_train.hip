@@ -239,21 +239,19 @@ extern "C" int se_encoder_bwd_bf16(const se_encoder* enc, const int32_t* lengths
     const se_encoder::Layer& y = enc->layers[i];
     const SavedLayer& a = s.l[i];
     // ---- output LayerNorm:  x2 = LN(pre2)
-    SE_TRY(se::launch_layernorm_bwd(a.pre2, nullptr, 1, gy, y.oln_w, M, H, eps, 0, w.fa, w.b1, g->oln_w[i], g->oln_b[i], 0, st));
+    //      (its dx column sums are the bias gradient of the linear that produced pre2)
+    SE_TRY(se::launch_layernorm_bwd(a.pre2, nullptr, 1, gy, y.oln_w, M, H, eps, 0, w.fa, w.b1, g->oln_w[i], g->oln_b[i], g->ff2_b[i], 0, st));
     // ---- FFN output linear:  pre2 = h W2^T + b2 + x1
     SE_TRY(weight_grad(w.b1, H, a.h, I, M, Mp, H, I, g->ff2_w[i], w, stream));
-    SE_TRY(se_colsum_f32(w.fa, M, H, H, g->ff2_b[i], 0, stream));
     SE_TRY(input_grad(w.b1, y.ff2_w, M, H, I, nullptr, w.bi, nullptr, w, stream));                 // dh (M, I)
-    SE_TRY(se_gelu_bwd_bf16(w.bi, a.hpre, Mz * I, w.bi, stream));                                  // dhpre
+    SE_TRY(se::launch_gelu_bwd_colsum(w.bi, a.hpre, w.bi, M, I, g->ff1_b[i], st));                 // dhpre, and its column sums
     // ---- FFN input linear:  hpre = x1 W1^T + b1
     SE_TRY(weight_grad(w.bi, I, a.x1_bf, H, M, Mp, I, H, g->ff1_w[i], w, stream));
-    SE_TRY(se::launch_colsum_bf16(w.bi, M, I, I, g->ff1_b[i], st));
     SE_TRY(input_grad(w.bi, y.ff1_w, M, I, H, w.fa, nullptr, w.fb, w, stream));                    // dx1 = dhpre W1 + dpre2
     // ---- attention-output LayerNorm:  x1 = LN(pre1)
-    SE_TRY(se::launch_layernorm_bwd(a.pre1, nullptr, 1, w.fb, y.aln_w, M, H, eps, 0, w.fa, w.b1, g->aln_w[i], g->aln_b[i], 0, st));
+    SE_TRY(se::launch_layernorm_bwd(a.pre1, nullptr, 1, w.fb, y.aln_w, M, H, eps, 0, w.fa, w.b1, g->aln_w[i], g->aln_b[i], g->ao_b[i], 0, st));
     // ---- attention output linear:  pre1 = ctx Wo^T + bo + x0
     SE_TRY(weight_grad(w.b1, H, a.ctx, H, M, Mp, H, H, g->ao_w[i], w, stream));
-    SE_TRY(se_colsum_f32(w.fa, M, H, H, g->ao_b[i], 0, stream));
     SE_TRY(input_grad(w.b1, y.ao_w, M, H, H, nullptr, w.b2, nullptr, w, stream));                  // dctx (M, H)
     // ---- attention core
     SE_TRY(se_mhsa_bwd_bf16(a.qkv, a.ctx, w.b2, a.lse, lengths, B, T, enc->cfg.heads, w.b3, w.dvec, stream));
@@ -272,9 +270,8 @@ extern "C" int se_encoder_bwd_bf16(const se_encoder* enc, const int32_t* lengths
     gy = w.fb;
   }
   // ---- input stage:  x = LN(xin Win^T + b + PE)
-  SE_TRY(se::launch_layernorm_bwd(s.pre0, enc->pe, T, gy, enc->in_ln_w, M, H, eps, 0, w.fa, w.b1, g->in_ln_w, g->in_ln_b, 0, st));
+  SE_TRY(se::launch_layernorm_bwd(s.pre0, enc->pe, T, gy, enc->in_ln_w, M, H, eps, 0, w.fa, w.b1, g->in_ln_w, g->in_ln_b, g->in_b, 0, st));
   SE_TRY(weight_grad(w.b1, H, s.xin, se::kInPad, M, Mp, H, se::kInPad, w.gfused, w, stream));
   SE_HIP(hipMemcpy2DAsync(g->in_w, (size_t)D * 4, w.gfused, (size_t)se::kInPad * 4, (size_t)D * 4, H, hipMemcpyDeviceToDevice, st));
-  SE_TRY(se_colsum_f32(w.fa, M, H, H, g->in_b, 0, stream));
   return SE_OK;
 }

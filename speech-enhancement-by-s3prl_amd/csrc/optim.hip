@@ -1,0 +1,172 @@
+// optim.hip -- row E2's optimizer side on the device: gradient norms and the BertAdam update for ALL parameter tensors in
+// two launches (the reference does ~15 small torch kernels per parameter tensor: runner.py:463-471 -> clip_grad_norm_,
+// S3PRL BertAdam.step).  HBM-bound: 16 B read + 12 B written per parameter element in the update, 4 B read in the norm.
+//
+//   se_multi_sumsq_f32    sumsq[t] = sum g_t^2                       (one launch; fp64 atomics per 16 Ki-element chunk)
+//   se_bertadam_step_f32  c_g = min(1, G / (sqrt(sum_t sumsq[t]) + 1e-6))      global clip (runner.py:464), G <= 0: off
+//                         c_t = min(1, C / (c_g sqrt(sumsq[t]) + 1e-6))         BertAdam's per-parameter clip, C <= 0: off
+//                         g' = c_g c_t g ; m = b1 m + (1-b1) g' ; v = b2 v + (1-b2) g'^2
+//                         p -= lr_t (m / (sqrt(v) + e) + wd_t p)                no bias correction, decoupled decay
+// Tensor tables travel in the kernel arguments (<= 64 tensors per launch), so nothing is staged in device memory and
+// the call is asynchronous.
+#include <math.h>
+#include <algorithm>
+#include "common.h"
+
+namespace se {
+
+constexpr int kOptSlots = 64;
+constexpr uint32_t kOptChunk = 16384;      // elements per workgroup
+
+struct OptSlot {
+  float* p;
+  const float* g;
+  float* m;
+  float* v;
+  uint32_t n;
+  float wd;
+  uint32_t chunk0;      // first workgroup of this tensor inside the launch
+  uint32_t tensor;      // index into sumsq
+};
+struct OptBatch {
+  OptSlot s[kOptSlots];
+  int count;
+};
+
+__device__ __forceinline__ int find_slot(const OptBatch& b, uint32_t blk) {
+  int lo = 0;
+  for (int i = 1; i < b.count; ++i)
+    if (b.s[i].chunk0 <= blk) lo = i;
+  return lo;
+}
+
+__global__ __launch_bounds__(256) void multi_sumsq_kernel(const OptBatch b, double* __restrict__ sumsq) {
+  __shared__ float red[4];
+  const int si = find_slot(b, blockIdx.x);
+  const OptSlot& s = b.s[si];
+  const uint32_t e0 = (blockIdx.x - s.chunk0) * kOptChunk, e1 = min(s.n, e0 + kOptChunk);
+  float acc = 0.f;
+  const float* g = s.g;
+  if ((reinterpret_cast<uintptr_t>(g) & 15) == 0) {
+    uint32_t i = e0 + threadIdx.x * 4;
+    for (; i + 3 < e1; i += 1024) {
+      const float4 t = *reinterpret_cast<const float4*>(g + i);
+      acc += (t.x * t.x + t.y * t.y) + (t.z * t.z + t.w * t.w);
+    }
+    for (; i < e1; ++i) acc += g[i] * g[i];       // ragged tail of the last chunk (at most 3 elements on one thread)
+  } else {
+    for (uint32_t i = e0 + threadIdx.x; i < e1; i += 256) acc += g[i] * g[i];
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(&sumsq[s.tensor], (double)((red[0] + red[1]) + (red[2] + red[3])));
+}
+
+__global__ __launch_bounds__(256) void bertadam_kernel(const OptBatch b, const double* __restrict__ sumsq, int n_tensors, float lr_t, float b1,
+                                                       float ob1, float b2, float ob2, float e, float max_grad_norm, float global_max_norm) {
+  __shared__ float coef_s;
+  const int si = find_slot(b, blockIdx.x);
+  const OptSlot& s = b.s[si];
+  if (threadIdx.x == 0) {
+    float cg = 1.f;
+    if (global_max_norm > 0.f) {
+      double tot = 0.0;
+      for (int t = 0; t < n_tensors; ++t) tot += sumsq[t];
+      cg = fminf(1.f, global_max_norm / ((float)sqrt(tot) + 1e-6f));
+    }
+    float ct = 1.f;
+    if (max_grad_norm > 0.f) ct = fminf(1.f, max_grad_norm / (cg * (float)sqrt(sumsq[s.tensor]) + 1e-6f));
+    coef_s = cg * ct;
+  }
+  __syncthreads();
+  const float coef = coef_s, wd = s.wd;
+  const uint32_t e0 = (blockIdx.x - s.chunk0) * kOptChunk, e1 = min(s.n, e0 + kOptChunk);
+  float* p = s.p;
+  const float* g = s.g;
+  float* m = s.m;
+  float* v = s.v;
+  const bool vec = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
+                     reinterpret_cast<uintptr_t>(v)) & 15) == 0;
+  auto upd = [&](float& pp, float gg, float& mm, float& vv) {
+    gg *= coef;
+    mm = b1 * mm + ob1 * gg;
+    vv = b2 * vv + ob2 * gg * gg;
+    pp -= lr_t * (mm / (sqrtf(vv) + e) + wd * pp);
+  };
+  uint32_t i = e0 + (vec ? threadIdx.x * 4 : threadIdx.x);
+  if (vec) {
+    for (; i + 3 < e1; i += 1024) {
+      float4 pp = *reinterpret_cast<float4*>(p + i), mm = *reinterpret_cast<float4*>(m + i), vv = *reinterpret_cast<float4*>(v + i);
+      const float4 gg = *reinterpret_cast<const float4*>(g + i);
+      upd(pp.x, gg.x, mm.x, vv.x); upd(pp.y, gg.y, mm.y, vv.y); upd(pp.z, gg.z, mm.z, vv.z); upd(pp.w, gg.w, mm.w, vv.w);
+      *reinterpret_cast<float4*>(p + i) = pp;
+      *reinterpret_cast<float4*>(m + i) = mm;
+      *reinterpret_cast<float4*>(v + i) = vv;
+    }
+    for (; i < e1; ++i) upd(p[i], g[i], m[i], v[i]);
+  } else {
+    for (; i < e1; i += 256) upd(p[i], g[i], m[i], v[i]);
+  }
+}
+
+template <typename F>
+int for_batches(float* const* params, const float* const* grads, float* const* m, float* const* v, const uint64_t* sizes,
+                const float* weight_decay, int n_tensors, F&& launch) {
+  int t = 0;
+  while (t < n_tensors) {
+    OptBatch b;
+    b.count = 0;
+    uint32_t chunks = 0;
+    while (t < n_tensors && b.count < kOptSlots) {
+      if (sizes[t] == 0) { ++t; continue; }
+      if (sizes[t] > 0xffffffffull) {
+        set_error("optimizer: tensor %d has %llu elements (> 2^32 - 1)", t, (unsigned long long)sizes[t]);
+        return SE_ERR_INVALID;
+      }
+      OptSlot& s = b.s[b.count++];
+      s.p = params ? params[t] : nullptr;
+      s.g = grads[t];
+      s.m = m ? m[t] : nullptr;
+      s.v = v ? v[t] : nullptr;
+      s.n = (uint32_t)sizes[t];
+      s.wd = weight_decay ? weight_decay[t] : 0.f;
+      s.chunk0 = chunks;
+      s.tensor = (uint32_t)t;
+      chunks += (s.n + kOptChunk - 1) / kOptChunk;
+      ++t;
+    }
+    if (b.count == 0) break;
+    const int rc = launch(b, chunks);
+    if (rc) return rc;
+  }
+  return SE_OK;
+}
+
+}  // namespace se
+
+extern "C" int se_multi_sumsq_f32(const float* const* grads, const uint64_t* sizes, int n_tensors, double* sumsq, void* stream) {
+  SE_REQUIRE(grads && sizes && sumsq && n_tensors > 0, "se_multi_sumsq_f32: bad argument");
+  hipStream_t st = se::as_stream(stream);
+  SE_HIP(hipMemsetAsync(sumsq, 0, sizeof(double) * n_tensors, st));
+  return se::for_batches(nullptr, grads, nullptr, nullptr, sizes, nullptr, n_tensors, [&](const se::OptBatch& b, uint32_t chunks) {
+    hipLaunchKernelGGL(se::multi_sumsq_kernel, dim3(chunks), dim3(256), 0, st, b, sumsq);
+    SE_LAUNCH_CHECK();
+    return (int)SE_OK;
+  });
+}
+
+extern "C" int se_bertadam_step_f32(float* const* params, const float* const* grads, float* const* m, float* const* v, const uint64_t* sizes,
+                                    const float* weight_decay, int n_tensors, const double* sumsq, double lr_t, double b1, double b2, double e,
+                                    double max_grad_norm, double global_max_norm, void* stream) {
+  SE_REQUIRE(params && grads && m && v && sizes && n_tensors > 0, "se_bertadam_step_f32: bad argument");
+  SE_REQUIRE(sumsq || (max_grad_norm <= 0.0 && global_max_norm <= 0.0), "se_bertadam_step_f32: clipping needs the gradient sums of squares");
+  hipStream_t st = se::as_stream(stream);
+  return se::for_batches(params, grads, m, v, sizes, weight_decay, n_tensors, [&](const se::OptBatch& b, uint32_t chunks) {
+    hipLaunchKernelGGL(se::bertadam_kernel, dim3(chunks), dim3(256), 0, st, b, sumsq, n_tensors, (float)lr_t, (float)b1, (float)(1.0 - b1),
+                       (float)b2, (float)(1.0 - b2), (float)e, (float)max_grad_norm, (float)global_max_norm);
+    SE_LAUNCH_CHECK();
+    return (int)SE_OK;
+  });
+}

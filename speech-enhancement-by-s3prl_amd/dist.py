@@ -48,7 +48,8 @@ class FlatGradAllReducer:
             self.views.append(self.flat[off:off + p.numel()].view_as(p))
             off += p.numel()
 
-    def reduce(self):
+    def reduce(self, copy_back=True):
+        """copy_back=False leaves the reduced gradients in the flat buffer's views only (the fused optimizer reads them there)."""
         for p, v in zip(self.params, self.views):
             if p.grad is None:
                 v.zero_()
@@ -56,11 +57,12 @@ class FlatGradAllReducer:
                 v.copy_(p.grad)
         if is_distributed():
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-        for p, v in zip(self.params, self.views):
-            if p.grad is None:
-                p.grad = v.clone()
-            else:
-                p.grad.copy_(v)
+        if copy_back:
+            for p, v in zip(self.params, self.views):
+                if p.grad is None:
+                    p.grad = v.clone()
+                else:
+                    p.grad.copy_(v)
         return self.flat
 
 
@@ -76,7 +78,24 @@ class DataParallelTrainStep:
     def step(self, loss):
         """loss already computed with the global-mean criterion; backward, all-reduce, clip, (maybe) step."""
         loss.backward()
-        self.reducer.reduce()
+        fused = getattr(self.optimizer, 'step_fused', None) is not None and self.reducer.flat.is_cuda
+        if fused:
+            # device path: gradients stay in the flat (all-reduced) buffer; norms in one launch, global clip + per-tensor clip +
+            # BertAdam in one more.  The skip decision reads the reduced norm, identically on every rank.
+            self.reducer.reduce(copy_back=False)
+            tab = self.optimizer._fused_table(grads=dict(zip(self.reducer.params, self.reducer.views)))
+            if tab is not None:
+                sumsq = self.optimizer.grad_sumsq(tab)
+                gn = float(sumsq.sum().sqrt())
+                skipped = math.isnan(gn) or math.isinf(gn)
+                if not skipped:
+                    self.optimizer.step_fused(tab, sumsq, global_max_norm=self.grad_clip)
+                self.optimizer.zero_grad()
+                return gn, skipped
+            for p, v in zip(self.reducer.params, self.reducer.views):
+                p.grad = v.clone() if p.grad is None else p.grad.copy_(v)
+        else:
+            self.reducer.reduce()
         grad_norm = torch.nn.utils.clip_grad_norm_(self.reducer.params, self.grad_clip)
         gn = float(grad_norm)
         skipped = math.isnan(gn) or math.isinf(gn)          # identical on every rank: taken on the reduced gradient

@@ -133,3 +133,41 @@ class HeadEnhanceStep:
         wav_tar = wavs[:, self.pre.channel_tar, :]
         wav_pred = decode.decode_wav(self.pre, predicted, ph_inp, lengths, wav_tar, max_len=max_len)
         return wav_pred, predicted, lin_tar
+
+
+class MockingjayFinetuneStep:
+    """One training step of config 3 (runner.py:431-471 with `--downstream Mockingjay`): wavs -> features -> Mockingjay
+    (encoder + spec head, training paths) -> global-mean masked log-L1 -> backward on the HIP kernels -> ONE flat-buffer
+    gradient all-reduce across ranks (RCCL) -> clip_grad_norm_(1.0) / NaN skip -> BertAdam."""
+
+    def __init__(self, preprocessor, model, optimizer, grad_clip=1.0):
+        from .dist import DataParallelTrainStep
+        self.pre, self.model = preprocessor, model
+        self.criterion = L1()
+        self.dp = DataParallelTrainStep(model, self.criterion, optimizer, grad_clip=grad_clip)
+
+    def __call__(self, wavs, lengths):
+        with torch.no_grad():
+            feats_up, feats_down, lin_inp, ph_inp, lin_tar, ph_tar = self.pre(wavs)
+        predicted, res = self.model(features=feats_up, linears=lin_inp)
+        stft_lengths = lengths // self.pre._win_args['hop_length'] + 1
+        loss, _ = self.criterion(log_predicted=res['log_predicted'], linear_tar=lin_tar, stft_lengths=stft_lengths)
+        grad_norm, skipped = self.dp.step(loss)
+        return loss.detach(), grad_norm, skipped
+
+
+def build_mockingjay(ckpt, device, tmp_dir=None):
+    """Mockingjay(dckpt) from an in-memory checkpoint dict (the class loads from a path, model.py:148)."""
+    import os
+    import tempfile
+    from .heads import Mockingjay
+    d = tmp_dir or tempfile.mkdtemp(prefix='se_amd_ckpt_')
+    path = os.path.join(d, 'states.ckpt')
+    torch.save(ckpt, path)
+    try:
+        model = Mockingjay(path)
+    finally:
+        os.remove(path)
+        if tmp_dir is None:
+            os.rmdir(d)
+    return model.to(device).train()

@@ -47,3 +47,68 @@ def test_head_backward_vs_autograd(gpu, B, F, D, N, act):
     (p * g.to(gpu)).sum().backward()
     assert (m.linear.weight.grad.cpu().double() - w.grad).abs().max().item() < 1e-4 * w.grad.abs().max().item()
     assert (m.linear.bias.grad.cpu().double() - b.grad).abs().max().item() < 1e-4 * b.grad.abs().max().item()
+
+
+def _opt_fixture(device, seed=0):
+    from speech_enhancement_by_s3prl_amd.solver import get_optimizer
+    g = torch.Generator().manual_seed(seed)
+    shapes = {'a.weight': (201, 120), 'a.bias': (201,), 'enc.LayerNorm.weight': (768,), 'enc.LayerNorm.bias': (768,),
+              'big.weight': (3072, 768), 'odd.weight': (37, 5), 'tiny.bias': (3,)}
+    named = [(n, torch.nn.Parameter((torch.randn(*s, generator=g) * 0.1).to(device))) for n, s in shapes.items()]
+    opt = get_optimizer(named, lr=1e-3, warmup_proportion=0.1, training_steps=20)
+    grads = [[torch.randn(*s, generator=g) * sc for s in shapes.values()] for sc in (0.001, 0.2, 3.0, 0.05)]   # per-tensor clip on and off
+    return named, opt, grads
+
+
+def test_fused_bertadam_matches_oracle(gpu):
+    """two-launch BertAdam (se_multi_sumsq_f32 + se_bertadam_step_f32) vs oracle/optim.py in float64: parameters and both
+    moments after 4 steps (fp32 bound 1e-5); the per-tensor torch path on the CPU agrees to 2e-4 only -- its fp32 norm of a
+    2.4 M element tensor is itself 4e-5 off."""
+    from oracle import optim as oopt
+    named_g, opt_g, grads = _opt_fixture(gpu)
+    named_c, opt_c, _ = _opt_fixture(torch.device('cpu'))
+    ref = {n: [p.detach().cpu().double(), torch.zeros(p.shape, dtype=torch.float64), torch.zeros(p.shape, dtype=torch.float64)] for n, p in named_g}
+    for k, step_grads in enumerate(grads):
+        for (n, pg), (_, pc), g in zip(named_g, named_c, step_grads):
+            pg.grad, pc.grad = g.to(gpu), g.clone()
+            wd = 0.0 if ('bias' in n or 'LayerNorm' in n) else 0.01
+            ref[n] = list(oopt.bert_adam_step(ref[n][0], g.double(), ref[n][1], ref[n][2], k, 1e-3, 0.1, 20, wd))
+        v0 = named_g[0][1]._version
+        opt_g.step()
+        opt_c.step()
+        assert named_g[0][1]._version > v0           # engines key their bf16 copies on the version counter
+    for (n, pg), (_, pc) in zip(named_g, named_c):
+        sg = opt_g.state[pg]
+        assert sg['step'] == 4
+        for got, want, what in ((pg.detach(), ref[n][0], 'p'), (sg['next_m'], ref[n][1], 'm'), (sg['next_v'], ref[n][2], 'v')):
+            err = (got.double().cpu() - want).abs().max().item()
+            assert err < 1e-5 * want.abs().max().item() + 1e-12, (n, what, err)
+        assert torch.allclose(pg.detach().cpu(), pc.detach(), rtol=2e-4, atol=1e-6), n
+
+
+def test_fused_train_step_global_clip(gpu):
+    """DataParallelTrainStep's device path (global clip folded into the update) vs clip_grad_norm_ + BertAdam on the CPU."""
+    from speech_enhancement_by_s3prl_amd.dist import DataParallelTrainStep
+    from speech_enhancement_by_s3prl_amd.objective import L1
+    named_g, opt_g, grads = _opt_fixture(gpu, seed=1)
+    named_c, opt_c, _ = _opt_fixture(torch.device('cpu'), seed=1)
+    model = torch.nn.Module()
+    for i, (_, p) in enumerate(named_g):
+        model.register_parameter(f'p{i}', p)
+    dp = DataParallelTrainStep(model, L1(), opt_g, grad_clip=1.0)
+    for step_grads in grads:
+        # a loss whose gradient wrt each parameter is exactly the prescribed tensor
+        loss = sum((p * g.to(gpu)).sum() for (_, p), g in zip(named_g, step_grads))
+        gn, skipped = dp.step(loss)
+        for (_, pc), g in zip(named_c, step_grads):
+            pc.grad = g.clone()
+        ref_gn = torch.nn.utils.clip_grad_norm_([p for _, p in named_c], 1.0)
+        opt_c.step()
+        assert not skipped and abs(gn - float(ref_gn)) < 2e-4 * float(ref_gn)
+    for (n, pg), (_, pc) in zip(named_g, named_c):
+        assert torch.allclose(pg.detach().cpu(), pc.detach(), rtol=3e-4, atol=1e-6), n
+    # NaN gradient: the step is skipped, parameters untouched
+    before = [p.detach().clone() for _, p in named_g]
+    loss = sum((p * float('nan')).sum() for _, p in named_g)
+    gn, skipped = dp.step(loss)
+    assert skipped and all(torch.equal(b, p.detach()) for b, (_, p) in zip(before, named_g))
