@@ -33,6 +33,47 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const uint16_t* __r
   }
 }
 
+// vector form of the same (ld_in % 8 == 0, ld_out % 8 == 0, 16-B aligned bases): 16-B global loads of row pieces, 16-B
+// global stores of 8 consecutive source rows of one column (8 lanes complete a 128-B line of the output row); the
+// 2-byte gathers happen in LDS only (132-B row stride: the 8 row-chunks of a store wave hit distinct banks).
+__global__ __launch_bounds__(256) void transpose_bf16_vec_kernel(const uint16_t* __restrict__ in, int rows, int cols, int ld_in,
+                                                                 uint16_t* __restrict__ out, int ld_out) {
+  __shared__ uint32_t tile[64][33];
+  const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int rl = (t >> 3) + 32 * pass, r = r0 + rl, c = c0 + (t & 7) * 8;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (r < rows) {
+      if (c + 7 < cols) {
+        v = *reinterpret_cast<const uint4*>(in + (size_t)r * ld_in + c);
+      } else if (c < cols) {
+        uint16_t e[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) e[k] = (c + k < cols) ? in[(size_t)r * ld_in + c + k] : (uint16_t)0;
+        v = make_uint4(e[0] | ((uint32_t)e[1] << 16), e[2] | ((uint32_t)e[3] << 16), e[4] | ((uint32_t)e[5] << 16), e[6] | ((uint32_t)e[7] << 16));
+      }
+    }
+    uint32_t* d = &tile[rl][(t & 7) * 4];
+    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  }
+  __syncthreads();
+  const uint16_t* t16 = reinterpret_cast<const uint16_t*>(&tile[0][0]);
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int cl = (t >> 3) + 32 * pass, m = (t & 7) * 8;
+    const int c = c0 + cl, r = r0 + m;
+    if (c < cols && r < ld_out) {
+      uint16_t e[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) e[k] = t16[(m + k) * 66 + cl];
+      *reinterpret_cast<uint4*>(out + (size_t)c * ld_out + r) =
+          make_uint4(e[0] | ((uint32_t)e[1] << 16), e[2] | ((uint32_t)e[3] << 16), e[4] | ((uint32_t)e[5] << 16), e[6] | ((uint32_t)e[7] << 16));
+    }
+  }
+}
+
 // same from an fp32 source (casts on the way): out[c][r] = bf16(in[r][c])
 __global__ __launch_bounds__(256) void transpose_f32_bf16_kernel(const float* __restrict__ in, int rows, int cols, int ld_in,
                                                                  uint16_t* __restrict__ out, int ld_out) {
@@ -250,7 +291,10 @@ extern "C" int se_transpose_bf16(const uint16_t* in, int rows, int cols, int ld_
   SE_REQUIRE(in && out && rows > 0 && cols > 0 && ld_in >= cols && ld_out >= rows, "se_transpose_bf16: bad argument");
   dim3 grid((ld_out + 63) / 64, (cols + 63) / 64);
   SE_REQUIRE(grid.y <= 65535, "se_transpose_bf16: too many columns");
-  hipLaunchKernelGGL(se::transpose_bf16_kernel, grid, dim3(256), 0, se::as_stream(stream), in, rows, cols, ld_in, out, ld_out);
+  if (ld_in % 8 == 0 && ld_out % 8 == 0 && (((uintptr_t)in | (uintptr_t)out) & 15) == 0)
+    hipLaunchKernelGGL(se::transpose_bf16_vec_kernel, grid, dim3(256), 0, se::as_stream(stream), in, rows, cols, ld_in, out, ld_out);
+  else
+    hipLaunchKernelGGL(se::transpose_bf16_kernel, grid, dim3(256), 0, se::as_stream(stream), in, rows, cols, ld_in, out, ld_out);
   SE_LAUNCH_CHECK();
   return SE_OK;
 }
