@@ -254,6 +254,10 @@ int se_transpose_f32_bf16(const float* in, int rows, int cols, int ld_in, uint16
  * workspace >= splits * N * K * 4 bytes. */
 int se_wgrad_bf16(const uint16_t* dYt, const uint16_t* Xt, int Mp, int N, int K, int splits, float* dW, int accumulate,
                   void* workspace, size_t workspace_bytes, void* stream);
+/* same result straight from the ROW-MAJOR operands (no transposes): dW[N,K] (+)= dY[M,N]^T . X[M,K]; the fragments are taken
+ * from row-major LDS panels with the hardware-transposed LDS read.  N, K, ldy, ldx multiples of 8; workspace >= splits*N*K floats. */
+int se_wgrad_tn_bf16(const uint16_t* dY, int ldy, const uint16_t* X, int ldx, int M, int N, int K, int splits, float* dW,
+                     int accumulate, void* workspace, size_t workspace_bytes, void* stream);
 /* bias gradient: out[c] (+)= sum_r x[r][c] */
 int se_colsum_f32(const float* x, int rows, int cols, int ld, float* out, int accumulate, void* stream);
 /* LayerNorm backward (TF style).  x_in = LayerNorm input (gelu_in: its pre-GELU value, i.e. y = LN(gelu(x_in)), and

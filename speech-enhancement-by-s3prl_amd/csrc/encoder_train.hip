@@ -17,13 +17,7 @@
 namespace {
 
 using se::al256;
-constexpr int kSplits = 8;
-
-inline int padded_rows(int M) {                 // rows of the transposed operands: splits x (multiple of 64, >= 128)
-  int mc = (M + kSplits - 1) / kSplits;
-  mc = std::max(128, (mc + 63) / 64 * 64);
-  return mc * kSplits;
-}
+constexpr int kSplits = 16;        // upper bound of the weight-gradient split count (workspace sizing)
 
 struct SavedLayer {
   uint16_t *x0_bf, *qkv, *ctx, *x1_bf, *hpre, *h;
@@ -66,7 +60,6 @@ struct TrainWs {
   uint16_t *bi;                      // bf16 (M, I)
   uint16_t *b3;                      // bf16 (M, 3H)
   float* dvec;                       // (B, heads, T)
-  uint16_t *ta, *tb;                 // transposed operands (max(I, 3H), Mp)
   uint16_t* wt;                      // transposed weight copy (max 3H*H, I*H)
   float* partials;                   // split-K slabs
   float* gfused;                     // fused qkv weight gradient (3H, H) / padded input weight gradient (H, kInPad)
@@ -76,7 +69,6 @@ struct TrainWs {
 
 TrainWs carve_ws(const se_encoder* e, int B, int T, char* base) {
   const size_t M = (size_t)B * T, H = e->cfg.hidden, I = e->cfg.intermediate, heads = e->cfg.heads;
-  const size_t Mp = padded_rows((int)M);
   const size_t wide = std::max(I, 3 * H);
   TrainWs w;
   size_t off = 0;
@@ -88,8 +80,6 @@ TrainWs carve_ws(const se_encoder* e, int B, int T, char* base) {
   w.bi = (uint16_t*)take(M * I * 2);
   w.b3 = (uint16_t*)take(M * 3 * H * 2);
   w.dvec = (float*)take((size_t)B * heads * T * 4);
-  w.ta = (uint16_t*)take(wide * Mp * 2);
-  w.tb = (uint16_t*)take(wide * Mp * 2);
   w.wt = (uint16_t*)take(wide * H * 2);
   w.partials = (float*)take((size_t)kSplits * wide * H * 4);
   w.gfused = (float*)take(std::max(3 * H * H, H * (size_t)se::kInPad) * 4);
@@ -204,11 +194,14 @@ extern "C" int se_encoder_fwd_train_bf16(const se_encoder* enc, const float* fea
 
 namespace {
 
-// dW (N, K) = dY^T X from row-major bf16 dY (M, N) [ld ldy] and X (M, K) [ld ldx]; bias gradient by the caller
-int weight_grad(const uint16_t* dY, int ldy, const uint16_t* X, int ldx, int M, int Mp, int N, int K, float* dW, const TrainWs& w, void* stream) {
-  SE_TRY(se_transpose_bf16(dY, M, N, ldy, w.ta, Mp, stream));
-  SE_TRY(se_transpose_bf16(X, M, K, ldx, w.tb, Mp, stream));
-  return se_wgrad_bf16(w.ta, w.tb, Mp, N, K, kSplits, dW, 0, w.partials, (size_t)kSplits * N * K * sizeof(float), stream);
+// dW (N, K) = dY^T X from row-major bf16 dY (M, N) [ld ldy] and X (M, K) [ld ldx]; bias gradient by the caller.
+// Split count: the TN kernel's m-splits are pinned to XCDs in groups of 8; more splits fill the chip better but every
+// split costs one fp32 slab (N K 4 bytes written + read back), so the big FFN shapes take 16 and the rest 8.
+int weight_grad(const uint16_t* dY, int ldy, const uint16_t* X, int ldx, int M, int N, int K, float* dW, const TrainWs& w, void* stream) {
+  const int tiles = ((N + 255) / 256) * ((K + 127) / 128);
+  int splits = tiles >= 64 ? 16 : 8;
+  while (splits > 1 && (size_t)splits * 64 > (size_t)M) splits >>= 1;
+  return se_wgrad_tn_bf16(dY, ldy, X, ldx, M, N, K, splits, dW, 0, w.partials, (size_t)splits * N * K * sizeof(float), stream);
 }
 
 // dX (M, K) = dY (M, N) . W (N, K) [+ residual]   through the forward GEMM on W^T (K, N)
@@ -229,7 +222,7 @@ extern "C" int se_encoder_bwd_bf16(const se_encoder* enc, const int32_t* lengths
   SE_REQUIRE(((uintptr_t)saved % 256 == 0) && ((uintptr_t)workspace % 256 == 0), "se_encoder_bwd_bf16: buffers must be 256-B aligned");
   const int H = enc->cfg.hidden, I = enc->cfg.intermediate, D = enc->cfg.input_dim, L = enc->cfg.layers;
   const size_t Mz = (size_t)B * T;
-  const int M = (int)Mz, Mp = padded_rows(M);
+  const int M = (int)Mz;
   hipStream_t st = se::as_stream(stream);
   const Saved s = carve_saved(enc, B, T, reinterpret_cast<char*>(const_cast<void*>(saved)));
   const TrainWs w = carve_ws(enc, B, T, reinterpret_cast<char*>(workspace));
@@ -242,21 +235,21 @@ extern "C" int se_encoder_bwd_bf16(const se_encoder* enc, const int32_t* lengths
     //      (its dx column sums are the bias gradient of the linear that produced pre2)
     SE_TRY(se::launch_layernorm_bwd(a.pre2, nullptr, 1, gy, y.oln_w, M, H, eps, 0, w.fa, w.b1, g->oln_w[i], g->oln_b[i], g->ff2_b[i], 0, st));
     // ---- FFN output linear:  pre2 = h W2^T + b2 + x1
-    SE_TRY(weight_grad(w.b1, H, a.h, I, M, Mp, H, I, g->ff2_w[i], w, stream));
+    SE_TRY(weight_grad(w.b1, H, a.h, I, M, H, I, g->ff2_w[i], w, stream));
     SE_TRY(input_grad(w.b1, y.ff2_w, M, H, I, nullptr, w.bi, nullptr, w, stream));                 // dh (M, I)
     SE_TRY(se::launch_gelu_bwd_colsum(w.bi, a.hpre, w.bi, M, I, g->ff1_b[i], st));                 // dhpre, and its column sums
     // ---- FFN input linear:  hpre = x1 W1^T + b1
-    SE_TRY(weight_grad(w.bi, I, a.x1_bf, H, M, Mp, I, H, g->ff1_w[i], w, stream));
+    SE_TRY(weight_grad(w.bi, I, a.x1_bf, H, M, I, H, g->ff1_w[i], w, stream));
     SE_TRY(input_grad(w.bi, y.ff1_w, M, I, H, w.fa, nullptr, w.fb, w, stream));                    // dx1 = dhpre W1 + dpre2
     // ---- attention-output LayerNorm:  x1 = LN(pre1)
     SE_TRY(se::launch_layernorm_bwd(a.pre1, nullptr, 1, w.fb, y.aln_w, M, H, eps, 0, w.fa, w.b1, g->aln_w[i], g->aln_b[i], g->ao_b[i], 0, st));
     // ---- attention output linear:  pre1 = ctx Wo^T + bo + x0
-    SE_TRY(weight_grad(w.b1, H, a.ctx, H, M, Mp, H, H, g->ao_w[i], w, stream));
+    SE_TRY(weight_grad(w.b1, H, a.ctx, H, M, H, H, g->ao_w[i], w, stream));
     SE_TRY(input_grad(w.b1, y.ao_w, M, H, H, nullptr, w.b2, nullptr, w, stream));                  // dctx (M, H)
     // ---- attention core
     SE_TRY(se_mhsa_bwd_bf16(a.qkv, a.ctx, w.b2, a.lse, lengths, B, T, enc->cfg.heads, w.b3, w.dvec, stream));
     // ---- fused QKV linear:  qkv = x0 Wqkv^T + b
-    SE_TRY(weight_grad(w.b3, 3 * H, a.x0_bf, H, M, Mp, 3 * H, H, w.gfused, w, stream));
+    SE_TRY(weight_grad(w.b3, 3 * H, a.x0_bf, H, M, 3 * H, H, w.gfused, w, stream));
     SE_TRY(se::launch_colsum_bf16(w.b3, M, 3 * H, 3 * H, w.bfused, st));
     {
       float* wdst[3] = {g->q_w[i], g->k_w[i], g->v_w[i]};
@@ -271,7 +264,7 @@ extern "C" int se_encoder_bwd_bf16(const se_encoder* enc, const int32_t* lengths
   }
   // ---- input stage:  x = LN(xin Win^T + b + PE)
   SE_TRY(se::launch_layernorm_bwd(s.pre0, enc->pe, T, gy, enc->in_ln_w, M, H, eps, 0, w.fa, w.b1, g->in_ln_w, g->in_ln_b, g->in_b, 0, st));
-  SE_TRY(weight_grad(w.b1, H, s.xin, se::kInPad, M, Mp, H, se::kInPad, w.gfused, w, stream));
+  SE_TRY(weight_grad(w.b1, H, s.xin, se::kInPad, M, H, se::kInPad, w.gfused, w, stream));
   SE_HIP(hipMemcpy2DAsync(g->in_w, (size_t)D * 4, w.gfused, (size_t)se::kInPad * 4, (size_t)D * 4, H, hipMemcpyDeviceToDevice, st));
   return SE_OK;
 }

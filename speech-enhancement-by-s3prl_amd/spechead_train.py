@@ -6,7 +6,7 @@ backward needs, backward runs on the HIP building blocks of csrc/bwd.hip through
 
 backward (mixed precision as the forward: bf16 GEMM operands, fp32 sums):
     dp   = epilogue'(p; d_pred, d_logp)              fp32 (M, N) + bf16 (M, 256) zero padded
-    dWo  = dp^T xn   (wgrad: transposed operands, split-K over M)      dbo = colsum(dp)
+    dWo  = dp^T xn   (se_wgrad_tn_bf16: row-major operands, split over M)   dbo = colsum(dp)
     dxn  = dp Wo     (se_gemm_bf16 on the transposed weight)
     dpre = LayerNorm'(gelu(pre)) . gelu'(pre)        (+ dgamma, dbeta)
     dWd  = dpre^T x  (wgrad)                                            dbd = colsum(dpre)
@@ -70,6 +70,19 @@ def wgrad(dYt16, Xt16, N, K, splits=_SPLITS):
     ws = torch.empty(splits * N * K, device=dYt16.device, dtype=torch.float32)
     _lib.check(lib.se_wgrad_bf16(_lib.ptr(dYt16), _lib.ptr(Xt16), Mp, N, K, splits, _lib.ptr(dW), 0, _lib.ptr(ws), ws.numel() * 4,
                                  _lib.stream()), 'se_wgrad_bf16')
+    return dW
+
+
+def wgrad_tn(dY16, X16, N, K, splits=8):
+    """dW (N, K) fp32 = dY^T X straight from the row-major bf16 operands dY (M, ldy >= N), X (M, ldx >= K)."""
+    lib = _lib.load()
+    M = dY16.shape[0]
+    while splits > 1 and splits * 64 > M:
+        splits //= 2
+    dW = torch.empty(N, K, device=dY16.device, dtype=torch.float32)
+    ws = torch.empty(splits * N * K, device=dY16.device, dtype=torch.float32)
+    _lib.check(lib.se_wgrad_tn_bf16(_lib.ptr(dY16), dY16.shape[1], _lib.ptr(X16), X16.shape[1], M, N, K, splits, _lib.ptr(dW), 0,
+                                    _lib.ptr(ws), ws.numel() * 4, _lib.stream()), 'se_wgrad_tn_bf16')
     return dW
 
 
@@ -143,9 +156,7 @@ class SpecHeadTrainFn(torch.autograd.Function):
         _lib.check(lib.se_layernorm_bwd_f32(_lib.ptr(pre), _lib.ptr(dxn), _lib.ptr(ln_w.contiguous().float()), M, H, ln_eps, 1, _lib.ptr(dpre32),
                                             _lib.ptr(dpre16), _lib.ptr(d_ln_w), _lib.ptr(d_ln_b), 0, _lib.stream()), 'se_layernorm_bwd_f32')
         # dense linear: dWd = dpre^T x, dbd = colsum(dpre)
-        dpret = transpose_bf16(dpre16, Mp)
-        xt = transpose_bf16(x16, Mp)
-        d_dense_w = wgrad(dpret, xt, H, H)
+        d_dense_w = wgrad_tn(dpre16, x16, H, H)
         d_dense_b = colsum(dpre32)
         d_hidden = None
         if ctx.needs_input_grad[0]:

@@ -154,3 +154,22 @@ def test_spechead_train_step_decreases_loss(gpu):
         opt.zero_grad()
         losses.append(loss.item())
     assert losses[-1] < losses[0]
+
+
+@pytest.mark.parametrize('M,N,K,splits', [(5003, 768, 3072, 8), (4100, 2304, 768, 8), (1001, 768, 128, 4), (333, 256, 512, 1), (70, 8, 8, 3)])
+def test_wgrad_tn_vs_fp64(gpu, M, N, K, splits):
+    """weight gradient straight from the row-major operands (tr-read fragments, zero source for the ragged m tail)."""
+    L = _L()
+    lib = L.load()
+    torch.manual_seed(M)
+    ldy, ldx = N + 8, K                      # a padded leading dimension on one side
+    dY = torch.randn(M, ldy, device=gpu).bfloat16()
+    X = torch.randn(M, ldx, device=gpu).bfloat16()
+    dW = torch.full((N, K), float('nan'), device=gpu)
+    ws = torch.empty(splits * N * K, device=gpu)
+    L.check(lib.se_wgrad_tn_bf16(L.ptr(dY), ldy, L.ptr(X), ldx, M, N, K, splits, L.ptr(dW), 0, L.ptr(ws), ws.numel() * 4, L.stream()), 'wgrad_tn')
+    ref = dY[:, :N].double().T @ X.double()
+    assert (dW.double() - ref).abs().max().item() < 2e-5 * ref.abs().max().item() + 1e-4
+    # accumulate form
+    L.check(lib.se_wgrad_tn_bf16(L.ptr(dY), ldy, L.ptr(X), ldx, M, N, K, splits, L.ptr(dW), 1, L.ptr(ws), ws.numel() * 4, L.stream()), 'wgrad_tn')
+    assert (dW.double() - 2 * ref).abs().max().item() < 4e-5 * ref.abs().max().item() + 2e-4

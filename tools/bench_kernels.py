@@ -1,5 +1,5 @@
 """Micro-benchmarks of the individual kernels on the bench shapes (developer tool; run on the GPU box).
-    python tools/bench_kernels.py gemm|mhsa|stft|all
+    python tools/bench_kernels.py gemm|gemmln|mhsa|stft|wgrad|all
 """
 import os
 import sys
@@ -54,6 +54,36 @@ def bench_gemm():
         print(f'gemm M={M} N={N} K={K} act={act} res={res}: {ms*1e3:8.1f} us  {2.0*M*N*K/ms/1e9:8.1f} TF/s  relerr {err:.1e}', flush=True)
 
 
+def bench_wgrad():
+    """weight gradient dW = dY^T X: transposes + split-K forward GEMM (old) vs the TN kernel on row-major operands."""
+    M = 32 * 1001
+    Mp = 32256
+    for (N, K) in [(768, 3072), (3072, 768), (2304, 768), (768, 768), (768, 128)]:
+        dY = torch.randn(M, N, device=dev).bfloat16()
+        X = torch.randn(M, K, device=dev).bfloat16()
+        dW = torch.empty(N, K, device=dev)
+        ws = torch.empty(8 * N * K, device=dev)
+        ta = torch.empty(N, Mp, device=dev, dtype=torch.bfloat16)
+        tb = torch.empty(K, Mp, device=dev, dtype=torch.bfloat16)
+
+        def old():
+            L.check(lib.se_transpose_bf16(L.ptr(dY), M, N, N, L.ptr(ta), Mp, L.stream()), 't')
+            L.check(lib.se_transpose_bf16(L.ptr(X), M, K, K, L.ptr(tb), Mp, L.stream()), 't')
+            L.check(lib.se_wgrad_bf16(L.ptr(ta), L.ptr(tb), Mp, N, K, 8, L.ptr(dW), 0, L.ptr(ws), ws.numel() * 4, L.stream()), 'w')
+        ms_old = timeit(old)
+        ref = dW.clone()
+        line = f'wgrad N={N} K={K}: transposes + split-K gemm2 {ms_old*1e3:8.1f} us ({2.0*M*N*K/ms_old/1e9:6.1f} TF/s)'
+        for splits in (4, 8, 16):
+            ws2 = torch.empty(splits * N * K, device=dev)
+
+            def tn():
+                L.check(lib.se_wgrad_tn_bf16(L.ptr(dY), N, L.ptr(X), K, M, N, K, splits, L.ptr(dW), 0, L.ptr(ws2), ws2.numel() * 4, L.stream()), 'wtn')
+            ms = timeit(tn)
+            err = (dW - ref).abs().max().item() / ref.abs().max().item()
+            line += f' | TN s={splits}: {ms*1e3:7.1f} us ({2.0*M*N*K/ms/1e9:6.1f} TF/s, diff {err:.0e})'
+        print(line, flush=True)
+
+
 def bench_gemm_ln():
     M, N = 32 * 1001, 768
     for K in (768, 3072):
@@ -106,3 +136,5 @@ if __name__ == '__main__':
         bench_mhsa()
     if what in ('stft', 'all'):
         bench_stft()
+    if what in ('wgrad',):
+        bench_wgrad()
