@@ -17,7 +17,7 @@
 namespace {
 
 using se::al256;
-constexpr int kSplits = 16;        // upper bound of the weight-gradient split count (workspace sizing)
+constexpr int kSplits = 32;        // upper bound of the weight-gradient split count (workspace sizing)
 
 struct SavedLayer {
   uint16_t *x0_bf, *qkv, *ctx, *x1_bf, *hpre, *h;
@@ -195,12 +195,12 @@ extern "C" int se_encoder_fwd_train_bf16(const se_encoder* enc, const float* fea
 namespace {
 
 // dW (N, K) = dY^T X from row-major bf16 dY (M, N) [ld ldy] and X (M, K) [ld ldx]; bias gradient by the caller.
-// Split count: the TN kernel's m-splits are pinned to XCDs in groups of 8; more splits fill the chip better but every
-// split costs one fp32 slab (N K 4 bytes written + read back), so the big FFN shapes take 16 and the rest 8.
+// Split count: one 256 x 256 output tile per workgroup and one workgroup per CU (128 KiB of LDS), so the m range is split until
+// tiles x splits just fills the 256 CUs; every split costs one fp32 slab (N K 4 bytes written + read back), hence the cap.
 int weight_grad(const uint16_t* dY, int ldy, const uint16_t* X, int ldx, int M, int N, int K, float* dW, const TrainWs& w, void* stream) {
-  const int tiles = ((N + 255) / 256) * ((K + 127) / 128);
-  int splits = tiles >= 64 ? 16 : 8;
-  while (splits > 1 && (size_t)splits * 64 > (size_t)M) splits >>= 1;
+  const int tiles = ((N + 255) / 256) * ((K + 255) / 256);
+  int splits = std::max(1, std::min(kSplits, 256 / tiles));
+  while (splits > 1 && (size_t)splits * 64 > (size_t)M) --splits;
   return se_wgrad_tn_bf16(dY, ldy, X, ldx, M, N, K, splits, dW, 0, w.partials, (size_t)splits * N * K * sizeof(float), stream);
 }
 

@@ -2,15 +2,20 @@
 //
 // The reduction dim is M = B*T (~32 000 rows), the slow index of both operands, so neither is in the K-contiguous layout
 // the forward GEMM kernels stage.  Instead of transposing both operands through HBM (15 % of a fine-tune step), this kernel
-// stages row-major [64 m][64 col] panels with LDS-DMA and takes the MFMA fragments out of them with the hardware-transposed
+// stages row-major [32 m][64 col] panels with LDS-DMA and takes the MFMA fragments out of them with the hardware-transposed
 // LDS read (ds_read_b64_tr_b16), the way the flash-attention kernels read V^T / Q^T:
-//   tile     : 256 (n) x 128 (k) outputs per 512-thread workgroup, 8 waves as 4 x 2, wave tile 64 x 64 = 2 x 2
-//              v_mfma_f32_32x32x16_bf16 accumulators; 64 rows of m per stage
-//   staging  : global_load_lds_dwordx4 into a 3-deep ring of 48 KiB stages = 4 dY panels + 2 X panels of [64 m][64 col]
-//              bf16 (128-B rows, the kv_off swizzle of mhsa_tile.h: conflict-free for the tr reads); wave w loads rows
-//              8w..8w+7 of every panel; rows past the split's end read a 16-B zero word instead (no tail pass, no padding)
-//   fragments: per 16 rows of m, 2 + 2 fragments = 8 tr reads feed 4 MFMAs; both operands see the same permuted m order
-//   split     : grid.y splits of the m range, each writing its own fp32 slab [N][K]; a slab reduce finishes (deterministic)
+//   tile     : 256 (n) x 256 (k) outputs per 512-thread workgroup, 8 waves as 2 x 4, wave tile 128 x 64 = 4 x 2
+//              v_mfma_f32_32x32x16_bf16 accumulators (128 registers); 32 rows of m per stage
+//   staging  : global_load_lds_dwordx4 into a 4-deep ring of 32 KiB stages = 4 dY panels + 4 X panels of [32 m][64 col]
+//              bf16 (128-B rows, the kv_off swizzle of mhsa_tile.h: conflict-free for the tr reads), two stages in flight
+//              behind the one being multiplied; rows past the split's end read a 16-B zero word instead (no tail pass)
+//   fragments: per 16 rows of m, 4 + 2 fragments = 12 tr reads feed 8 MFMAs.  The b64 transposed read runs at half the LDS
+//              rate of ds_read_b128 (measured: ~8 clk per wave instruction), which makes LDS the limiter of this kernel --
+//              hence the 128 x 64 wave tile (1.5 reads per MFMA; the first 64 x 64 version needed 2 and ran LDS-bound at
+//              575 clk per 16-row step against 512 clk of MFMA work)
+//   split    : the m range is split so that tiles x splits ~ one workgroup per CU; every split writes its own fp32 slab
+//              [N][K] and a slab reduce finishes (deterministic).  Work items are dealt to the XCDs in contiguous ranges
+//              (bijective remap), so the tiles of one split -- which re-read the same dY / X slices -- share an L2.
 #include <stdlib.h>
 #include <algorithm>
 #include "common.h"
@@ -20,11 +25,13 @@
 
 namespace se {
 
-constexpr int kWN = 256, kWK = 128, kWM = 64;
-constexpr int kWPanel = kWM * 64 * 2;                       // 8 KiB
-constexpr int kWStage = (kWN / 64 + kWK / 64) * kWPanel;    // 48 KiB
-constexpr int kWStages = 3;
+constexpr int kWN = 256, kWK = 256, kWM = 32;
+constexpr int kWPanel = kWM * 64 * 2;                       // 4 KiB
+constexpr int kWPanels = kWN / 64 + kWK / 64;               // 8
+constexpr int kWStage = kWPanels * kWPanel;                 // 32 KiB
+constexpr int kWStages = 4;
 constexpr int kWLds = kWStages * kWStage;
+constexpr int kWDma = kWStage / 1024 / 8;                   // DMA instructions per wave per stage (4)
 
 __device__ uint4 g_wgrad_zero = {0u, 0u, 0u, 0u};
 
@@ -34,68 +41,63 @@ typedef const __attribute__((address_space(1))) void* w_glb_ptr_t;
 
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void wgrad_tn_kernel(
     const uint16_t* __restrict__ dY, int ldy, const uint16_t* __restrict__ X, int ldx, int M, int N, int K, int m_per_split,
-    int tiles_k, int splits_total, float* __restrict__ partials) {
+    int tiles_k, int tiles, int work, float* __restrict__ partials, unsigned long long* __restrict__ stamps) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wn = wave >> 1, wk = wave & 1;
+  const int wn = wave >> 2, wk = wave & 3;
   const int l31 = lane & 31, hh = lane >> 5;
-  // XCD-aware work mapping: workgroups are dealt round-robin to the 8 XCDs (linear id % 8), each with its own 4 MB L2.  All
-  // output tiles of ONE m-split re-read the same 64-row slices of dY and X, so a split is pinned to one XCD (split = xcd +
-  // 8 q): its tiles run side by side there and every slice is fetched from HBM once per launch instead of once per tile.
-  int tile, split;
+  // XCD-aware bijective remap: workgroup ids are dealt round-robin to the 8 XCDs; XCD x takes the contiguous range of work
+  // items (split-major) [x W/8, (x+1) W/8), i.e. about one split: its tiles re-read the same slices of dY and X from one L2
+  int id;
   {
-    const int lin = blockIdx.x, tiles = gridDim.x / splits_total;
-    if ((splits_total & 7) == 0) {
-      const int xcd = lin & 7, i = lin >> 3;
-      split = xcd + 8 * (i / tiles);
-      tile = i % tiles;
-    } else {
-      split = lin / tiles;
-      tile = lin - split * tiles;
-    }
+    const int orig = blockIdx.x, xcd = orig & 7, q = work >> 3, r = work & 7;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
   }
+  const int split = id / tiles, tile = id - split * tiles;
   const int tn = tile / tiles_k, tk = tile - tn * tiles_k;
   const int n0 = tn * kWN, k0 = tk * kWK;
   const int m_begin = split * m_per_split, m_end = min(M, m_begin + m_per_split);
   const int nt = m_end > m_begin ? (m_end - m_begin + kWM - 1) / kWM : 0;
 
-  // ---- DMA sources: piece i of this wave = rows 8 wave .. +7 of panel i; lane -> row, LDS slot lane & 7 holds logical
-  //      16-B chunk (lane & 7) ^ f(row) (the swizzle is applied on the source side: the DMA destination is lane-linear)
-  const int row = 8 * wave + (lane >> 3);
+  // ---- DMA sources: piece i of this wave = rows 8 rg .. +7 of panel 2 i + (wave >> 2), rg = wave & 3; lane -> row, LDS slot
+  //      lane & 7 holds logical 16-B chunk (lane & 7) ^ f(row) (swizzle on the source side: the DMA destination is lane-linear)
+  const int row = 8 * (wave & 3) + (lane >> 3);
   const int f = (((row >> 1) & 1) << 2) | ((row >> 2) & 3);
   const int col8 = ((lane & 7) ^ f) * 8;
-  const uint16_t* src[6];
-  int ld[6];
-  bool col_ok[6];
+  const uint16_t* src[kWDma];
+  int ld[kWDma];
+  bool col_ok[kWDma];
 #pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    if (i < 4) {
-      const int c = n0 + 64 * i + col8;
+  for (int i = 0; i < kWDma; ++i) {
+    const int panel = 2 * i + (wave >> 2);
+    if (panel < 4) {
+      const int c = n0 + 64 * panel + col8;
       col_ok[i] = c < N;
       src[i] = dY + (col_ok[i] ? c : 0);
       ld[i] = ldy;
     } else {
-      const int c = k0 + 64 * (i - 4) + col8;
+      const int c = k0 + 64 * (panel - 4) + col8;
       col_ok[i] = c < K;
       src[i] = X + (col_ok[i] ? c : 0);
       ld[i] = ldx;
     }
   }
   const uint16_t* zero = reinterpret_cast<const uint16_t*>(&g_wgrad_zero);
+  const int piece_off = (wave >> 2) * kWPanel + (wave & 3) * 1024;
 #define SEW_ISSUE(t, st)                                                                                        \
   do {                                                                                                          \
     const int m = m_begin + (t) * kWM + row;                                                                    \
-    char* sb = smem + (st) * kWStage + wave * 1024;                                                             \
-    _Pragma("unroll") for (int i = 0; i < 6; ++i) {                                                             \
+    char* sb = smem + (st) * kWStage + piece_off;                                                               \
+    _Pragma("unroll") for (int i = 0; i < kWDma; ++i) {                                                         \
       const uint16_t* p = (m < m_end && col_ok[i]) ? src[i] + (size_t)m * ld[i] : zero;                         \
-      __builtin_amdgcn_global_load_lds((w_glb_ptr_t)p, (w_lds_ptr_t)(sb + i * kWPanel), 16, 0, 0);              \
+      __builtin_amdgcn_global_load_lds((w_glb_ptr_t)p, (w_lds_ptr_t)(sb + 2 * i * kWPanel), 16, 0, 0);          \
     }                                                                                                           \
   } while (0)
 
-  f32x16 acc[2][2];
+  f32x16 acc[4][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -110,51 +112,75 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     toff[blk][0] = kv_off(4 * hh + tq, dcol >> 3) + (dcol & 7) * 2;
     toff[blk][1] = kv_off(4 * hh + tq + 8, dcol >> 3) + (dcol & 7) * 2;
   }
-  const int a_base = wn * kWPanel, b_base = (4 + wk) * kWPanel;
+  const int a_base = 2 * wn * kWPanel, b_base = (4 + wk) * kWPanel;     // this wave's 2 dY panels (128 n) and its X panel (64 k)
 
+  // developer stamps (SE_AMD_WGRAD_STAMPS=1): lane 0 of every wave of workgroups 0..7 appends s_memtime values
+  const bool st_on = stamps && lane == 0 && blockIdx.x < 8;
+  unsigned long long* st_buf = stamps + ((size_t)blockIdx.x * 8 + wave) * 256;
+  int st_i = 0;
+#define SEW_STAMP()                                                        \
+  do {                                                                     \
+    if (st_on && st_i < 256) st_buf[st_i++] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+  SEW_STAMP();
   if (nt > 0) SEW_ISSUE(0, 0);
   if (nt > 1) SEW_ISSUE(1, 1);
+  if (nt > 2) SEW_ISSUE(2, 2);
   int st = 0;
   for (int t = 0; t < nt; ++t) {
-    if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // this wave's pieces of tile t landed; t+1 stays in flight
+    SEW_STAMP();
+    // this wave's pieces of tile t landed; tiles t+1, t+2 stay in flight
+    if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SEW_STAMP();
     __builtin_amdgcn_s_barrier();        // everyone's pieces landed AND everyone finished the stage refilled below
-    if (t + 2 < nt) {
-      const int st2 = (st + 2 >= kWStages) ? st + 2 - kWStages : st + 2;
-      SEW_ISSUE(t + 2, st2);
-    }
+    SEW_STAMP();
     const char* sb = smem + st * kWStage;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      bf16x8 af[2], bfr[2];
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 af[4], bfr[2];
 #pragma unroll
-      for (int blk = 0; blk < 2; ++blk) {
-        const bf16x4 alo = SE_WTR(sb + a_base + toff[blk][0] + s * 2048);
-        const bf16x4 ahi = SE_WTR(sb + a_base + toff[blk][1] + s * 2048);
-        const bf16x4 blo = SE_WTR(sb + b_base + toff[blk][0] + s * 2048);
-        const bf16x4 bhi = SE_WTR(sb + b_base + toff[blk][1] + s * 2048);
-        af[blk] = (bf16x8){alo[0], alo[1], alo[2], alo[3], ahi[0], ahi[1], ahi[2], ahi[3]};
-        bfr[blk] = (bf16x8){blo[0], blo[1], blo[2], blo[3], bhi[0], bhi[1], bhi[2], bhi[3]};
+      for (int blk = 0; blk < 4; ++blk) {
+        const int off = a_base + (blk >> 1) * kWPanel + s * 2048;
+        const bf16x4 lo = SE_WTR(sb + off + toff[blk & 1][0]);
+        const bf16x4 hi = SE_WTR(sb + off + toff[blk & 1][1]);
+        af[blk] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
       }
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int blk = 0; blk < 2; ++blk) {
+        const bf16x4 lo = SE_WTR(sb + b_base + s * 2048 + toff[blk][0]);
+        const bf16x4 hi = SE_WTR(sb + b_base + s * 2048 + toff[blk][1]);
+        bfr[blk] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+      if (s == 0) {
+        // refill the slot of stage t-1 (free since the barrier above).  Issued here, behind the first step's fragment reads:
+        // every global_load_lds stalls the issuing wave ~110 clk, which now overlaps the LDS pipe serving those reads
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 3 < nt) SEW_ISSUE(t + 3, (st + 3) & 3);
+        __builtin_amdgcn_sched_barrier(0);
+        SEW_STAMP();
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
-    st = (st + 1 == kWStages) ? 0 : st + 1;
+    st = (st + 1) & 3;
   }
+  SEW_STAMP();
 #undef SEW_ISSUE
 
-  // ---- epilogue: acc[i][j][r] = dW[n0 + 64 wn + 32 i + (r&3) + 8 (r>>2) + 4 hh][k0 + 64 wk + 32 j + l31]
+  // ---- epilogue: acc[i][j][r] = dW[n0 + 128 wn + 32 i + (r&3) + 8 (r>>2) + 4 hh][k0 + 64 wk + 32 j + l31]
   float* out = partials + (size_t)split * N * K;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int kc = k0 + 64 * wk + 32 * j + l31;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int n = n0 + 64 * wn + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        const int n = n0 + 128 * wn + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * hh;
         if (n < N && kc < K) out[(size_t)n * K + kc] = acc[i][j][r];
       }
     }
@@ -193,11 +219,22 @@ extern "C" int se_wgrad_tn_bf16(const uint16_t* dY, int ldy, const uint16_t* X, 
   const int tiles_n = (N + se::kWN - 1) / se::kWN, tiles_k = (K + se::kWK - 1) / se::kWK;
   const int tiles_m = (M + se::kWM - 1) / se::kWM;
   const int m_per_split = (tiles_m + splits - 1) / splits * se::kWM;
+  const int tiles = tiles_n * tiles_k, work = tiles * splits;
   float* partials = reinterpret_cast<float*>(workspace);
+  static int stamp_env = -1;
+  if (stamp_env < 0) {
+    const char* e = getenv("SE_AMD_WGRAD_STAMPS");       // developer switch: the 128 KiB after the slabs receive cycle stamps
+    stamp_env = e ? atoi(e) : 0;
+  }
+  unsigned long long* stamps = nullptr;
+  if (stamp_env) {
+    SE_REQUIRE(workspace_bytes >= (size_t)splits * N * K * sizeof(float) + 8 * 8 * 256 * 8, "se_wgrad_tn_bf16: stamp build needs 128 KiB more workspace");
+    stamps = reinterpret_cast<unsigned long long*>(partials + (size_t)splits * N * K);
+  }
   {
     se::ProfScope prof(se::kProfGemm, 2.0 * M * (double)N * K, st);
-    hipLaunchKernelGGL(se::wgrad_tn_kernel, dim3(tiles_n * tiles_k * splits), dim3(512), se::kWLds, st, dY, ldy, X, ldx, M, N, K, m_per_split,
-                       tiles_k, splits, partials);
+    hipLaunchKernelGGL(se::wgrad_tn_kernel, dim3(work), dim3(512), se::kWLds, st, dY, ldy, X, ldx, M, N, K, m_per_split, tiles_k, tiles, work,
+                       partials, stamps);
     SE_LAUNCH_CHECK();
   }
   const size_t n4 = (size_t)N * K / 4;

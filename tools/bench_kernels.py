@@ -73,7 +73,7 @@ def bench_wgrad():
         ms_old = timeit(old)
         ref = dW.clone()
         line = f'wgrad N={N} K={K}: transposes + split-K gemm2 {ms_old*1e3:8.1f} us ({2.0*M*N*K/ms_old/1e9:6.1f} TF/s)'
-        for splits in (4, 8, 16):
+        for splits in sorted({max(1, min(32, 256 // (((N + 255) // 256) * ((K + 255) // 256)))), 8, 16}):
             ws2 = torch.empty(splits * N * K, device=dev)
 
             def tn():
