@@ -275,13 +275,16 @@ int se_spec_epilogue_bwd_f32(const float* p, const float* d_pred, const float* d
 /* ------------------------------------------------------------------------------------------------
  * Training path of the encoder (rows B1-B3 under autograd; C4 `Mockingjay` fine-tune and E2: model.py:163-171,
  * runner.py:453-471).  Replaces what torch autograd records / replays through TRANSFORMER.forward.
- * Dropout is not applied.  hidden_size must be 768 (256 is also built, for small-size parity tests).
+ * hidden_size must be 768 (256 is also built, for small-size parity tests).
  * ---------------------------------------------------------------------------------------------- */
-/* flash MHSA forward that also stores the per-(utterance, head, query) log-sum-exp (log2 domain), (B, heads, T) fp32 */
-int se_mhsa_fwd_lse_bf16(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, float* lse, void* stream);
+/* flash MHSA forward that also stores the per-(utterance, head, query) log-sum-exp (log2 domain), (B, heads, T) fp32.
+ * dropout_p > 0 drops the attention probabilities (attention_probs_dropout_prob, pretrain_sample.yaml:10) with the
+ * counter-based mask of (seed, site) -- csrc/dropout.h; the backward regenerates it from the same three values. */
+int se_mhsa_fwd_lse_bf16(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, float* lse,
+                         float dropout_p, uint64_t seed, uint32_t site, void* stream);
 /* flash MHSA backward: d_ctx (B*T, H) bf16 -> dqkv (B*T, 3H) bf16 = [dQ | dK | dV]; dvec (B, heads, T) fp32 scratch */
 int se_mhsa_bwd_bf16(const uint16_t* qkv, const uint16_t* ctx, const uint16_t* d_ctx, const float* lse, const int32_t* lengths,
-                     int B, int T, int heads, uint16_t* dqkv, float* dvec, void* stream);
+                     int B, int T, int heads, uint16_t* dqkv, float* dvec, float dropout_p, uint64_t seed, uint32_t site, void* stream);
 /* y = gelu(x) and dx = dy * gelu'(x), bf16 arrays of n elements (n % 8 == 0) */
 int se_gelu_bf16(const uint16_t* x, size_t n, uint16_t* y, void* stream);
 int se_gelu_bwd_bf16(const uint16_t* dy, const uint16_t* x, size_t n, uint16_t* dx, void* stream);
@@ -299,12 +302,17 @@ typedef struct se_encoder_grads {
 int se_encoder_refresh_bf16(se_encoder* enc, const se_encoder_weights* w, void* stream);
 size_t se_encoder_saved_bytes(const se_encoder* enc, int B, int T);
 size_t se_encoder_train_workspace_bytes(const se_encoder* enc, int B, int T);
-/* forward that keeps the activations the backward needs in `saved` (caller-owned, se_encoder_saved_bytes) */
+/* forward that keeps the activations the backward needs in `saved` (caller-owned, se_encoder_saved_bytes).
+ * dropout_p > 0: training mode with BERT's dropout sites (after the input LayerNorm, attention probabilities, after the
+ * attention-output and FFN-output dense; hidden_dropout_prob = attention_probs_dropout_prob = dropout_p) and counter-based
+ * masks from `seed` (csrc/dropout.h) -- nothing is stored, the backward regenerates them from the same (dropout_p, seed). */
 int se_encoder_fwd_train_bf16(const se_encoder* enc, const float* feats, const int32_t* lengths, int B, int T, float* hidden,
-                              void* saved, size_t saved_bytes, void* workspace, size_t workspace_bytes, void* stream);
+                              void* saved, size_t saved_bytes, void* workspace, size_t workspace_bytes, float dropout_p, uint64_t seed,
+                              void* stream);
 /* backward: d_hidden (B, T, H) fp32 -> every parameter gradient (overwritten, not accumulated) */
 int se_encoder_bwd_bf16(const se_encoder* enc, const int32_t* lengths, int B, int T, const float* d_hidden, const void* saved,
-                        size_t saved_bytes, const se_encoder_grads* grads, void* workspace, size_t workspace_bytes, void* stream);
+                        size_t saved_bytes, const se_encoder_grads* grads, void* workspace, size_t workspace_bytes, float dropout_p,
+                        uint64_t seed, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Optimizer side of row E2 (runner.py:463-471): gradient norms and BertAdam for all parameter tensors in two launches.

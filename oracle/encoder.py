@@ -98,8 +98,48 @@ def init_weights(cfg, inp_dim, seed=0, spec_out=None, dtype=torch.float32):
     return sd, head
 
 
-def encoder_forward(feats, sd, cfg, lengths=None, all_layers=False):
-    """B1-B3: feats (B, T, D) fp32 -> last hidden (B, T, H)  (select_layer -1, eval mode: no dropout).
+def _lowbias32(x):
+    """the 32-bit mixer of csrc/dropout.h on int64 tensors holding uint32 values"""
+    M = 0xffffffff
+    x = x & M
+    x = x ^ (x >> 16)
+    x = (x * 0x7feb352d) & M
+    x = x ^ (x >> 15)
+    x = (x * 0x846ca68b) & M
+    x = x ^ (x >> 16)
+    return x
+
+
+def dropout_key(seed, site):
+    M = 0xffffffff
+    v = ((seed & M) * 0x9E3779B9 + ((seed >> 32) & M) * 0x85EBCA6B + site) & M
+    k = int(_lowbias32(torch.tensor([v], dtype=torch.int64))[0])
+    return k if k else 1
+
+
+def keep_mask(seed, site, rows, cols, p, pairs_per_row=None):
+    """Dropout keep-mask of a (rows, cols) site, bit for bit what csrc/dropout.h generates: one 32-bit hash per element
+    pair (pair index = row * pairs_per_row + col // 2, pairs_per_row = ceil(cols / 2)), 16 bits per element, keep iff
+    bits >= round(p * 65536).  Returns a bool tensor (rows, cols)."""
+    ppr = (cols + 1) // 2 if pairs_per_row is None else pairs_per_row
+    thr = int(p * 65536.0 + 0.5)
+    key = dropout_key(seed, site)
+    r = torch.arange(rows, dtype=torch.int64)[:, None]
+    c = torch.arange(cols, dtype=torch.int64)[None, :]
+    pair = (r * ppr + (c >> 1)) & 0xffffffff
+    bits = _lowbias32(pair ^ key)
+    v = torch.where((c & 1) == 1, bits >> 16, bits & 0xffff)
+    return v >= thr
+
+
+def dropout_site(layer, which):
+    return 4 * layer + which
+
+
+def encoder_forward(feats, sd, cfg, lengths=None, all_layers=False, dropout_p=0.0, seed=0):
+    """B1-B3: feats (B, T, D) fp32 -> last hidden (B, T, H)  (select_layer -1).  dropout_p = 0: eval mode.
+    dropout_p > 0: training mode with the BERT dropout sites (after the input LayerNorm, attention probabilities, after the
+    attention-output and FFN-output dense) and the counter-based masks of keep_mask(seed, site, ...).
     Attention mask: additive (1-mask)*-10000 on key positions >= valid length."""
     B, T, _ = feats.shape
     H, nh = cfg.hidden_size, cfg.num_attention_heads
@@ -111,6 +151,14 @@ def encoder_forward(feats, sd, cfg, lengths=None, all_layers=False):
     x = F.linear(feats, sd['input_representations.spec_transform.weight'], sd['input_representations.spec_transform.bias'])
     x = x + position_encoding(T, H, feats.dtype)[None]
     x = layer_norm(x, sd['input_representations.LayerNorm.weight'], sd['input_representations.LayerNorm.bias'], cfg.layer_norm_eps)
+    drop = dropout_p > 0
+    scale = 1.0 / (1.0 - dropout_p) if drop else 1.0
+
+    def hidden_drop(t, site):          # t (B, T, H): element index = (b T + t) H + col
+        m = keep_mask(seed, site, B * T, H, dropout_p).reshape(B, T, H)
+        return t * m.to(t.dtype) * scale
+    if drop:
+        x = hidden_drop(x, dropout_site(cfg.num_hidden_layers, 0))
     outs = []
     for i in range(cfg.num_hidden_layers):
         p = f'encoder.layer.{i}.'
@@ -122,11 +170,18 @@ def encoder_forward(feats, sd, cfg, lengths=None, all_layers=False):
         v = v.view(B, T, nh, dh).permute(0, 2, 1, 3)
         scores = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(dh) + ext
         probs = torch.softmax(scores, dim=-1)
+        if drop:                       # row id = (b heads + head) T + q, pair = row_id * ceil(T/2) + key // 2
+            m = keep_mask(seed, dropout_site(i, 0), B * nh * T, T, dropout_p).reshape(B, nh, T, T)
+            probs = probs * m.to(probs.dtype) * scale
         ctx = torch.matmul(probs, v).permute(0, 2, 1, 3).reshape(B, T, H)
         a = F.linear(ctx, sd[p + 'attention.output.dense.weight'], sd[p + 'attention.output.dense.bias'])
+        if drop:
+            a = hidden_drop(a, dropout_site(i, 1))
         x = layer_norm(a + x, sd[p + 'attention.output.LayerNorm.weight'], sd[p + 'attention.output.LayerNorm.bias'], cfg.layer_norm_eps)
         h = gelu(F.linear(x, sd[p + 'intermediate.dense.weight'], sd[p + 'intermediate.dense.bias']))
         o = F.linear(h, sd[p + 'output.dense.weight'], sd[p + 'output.dense.bias'])
+        if drop:
+            o = hidden_drop(o, dropout_site(i, 2))
         x = layer_norm(o + x, sd[p + 'output.LayerNorm.weight'], sd[p + 'output.LayerNorm.bias'], cfg.layer_norm_eps)
         outs.append(x)
     return outs if all_layers else x

@@ -87,15 +87,15 @@ SIGNATURES = {
     'se_gelu_layernorm_f32': (c_int, [_P, _P, _P, c_int, c_int, c_float, _P, _P, _P]),
     'se_spec_epilogue_f32': (c_int, [_P, c_size_t, c_int, c_int, c_float, _P, _P, _P]),
     'se_spec_epilogue_bwd_f32': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_float, _P, _P, _P]),
-    'se_mhsa_fwd_lse_bf16': (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P]),
-    'se_mhsa_bwd_bf16': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P]),
+    'se_mhsa_fwd_lse_bf16': (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, c_float, ctypes.c_uint64, ctypes.c_uint32, _P]),
+    'se_mhsa_bwd_bf16': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, c_float, ctypes.c_uint64, ctypes.c_uint32, _P]),
     'se_gelu_bf16': (c_int, [_P, c_size_t, _P, _P]),
     'se_gelu_bwd_bf16': (c_int, [_P, _P, c_size_t, _P, _P]),
     'se_encoder_refresh_bf16': (c_int, [_P, POINTER(EncoderWeights), _P]),
     'se_encoder_saved_bytes': (c_size_t, [_P, c_int, c_int]),
     'se_encoder_train_workspace_bytes': (c_size_t, [_P, c_int, c_int]),
-    'se_encoder_fwd_train_bf16': (c_int, [_P, _P, _P, c_int, c_int, _P, _P, c_size_t, _P, c_size_t, _P]),
-    'se_encoder_bwd_bf16': (c_int, [_P, _P, c_int, c_int, _P, _P, c_size_t, POINTER(EncoderGrads), _P, c_size_t, _P]),
+    'se_encoder_fwd_train_bf16': (c_int, [_P, _P, _P, c_int, c_int, _P, _P, c_size_t, _P, c_size_t, c_float, ctypes.c_uint64, _P]),
+    'se_encoder_bwd_bf16': (c_int, [_P, _P, c_int, c_int, _P, _P, c_size_t, POINTER(EncoderGrads), _P, c_size_t, c_float, ctypes.c_uint64, _P]),
     'se_multi_sumsq_f32': (c_int, [_P, _P, c_int, _P, _P]),
     'se_bertadam_step_f32': (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, c_double, c_double, c_double, c_double, c_double, c_double, _P]),
     'se_prof_enable': (c_int, [c_int]),

@@ -10,6 +10,7 @@
 #include "common.h"
 #include "bf16.h"
 #include "encoder_impl.h"
+#include "dropout.h"
 
 extern "C" int se_gemm2_splitk_launch(const uint16_t* A, int lda, const uint16_t* W, int ldw, int M, int N, int Kc, int splits,
                                       float* partials, void* stream);
@@ -204,7 +205,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             const float* __restrict__ dy,
                                                             const float* __restrict__ w, int M, float eps, float* __restrict__ dx,
                                                             uint16_t* __restrict__ dx_bf16, float* __restrict__ dgamma,
-                                                            float* __restrict__ dbeta, float* __restrict__ dbias, int rows_per_wave) {
+                                                            float* __restrict__ dbeta, float* __restrict__ dbias, int rows_per_wave,
+                                                            uint32_t key_dy, uint32_t key_dx, uint32_t thr16, float dscale) {
   constexpr int H = 256 * NV;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   float4 gsum[NV], bsum[NV], xsum[NV];     // column sums of dy xhat (dgamma), dy (dbeta), dx (bias gradient of the producing linear)
@@ -220,6 +222,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     for (int i = 0; i < NV; ++i) {
       pre[i] = *reinterpret_cast<const float4*>(x_in + (size_t)row * H + (i * 64 + lane) * 4);
       g[i] = *reinterpret_cast<const float4*>(dy + (size_t)row * H + (i * 64 + lane) * 4);
+      if (key_dy) {           // the forward dropped this LayerNorm's OUTPUT (input stage): mask the incoming gradient
+        const uint32_t pr = (uint32_t)row * (H / 2) + (uint32_t)(i * 64 + lane) * 2;
+        const uint32_t b0 = dropout_bits(key_dy, pr), b1 = dropout_bits(key_dy, pr + 1);
+        g[i].x *= dropout_mul(b0, 0, thr16, dscale); g[i].y *= dropout_mul(b0, 1, thr16, dscale);
+        g[i].z *= dropout_mul(b1, 0, thr16, dscale); g[i].w *= dropout_mul(b1, 1, thr16, dscale);
+      }
       if (pe) {               // input stage: LayerNorm(x W^T + b + positional encoding)
         const float4 pp = *reinterpret_cast<const float4*>(pe + (size_t)(row % T) * H + (i * 64 + lane) * 4);
         pre[i].x += pp.x; pre[i].y += pp.y; pre[i].z += pp.z; pre[i].w += pp.w;
@@ -264,8 +272,14 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
       d.z = rstd * (g[i].z - a - v[i].z * bq); d.w = rstd * (g[i].w - a - v[i].w * bq);
       if (GELU_IN) { d.x *= gelu_grad(pre[i].x); d.y *= gelu_grad(pre[i].y); d.z *= gelu_grad(pre[i].z); d.w *= gelu_grad(pre[i].w); }
       const size_t o = (size_t)row * H + (i * 64 + lane) * 4;
+      if (dx) *reinterpret_cast<float4*>(dx + o) = d;           // residual branch: unmasked
+      if (key_dx) {           // the forward dropped the producing linear's output before the residual add: its gradient is masked
+        const uint32_t pr = (uint32_t)row * (H / 2) + (uint32_t)(i * 64 + lane) * 2;
+        const uint32_t b0 = dropout_bits(key_dx, pr), b1 = dropout_bits(key_dx, pr + 1);
+        d.x *= dropout_mul(b0, 0, thr16, dscale); d.y *= dropout_mul(b0, 1, thr16, dscale);
+        d.z *= dropout_mul(b1, 0, thr16, dscale); d.w *= dropout_mul(b1, 1, thr16, dscale);
+      }
       xsum[i].x += d.x; xsum[i].y += d.y; xsum[i].z += d.z; xsum[i].w += d.w;
-      if (dx) *reinterpret_cast<float4*>(dx + o) = d;
       if (dx_bf16) *reinterpret_cast<uint2*>(dx_bf16 + o) = make_uint2(pack_bf16x2(d.x, d.y), pack_bf16x2(d.z, d.w));
     }
   }
@@ -339,7 +353,8 @@ extern "C" int se_colsum_f32(const float* x, int rows, int cols, int ld, float* 
 }
 
 int se::launch_layernorm_bwd(const float* x_in, const float* pe, int T, const float* dy, const float* w, int M, int H, float eps, int gelu_in,
-                             float* dx, uint16_t* dx_bf16, float* dgamma, float* dbeta, float* dbias, int accumulate, hipStream_t st) {
+                             float* dx, uint16_t* dx_bf16, float* dgamma, float* dbeta, float* dbias, int accumulate, hipStream_t st,
+                             uint32_t key_dy, uint32_t key_dx, uint32_t thr16, float dscale) {
   SE_REQUIRE(H == 768 || H == 256, "layernorm backward: only H = 768 / 256 are built (got %d)", H);
   if (!accumulate) {
     if (dgamma) SE_HIP(hipMemsetAsync(dgamma, 0, sizeof(float) * H, st));
@@ -350,14 +365,14 @@ int se::launch_layernorm_bwd(const float* x_in, const float* pe, int T, const fl
   const int grid = (M + 4 * rows_per_wave - 1) / (4 * rows_per_wave);
   if (H == 768) {
     if (gelu_in)
-      hipLaunchKernelGGL((se::layernorm_bwd_kernel<3, 1>), dim3(grid), dim3(256), 0, st, x_in, pe, T, dy, w, M, eps, dx, dx_bf16, dgamma, dbeta, dbias, rows_per_wave);
+      hipLaunchKernelGGL((se::layernorm_bwd_kernel<3, 1>), dim3(grid), dim3(256), 0, st, x_in, pe, T, dy, w, M, eps, dx, dx_bf16, dgamma, dbeta, dbias, rows_per_wave, key_dy, key_dx, thr16, dscale);
     else
-      hipLaunchKernelGGL((se::layernorm_bwd_kernel<3, 0>), dim3(grid), dim3(256), 0, st, x_in, pe, T, dy, w, M, eps, dx, dx_bf16, dgamma, dbeta, dbias, rows_per_wave);
+      hipLaunchKernelGGL((se::layernorm_bwd_kernel<3, 0>), dim3(grid), dim3(256), 0, st, x_in, pe, T, dy, w, M, eps, dx, dx_bf16, dgamma, dbeta, dbias, rows_per_wave, key_dy, key_dx, thr16, dscale);
   } else {
     if (gelu_in)
-      hipLaunchKernelGGL((se::layernorm_bwd_kernel<1, 1>), dim3(grid), dim3(256), 0, st, x_in, pe, T, dy, w, M, eps, dx, dx_bf16, dgamma, dbeta, dbias, rows_per_wave);
+      hipLaunchKernelGGL((se::layernorm_bwd_kernel<1, 1>), dim3(grid), dim3(256), 0, st, x_in, pe, T, dy, w, M, eps, dx, dx_bf16, dgamma, dbeta, dbias, rows_per_wave, key_dy, key_dx, thr16, dscale);
     else
-      hipLaunchKernelGGL((se::layernorm_bwd_kernel<1, 0>), dim3(grid), dim3(256), 0, st, x_in, pe, T, dy, w, M, eps, dx, dx_bf16, dgamma, dbeta, dbias, rows_per_wave);
+      hipLaunchKernelGGL((se::layernorm_bwd_kernel<1, 0>), dim3(grid), dim3(256), 0, st, x_in, pe, T, dy, w, M, eps, dx, dx_bf16, dgamma, dbeta, dbias, rows_per_wave, key_dy, key_dx, thr16, dscale);
   }
   SE_LAUNCH_CHECK();
   return SE_OK;

@@ -13,8 +13,93 @@
 #include <algorithm>
 #include "common.h"
 #include "encoder_impl.h"
+#include "bf16.h"
+#include "dropout.h"
+
+namespace se {
+
+// Training-forward LayerNorm with the BERT dropout sites around it (one wave per row, H = 256 NV):
+//   v = x (+ positional table) ; key_in: v = dropout(v) ; + residual ; [pre_out = v] ; y = LN(v) ; key_out: y = dropout(y)
+// key_in is the dropout of a projection output before the residual add (attention-output / FFN-output dense), key_out the
+// dropout after the input LayerNorm.  `residual` and `out_f32` may alias (row-local).
+template <int NV>
+__global__ __launch_bounds__(256) void ln_train_kernel(const float* __restrict__ x, const float* __restrict__ pe, int T, const float* residual,
+                                                       const float* __restrict__ w, const float* __restrict__ b, int M, float eps,
+                                                       float* __restrict__ pre_out, float* out_f32, uint16_t* __restrict__ out_bf16,
+                                                       uint32_t key_in, uint32_t key_out, uint32_t thr16, float dscale) {
+  constexpr int H = 256 * NV;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  float4 v[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    v[i] = *reinterpret_cast<const float4*>(x + (size_t)row * H + c);
+    if (pe) {
+      const float4 p = *reinterpret_cast<const float4*>(pe + (size_t)(row % T) * H + c);
+      v[i].x += p.x; v[i].y += p.y; v[i].z += p.z; v[i].w += p.w;
+    }
+    if (key_in) {
+      const uint32_t pr = (uint32_t)row * (H / 2) + (uint32_t)(c >> 1);
+      const uint32_t b0 = dropout_bits(key_in, pr), b1 = dropout_bits(key_in, pr + 1);
+      v[i].x *= dropout_mul(b0, 0, thr16, dscale); v[i].y *= dropout_mul(b0, 1, thr16, dscale);
+      v[i].z *= dropout_mul(b1, 0, thr16, dscale); v[i].w *= dropout_mul(b1, 1, thr16, dscale);
+    }
+    if (residual) {
+      const float4 r = *reinterpret_cast<const float4*>(residual + (size_t)row * H + c);
+      v[i].x += r.x; v[i].y += r.y; v[i].z += r.z; v[i].w += r.w;
+    }
+    if (pre_out) *reinterpret_cast<float4*>(pre_out + (size_t)row * H + c) = v[i];
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  const float mean = s * (1.0f / H);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+    q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off);
+  const float rstd = 1.0f / sqrtf(q * (1.0f / H) + eps);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    const float4 ww = *reinterpret_cast<const float4*>(w + c), bb = *reinterpret_cast<const float4*>(b + c);
+    float4 y;
+    y.x = ww.x * (v[i].x * rstd) + bb.x; y.y = ww.y * (v[i].y * rstd) + bb.y;
+    y.z = ww.z * (v[i].z * rstd) + bb.z; y.w = ww.w * (v[i].w * rstd) + bb.w;
+    if (key_out) {
+      const uint32_t pr = (uint32_t)row * (H / 2) + (uint32_t)(c >> 1);
+      const uint32_t b0 = dropout_bits(key_out, pr), b1 = dropout_bits(key_out, pr + 1);
+      y.x *= dropout_mul(b0, 0, thr16, dscale); y.y *= dropout_mul(b0, 1, thr16, dscale);
+      y.z *= dropout_mul(b1, 0, thr16, dscale); y.w *= dropout_mul(b1, 1, thr16, dscale);
+    }
+    if (out_f32) *reinterpret_cast<float4*>(out_f32 + (size_t)row * H + c) = y;
+    if (out_bf16) *reinterpret_cast<uint2*>(out_bf16 + (size_t)row * H + c) = make_uint2(pack_bf16x2(y.x, y.y), pack_bf16x2(y.z, y.w));
+  }
+}
+
+}  // namespace se
 
 namespace {
+
+int launch_ln_train(const float* x, const float* pe, int T, const float* residual, const float* w, const float* b, int M, int H, float eps,
+                    float* pre_out, float* out_f32, uint16_t* out_bf16, uint32_t key_in, uint32_t key_out, const se::DropoutCfg& d, hipStream_t st) {
+  if (H == 768)
+    hipLaunchKernelGGL((se::ln_train_kernel<3>), dim3((M + 3) / 4), dim3(256), 0, st, x, pe, T, residual, w, b, M, eps, pre_out, out_f32, out_bf16,
+                       key_in, key_out, d.thr16, d.scale);
+  else
+    hipLaunchKernelGGL((se::ln_train_kernel<1>), dim3((M + 3) / 4), dim3(256), 0, st, x, pe, T, residual, w, b, M, eps, pre_out, out_f32, out_bf16,
+                       key_in, key_out, d.thr16, d.scale);
+  SE_LAUNCH_CHECK();
+  return SE_OK;
+}
 
 using se::al256;
 constexpr int kSplits = 32;        // upper bound of the weight-gradient split count (workspace sizing)
@@ -142,7 +227,7 @@ extern "C" size_t se_encoder_saved_bytes(const se_encoder* enc, int B, int T) {
 
 extern "C" size_t se_encoder_train_workspace_bytes(const se_encoder* enc, int B, int T) {
   if (!enc || B <= 0 || T <= 0) return 0;
-  return std::max(carve_ws(enc, B, T, nullptr).total, (size_t)B * T * enc->cfg.hidden * 4) + 256;
+  return std::max(carve_ws(enc, B, T, nullptr).total, 2 * al256((size_t)B * T * enc->cfg.hidden * 4)) + 256;
 }
 
 static int check_train_shape(const se_encoder* enc, int B, int T, const char* who) {
@@ -156,11 +241,13 @@ static int check_train_shape(const se_encoder* enc, int B, int T, const char* wh
 }
 
 extern "C" int se_encoder_fwd_train_bf16(const se_encoder* enc, const float* feats, const int32_t* lengths, int B, int T, float* hidden,
-                                         void* saved, size_t saved_bytes, void* workspace, size_t workspace_bytes, void* stream) {
+                                         void* saved, size_t saved_bytes, void* workspace, size_t workspace_bytes, float dropout_p,
+                                         uint64_t seed, void* stream) {
   SE_REQUIRE(enc && feats && hidden && saved && workspace, "se_encoder_fwd_train_bf16: null argument");
   SE_TRY(check_train_shape(enc, B, T, "se_encoder_fwd_train_bf16"));
   SE_REQUIRE(saved_bytes >= se_encoder_saved_bytes(enc, B, T), "se_encoder_fwd_train_bf16: saved buffer too small");
-  SE_REQUIRE(workspace_bytes >= (size_t)B * T * enc->cfg.hidden * 4, "se_encoder_fwd_train_bf16: workspace too small");
+  SE_REQUIRE(workspace_bytes >= 2 * al256((size_t)B * T * enc->cfg.hidden * 4), "se_encoder_fwd_train_bf16: workspace too small");
+  SE_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "se_encoder_fwd_train_bf16: dropout_p must be in [0, 1)");
   SE_REQUIRE(((uintptr_t)saved % 256 == 0) && ((uintptr_t)workspace % 256 == 0) && ((uintptr_t)hidden % 16 == 0),
              "se_encoder_fwd_train_bf16: buffers must be 256-B aligned");
   const int H = enc->cfg.hidden, I = enc->cfg.intermediate, D = enc->cfg.input_dim, L = enc->cfg.layers;
@@ -169,25 +256,45 @@ extern "C" int se_encoder_fwd_train_bf16(const se_encoder* enc, const float* fea
   hipStream_t st = se::as_stream(stream);
   Saved s = carve_saved(enc, B, T, reinterpret_cast<char*>(saved));
   float* x_f32 = reinterpret_cast<float*>(workspace);          // running residual stream (LayerNorm outputs)
+  float* tmp = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + al256(Mz * H * 4));   // projection output before dropout
   const float eps = enc->cfg.ln_eps;
+  const se::DropoutCfg dr = se::make_dropout(dropout_p, seed);
+  const bool drop = dr.thr16 != 0;
+  SE_REQUIRE(!drop || Mz * (size_t)H / 2 < 4294967296ull, "se_encoder_fwd_train_bf16: dropout pair index exceeds 32 bits");
   // B1
   SE_TRY(se::launch_cast_pad(feats, Mz, D, se::kInPad, s.xin, st));
   SE_TRY(se_gemm_bf16(s.xin, se::kInPad, enc->in_w, se::kInPad, enc->in_b, nullptr, M, H, se::kInPad, SE_ACT_IDENTITY, nullptr, s.pre0, H, stream));
-  SE_TRY(se::launch_layernorm(s.pre0, enc->pe, T, enc->in_ln_w, enc->in_ln_b, M, H, eps, x_f32, s.l[0].x0_bf, st));
+  if (drop)     // dropout after the input LayerNorm
+    SE_TRY(launch_ln_train(s.pre0, enc->pe, T, nullptr, enc->in_ln_w, enc->in_ln_b, M, H, eps, nullptr, x_f32, s.l[0].x0_bf, 0,
+                           se::dropout_key(seed, se::dropout_site(L, 0)), dr, st));
+  else
+    SE_TRY(se::launch_layernorm(s.pre0, enc->pe, T, enc->in_ln_w, enc->in_ln_b, M, H, eps, x_f32, s.l[0].x0_bf, st));
   for (int i = 0; i < L; ++i) {
     const se_encoder::Layer& y = enc->layers[i];
     SavedLayer& a = s.l[i];
+    const bool last = i == L - 1;
     // B2
     SE_TRY(se_gemm_bf16(a.x0_bf, H, y.qkv_w, H, y.qkv_b, nullptr, M, 3 * H, H, SE_ACT_IDENTITY, a.qkv, nullptr, 3 * H, stream));
-    SE_TRY(se_mhsa_fwd_lse_bf16(a.qkv, lengths, B, T, enc->cfg.heads, a.ctx, a.lse, stream));
-    SE_TRY(se_gemm_bf16(a.ctx, H, y.ao_w, H, y.ao_b, x_f32, M, H, H, SE_ACT_IDENTITY, nullptr, a.pre1, H, stream));
-    SE_TRY(se::launch_layernorm(a.pre1, nullptr, 1, y.aln_w, y.aln_b, M, H, eps, x_f32, a.x1_bf, st));
+    SE_TRY(se_mhsa_fwd_lse_bf16(a.qkv, lengths, B, T, enc->cfg.heads, a.ctx, a.lse, dropout_p, seed, se::dropout_site(i, 0), stream));
+    if (drop) {   // projection -> dropout -> + residual -> LayerNorm: the dropout sits between the GEMM and the residual add
+      SE_TRY(se_gemm_bf16(a.ctx, H, y.ao_w, H, y.ao_b, nullptr, M, H, H, SE_ACT_IDENTITY, nullptr, tmp, H, stream));
+      SE_TRY(launch_ln_train(tmp, nullptr, 1, x_f32, y.aln_w, y.aln_b, M, H, eps, a.pre1, x_f32, a.x1_bf, se::dropout_key(seed, se::dropout_site(i, 1)),
+                             0, dr, st));
+    } else {
+      SE_TRY(se_gemm_bf16(a.ctx, H, y.ao_w, H, y.ao_b, x_f32, M, H, H, SE_ACT_IDENTITY, nullptr, a.pre1, H, stream));
+      SE_TRY(se::launch_layernorm(a.pre1, nullptr, 1, y.aln_w, y.aln_b, M, H, eps, x_f32, a.x1_bf, st));
+    }
     // B3 (the pre-activation is kept for gelu')
     SE_TRY(se_gemm_bf16(a.x1_bf, H, y.ff1_w, H, y.ff1_b, nullptr, M, I, H, SE_ACT_IDENTITY, a.hpre, nullptr, I, stream));
     SE_TRY(se_gelu_bf16(a.hpre, Mz * I, a.h, stream));
-    SE_TRY(se_gemm_bf16(a.h, I, y.ff2_w, I, y.ff2_b, x_f32, M, H, I, SE_ACT_IDENTITY, nullptr, a.pre2, H, stream));
-    const bool last = i == L - 1;
-    SE_TRY(se::launch_layernorm(a.pre2, nullptr, 1, y.oln_w, y.oln_b, M, H, eps, last ? hidden : x_f32, last ? nullptr : s.l[i + 1].x0_bf, st));
+    if (drop) {
+      SE_TRY(se_gemm_bf16(a.h, I, y.ff2_w, I, y.ff2_b, nullptr, M, H, I, SE_ACT_IDENTITY, nullptr, tmp, H, stream));
+      SE_TRY(launch_ln_train(tmp, nullptr, 1, x_f32, y.oln_w, y.oln_b, M, H, eps, a.pre2, last ? hidden : x_f32, last ? nullptr : s.l[i + 1].x0_bf,
+                             se::dropout_key(seed, se::dropout_site(i, 2)), 0, dr, st));
+    } else {
+      SE_TRY(se_gemm_bf16(a.h, I, y.ff2_w, I, y.ff2_b, x_f32, M, H, I, SE_ACT_IDENTITY, nullptr, a.pre2, H, stream));
+      SE_TRY(se::launch_layernorm(a.pre2, nullptr, 1, y.oln_w, y.oln_b, M, H, eps, last ? hidden : x_f32, last ? nullptr : s.l[i + 1].x0_bf, st));
+    }
   }
   return SE_OK;
 }
@@ -214,7 +321,8 @@ int input_grad(const uint16_t* dY, const uint16_t* W, int M, int N, int K, const
 }  // namespace
 
 extern "C" int se_encoder_bwd_bf16(const se_encoder* enc, const int32_t* lengths, int B, int T, const float* d_hidden, const void* saved,
-                                   size_t saved_bytes, const se_encoder_grads* g, void* workspace, size_t workspace_bytes, void* stream) {
+                                   size_t saved_bytes, const se_encoder_grads* g, void* workspace, size_t workspace_bytes, float dropout_p,
+                                   uint64_t seed, void* stream) {
   SE_REQUIRE(enc && d_hidden && saved && g && workspace, "se_encoder_bwd_bf16: null argument");
   SE_TRY(check_train_shape(enc, B, T, "se_encoder_bwd_bf16"));
   SE_REQUIRE(saved_bytes >= se_encoder_saved_bytes(enc, B, T), "se_encoder_bwd_bf16: saved buffer too small");
@@ -227,13 +335,17 @@ extern "C" int se_encoder_bwd_bf16(const se_encoder* enc, const int32_t* lengths
   const Saved s = carve_saved(enc, B, T, reinterpret_cast<char*>(const_cast<void*>(saved)));
   const TrainWs w = carve_ws(enc, B, T, reinterpret_cast<char*>(workspace));
   const float eps = enc->cfg.ln_eps;
+  const se::DropoutCfg dr = se::make_dropout(dropout_p, seed);      // must be the forward's (p, seed): the masks are regenerated
+  const bool drop = dr.thr16 != 0;
+  auto dkey = [&](int layer, int which) { return drop ? se::dropout_key(seed, se::dropout_site(layer, which)) : 0u; };
   const float* gy = d_hidden;            // gradient wrt the current layer's output
   for (int i = L - 1; i >= 0; --i) {
     const se_encoder::Layer& y = enc->layers[i];
     const SavedLayer& a = s.l[i];
     // ---- output LayerNorm:  x2 = LN(pre2)
     //      (its dx column sums are the bias gradient of the linear that produced pre2)
-    SE_TRY(se::launch_layernorm_bwd(a.pre2, nullptr, 1, gy, y.oln_w, M, H, eps, 0, w.fa, w.b1, g->oln_w[i], g->oln_b[i], g->ff2_b[i], 0, st));
+    SE_TRY(se::launch_layernorm_bwd(a.pre2, nullptr, 1, gy, y.oln_w, M, H, eps, 0, w.fa, w.b1, g->oln_w[i], g->oln_b[i], g->ff2_b[i], 0, st,
+                                    0, dkey(i, 2), dr.thr16, dr.scale));
     // ---- FFN output linear:  pre2 = h W2^T + b2 + x1
     SE_TRY(weight_grad(w.b1, H, a.h, I, M, H, I, g->ff2_w[i], w, stream));
     SE_TRY(input_grad(w.b1, y.ff2_w, M, H, I, nullptr, w.bi, nullptr, w, stream));                 // dh (M, I)
@@ -242,12 +354,13 @@ extern "C" int se_encoder_bwd_bf16(const se_encoder* enc, const int32_t* lengths
     SE_TRY(weight_grad(w.bi, I, a.x1_bf, H, M, I, H, g->ff1_w[i], w, stream));
     SE_TRY(input_grad(w.bi, y.ff1_w, M, I, H, w.fa, nullptr, w.fb, w, stream));                    // dx1 = dhpre W1 + dpre2
     // ---- attention-output LayerNorm:  x1 = LN(pre1)
-    SE_TRY(se::launch_layernorm_bwd(a.pre1, nullptr, 1, w.fb, y.aln_w, M, H, eps, 0, w.fa, w.b1, g->aln_w[i], g->aln_b[i], g->ao_b[i], 0, st));
+    SE_TRY(se::launch_layernorm_bwd(a.pre1, nullptr, 1, w.fb, y.aln_w, M, H, eps, 0, w.fa, w.b1, g->aln_w[i], g->aln_b[i], g->ao_b[i], 0, st,
+                                    0, dkey(i, 1), dr.thr16, dr.scale));
     // ---- attention output linear:  pre1 = ctx Wo^T + bo + x0
     SE_TRY(weight_grad(w.b1, H, a.ctx, H, M, H, H, g->ao_w[i], w, stream));
     SE_TRY(input_grad(w.b1, y.ao_w, M, H, H, nullptr, w.b2, nullptr, w, stream));                  // dctx (M, H)
     // ---- attention core
-    SE_TRY(se_mhsa_bwd_bf16(a.qkv, a.ctx, w.b2, a.lse, lengths, B, T, enc->cfg.heads, w.b3, w.dvec, stream));
+    SE_TRY(se_mhsa_bwd_bf16(a.qkv, a.ctx, w.b2, a.lse, lengths, B, T, enc->cfg.heads, w.b3, w.dvec, dropout_p, seed, se::dropout_site(i, 0), stream));
     // ---- fused QKV linear:  qkv = x0 Wqkv^T + b
     SE_TRY(weight_grad(w.b3, 3 * H, a.x0_bf, H, M, 3 * H, H, w.gfused, w, stream));
     SE_TRY(se::launch_colsum_bf16(w.b3, M, 3 * H, 3 * H, w.bfused, st));
@@ -263,7 +376,8 @@ extern "C" int se_encoder_bwd_bf16(const se_encoder* enc, const int32_t* lengths
     gy = w.fb;
   }
   // ---- input stage:  x = LN(xin Win^T + b + PE)
-  SE_TRY(se::launch_layernorm_bwd(s.pre0, enc->pe, T, gy, enc->in_ln_w, M, H, eps, 0, w.fa, w.b1, g->in_ln_w, g->in_ln_b, g->in_b, 0, st));
+  SE_TRY(se::launch_layernorm_bwd(s.pre0, enc->pe, T, gy, enc->in_ln_w, M, H, eps, 0, w.fa, w.b1, g->in_ln_w, g->in_ln_b, g->in_b, 0, st,
+                                  dkey(L, 0), 0, dr.thr16, dr.scale));
   SE_TRY(weight_grad(w.b1, H, s.xin, se::kInPad, M, H, se::kInPad, w.gfused, w, stream));
   SE_HIP(hipMemcpy2DAsync(g->in_w, (size_t)D * 4, w.gfused, (size_t)se::kInPad * 4, (size_t)D * 4, H, hipMemcpyDeviceToDevice, st));
   return SE_OK;

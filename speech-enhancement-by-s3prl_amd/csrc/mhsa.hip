@@ -19,13 +19,16 @@
 #include "prof.h"
 #include "bf16.h"
 #include "mhsa_tile.h"
+#include "dropout.h"
 
 namespace se {
 
-template <int OCC>
+// DROP = 1 (training): the attention probabilities are dropped (counter-based mask of dropout.h, site key `dkey`) AFTER the
+// row sum, i.e. O = (P . mask / (1 - p)) V with P normalised by the full sum -- torch's dropout(softmax(.)) V
+template <int OCC, int DROP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void mhsa_fwd_kernel(
     const uint16_t* __restrict__ qkv, const int32_t* __restrict__ lengths, int T, int H, uint16_t* __restrict__ ctx,
-    float* __restrict__ lse) {
+    float* __restrict__ lse, uint32_t dkey, uint32_t thr16, float dscale) {
   __shared__ __attribute__((aligned(16))) char smem[2 * 2 * kAK * kHD * 2];   // 2 buffers x (K, V) x 8 KiB = 32 KiB
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -110,6 +113,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
     voff[dblk][1] = 8192 + kv_off(4 * hh + tq + 8, dcol >> 3) + (dcol & 7) * 2;
   }
 
+  // dropout: pair index of (this lane's query row, key) = row_id * ceil(T / 2) + key / 2
+  const uint32_t drop_row = ((uint32_t)(b * (H / kHD) + head) * (uint32_t)T + (uint32_t)min(q0 + l31, T - 1)) * (uint32_t)((T + 1) >> 1);
+
   SE_A_ISSUE(0);
   SE_A_WRITE(0);
   __syncthreads();
@@ -154,6 +160,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
     m_run = m_new;                                                                                                         \
     if (__any(alpha != 1.0f)) {                                                                                            \
       _Pragma("unroll") for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }                                   \
+    }                                                                                                                      \
+    if (DROP) {                                                                                                            \
+      const uint32_t pb = drop_row + (uint32_t)((kt * kAK + 4 * hh) >> 1);                                                 \
+      _Pragma("unroll") for (int r = 0; r < 16; r += 2) {                                                                  \
+        const uint32_t off = (uint32_t)(((r & 3) + 8 * (r >> 2)) >> 1);                                                    \
+        const uint32_t b0 = dropout_bits(dkey, pb + off), b1 = dropout_bits(dkey, pb + off + 16);                          \
+        s0[r] *= dropout_mul(b0, 0, thr16, dscale); s0[r + 1] *= dropout_mul(b0, 1, thr16, dscale);                        \
+        s1[r] *= dropout_mul(b1, 0, thr16, dscale); s1[r + 1] *= dropout_mul(b1, 1, thr16, dscale);                        \
+      }                                                                                                                    \
     }                                                                                                                      \
     bf16x8 pf[2][2];                                                                                                       \
     _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                                          \
@@ -208,7 +223,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
 
 }  // namespace se
 
-static int mhsa_fwd_launch(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, float* lse, void* stream) {
+static int mhsa_fwd_launch(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, float* lse, float dropout_p,
+                           uint64_t seed, uint32_t site, void* stream) {
   SE_REQUIRE(qkv && ctx, "se_mhsa_fwd_bf16: null argument");
   SE_REQUIRE(B > 0 && B <= 65535 && T > 0 && heads > 0 && heads <= 65535, "se_mhsa_fwd_bf16: bad shape B=%d T=%d heads=%d", B, T, heads);
   const int H = heads * se::kHD;
@@ -219,18 +235,26 @@ static int mhsa_fwd_launch(const uint16_t* qkv, const int32_t* lengths, int B, i
     const char* e = getenv("SE_AMD_MHSA_OCC");
     occ = e ? atoi(e) : 3;
   }
-  if (occ == 2) hipLaunchKernelGGL(se::mhsa_fwd_kernel<2>, grid, dim3(256), 0, se::as_stream(stream), qkv, lengths, T, H, ctx, lse);
-  else hipLaunchKernelGGL(se::mhsa_fwd_kernel<3>, grid, dim3(256), 0, se::as_stream(stream), qkv, lengths, T, H, ctx, lse);
+  const se::DropoutCfg d = se::make_dropout(dropout_p, seed);
+  if (d.thr16) {
+    SE_REQUIRE((double)B * heads * T * ((T + 1) / 2) < 4294967296.0, "se_mhsa_fwd: dropout pair index exceeds 32 bits");
+    hipLaunchKernelGGL((se::mhsa_fwd_kernel<2, 1>), grid, dim3(256), 0, se::as_stream(stream), qkv, lengths, T, H, ctx, lse,
+                       se::dropout_key(seed, site), d.thr16, d.scale);
+  } else if (occ == 2) {
+    hipLaunchKernelGGL((se::mhsa_fwd_kernel<2, 0>), grid, dim3(256), 0, se::as_stream(stream), qkv, lengths, T, H, ctx, lse, 0u, 0u, 1.f);
+  } else {
+    hipLaunchKernelGGL((se::mhsa_fwd_kernel<3, 0>), grid, dim3(256), 0, se::as_stream(stream), qkv, lengths, T, H, ctx, lse, 0u, 0u, 1.f);
+  }
   SE_LAUNCH_CHECK();
   return SE_OK;
 }
 
 extern "C" int se_mhsa_fwd_bf16(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, void* stream) {
-  return mhsa_fwd_launch(qkv, lengths, B, T, heads, ctx, nullptr, stream);
+  return mhsa_fwd_launch(qkv, lengths, B, T, heads, ctx, nullptr, 0.f, 0, 0, stream);
 }
 
 extern "C" int se_mhsa_fwd_lse_bf16(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, float* lse,
-                                    void* stream) {
+                                    float dropout_p, uint64_t seed, uint32_t site, void* stream) {
   SE_REQUIRE(lse, "se_mhsa_fwd_lse_bf16: null lse");
-  return mhsa_fwd_launch(qkv, lengths, B, T, heads, ctx, lse, stream);
+  return mhsa_fwd_launch(qkv, lengths, B, T, heads, ctx, lse, dropout_p, seed, site, stream);
 }

@@ -17,6 +17,7 @@
 #include "prof.h"
 #include "bf16.h"
 #include "mhsa_tile.h"
+#include "dropout.h"
 
 namespace se {
 
@@ -40,10 +41,12 @@ __device__ __forceinline__ void pair_mapping(int& b, int& head, int& tile) {
 
 // ------------------------------------------------------------------------------------------------------------------
 // dQ (and D): workgroup = 128 queries of one (utterance, head); streams (K, V) tiles of 64 keys.
-template <int OCC>
+// DROP: the forward dropped the probabilities (mhsa.hip); with mask m in {0, 1/(1-p)}: dV = (P m)^T dO, dS = P (m dP - D)
+template <int OCC, int DROP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void mhsa_bwd_dq_kernel(
     const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ o, const uint16_t* __restrict__ d_o, const float* __restrict__ lse,
-    const int32_t* __restrict__ lengths, int T, int H, uint16_t* __restrict__ dqkv, float* __restrict__ dvec) {
+    const int32_t* __restrict__ lengths, int T, int H, uint16_t* __restrict__ dqkv, float* __restrict__ dvec, uint32_t dkey, uint32_t thr16,
+    float dscale) {
   __shared__ __attribute__((aligned(16))) char smem[2 * 2 * kAK * kHD * 2];   // 2 buffers x (K, V) x 8 KiB
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -79,6 +82,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
   const float L2 = qvalid ? lse[stat] : INFINITY;       // exp2(x - inf) = 0: rows past T contribute nothing
   if (!qvalid) dsum = 0.f;
   if (qvalid && hh == 0) dvec[stat] = dsum;
+  const uint32_t drop_row = (uint32_t)stat * (uint32_t)((T + 1) >> 1);      // pair index base of this lane's query row
 
   // ---- staging of the (K, V) tiles: 64 rows x 128 B each; 256 threads x 16 B = 32 rows per pass
   const int srow = tid >> 3, sch = tid & 7;
@@ -153,7 +157,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
         if (key + 32 >= len) s1[r] = -INFINITY;
       }
     }
-    // dS^T = P^T (dP^T - D)   (the 1/8 of the score scale is applied once, in the epilogue)
+    // dS^T = P^T (m dP^T - D)   (the 1/8 of the score scale is applied once, in the epilogue)
+    if (DROP) {
+      const uint32_t pb = drop_row + (uint32_t)((kt * kAK + 4 * hh) >> 1);
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const uint32_t off = (uint32_t)(((r & 3) + 8 * (r >> 2)) >> 1);
+        const uint32_t b0 = dropout_bits(dkey, pb + off), b1 = dropout_bits(dkey, pb + off + 16);
+        p0[r] *= dropout_mul(b0, 0, thr16, dscale); p0[r + 1] *= dropout_mul(b0, 1, thr16, dscale);
+        p1[r] *= dropout_mul(b1, 0, thr16, dscale); p1[r + 1] *= dropout_mul(b1, 1, thr16, dscale);
+      }
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const float e0 = __builtin_amdgcn_exp2f(fmaf(s0[r], c, -L2));
@@ -205,10 +219,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
 // dK, dV: workgroup = 128 keys of one (utterance, head); streams (Q, dO) tiles of 64 queries (+ their lse / D).
 constexpr int kBufKV = 16384 + 512;   // Q tile, dO tile, lse[64], D[64]
 
-template <int OCC>
+template <int OCC, int DROP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void mhsa_bwd_dkv_kernel(
     const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ d_o, const float* __restrict__ lse, const float* __restrict__ dvec,
-    const int32_t* __restrict__ lengths, int T, int H, uint16_t* __restrict__ dqkv) {
+    const int32_t* __restrict__ lengths, int T, int H, uint16_t* __restrict__ dqkv, uint32_t dkey, uint32_t thr16, float dscale) {
   __shared__ __attribute__((aligned(16))) char smem[2 * kBufKV];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -298,6 +312,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
     toff[dblk][1] = kv_off(4 * hh + tq + 8, dcol >> 3) + (dcol & 7) * 2;
   }
 
+  // dropout indexing (see the DROP branch below)
+  const uint32_t drop_row0 = (uint32_t)(b * heads + head) * (uint32_t)T, drop_ppr = (uint32_t)((T + 1) >> 1);
+  const uint32_t drop_k2 = (uint32_t)(min(key, T - 1) >> 1);
+  const int drop_h = key & 1;
+
   SE_K_ISSUE(0);
   SE_K_WRITE(0);
   __syncthreads();
@@ -328,11 +347,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
         const float e1 = __builtin_amdgcn_exp2f(fmaf(sa[4 * g + 1], c, -l2.y));
         const float e2 = __builtin_amdgcn_exp2f(fmaf(sa[4 * g + 2], c, -l2.z));
         const float e3 = __builtin_amdgcn_exp2f(fmaf(sa[4 * g + 3], c, -l2.w));
-        sa[4 * g + 0] = e0; sa[4 * g + 1] = e1; sa[4 * g + 2] = e2; sa[4 * g + 3] = e3;
-        da[4 * g + 0] = e0 * (da[4 * g + 0] - dd.x);
-        da[4 * g + 1] = e1 * (da[4 * g + 1] - dd.y);
-        da[4 * g + 2] = e2 * (da[4 * g + 2] - dd.z);
-        da[4 * g + 3] = e3 * (da[4 * g + 3] - dd.w);
+        float m0 = 1.f, m1 = 1.f, m2 = 1.f, m3 = 1.f;
+        if (DROP) {
+          // lane = key, registers walk the queries: one hash per element (its pair partner is the neighbouring key, i.e. the
+          // neighbouring lane); pair = row_id(query) * ceil(T / 2) + key / 2, 16-bit half by the key's parity
+          const uint32_t q_first = (uint32_t)(qt * kAK + 32 * qb + 4 * hh + 8 * g);
+          const uint32_t pr = (drop_row0 + q_first) * drop_ppr + drop_k2;
+          m0 = dropout_mul(dropout_bits(dkey, pr), drop_h, thr16, dscale);
+          m1 = dropout_mul(dropout_bits(dkey, pr + drop_ppr), drop_h, thr16, dscale);
+          m2 = dropout_mul(dropout_bits(dkey, pr + 2 * drop_ppr), drop_h, thr16, dscale);
+          m3 = dropout_mul(dropout_bits(dkey, pr + 3 * drop_ppr), drop_h, thr16, dscale);
+        }
+        sa[4 * g + 0] = e0 * m0; sa[4 * g + 1] = e1 * m1; sa[4 * g + 2] = e2 * m2; sa[4 * g + 3] = e3 * m3;
+        da[4 * g + 0] = e0 * (m0 * da[4 * g + 0] - dd.x);
+        da[4 * g + 1] = e1 * (m1 * da[4 * g + 1] - dd.y);
+        da[4 * g + 2] = e2 * (m2 * da[4 * g + 2] - dd.z);
+        da[4 * g + 3] = e3 * (m3 * da[4 * g + 3] - dd.w);
       }
       bf16x8 pf[2], df[2];
 #pragma unroll
@@ -391,16 +421,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
 }  // namespace se
 
 extern "C" int se_mhsa_bwd_bf16(const uint16_t* qkv, const uint16_t* ctx, const uint16_t* d_ctx, const float* lse, const int32_t* lengths,
-                                int B, int T, int heads, uint16_t* dqkv, float* dvec, void* stream) {
+                                int B, int T, int heads, uint16_t* dqkv, float* dvec, float dropout_p, uint64_t seed, uint32_t site,
+                                void* stream) {
   SE_REQUIRE(qkv && ctx && d_ctx && lse && dqkv && dvec, "se_mhsa_bwd_bf16: null argument");
   SE_REQUIRE(B > 0 && B <= 65535 && T > 0 && heads > 0 && heads <= 65535, "se_mhsa_bwd_bf16: bad shape B=%d T=%d heads=%d", B, T, heads);
   const int H = heads * se::kHD;
   hipStream_t st = se::as_stream(stream);
   dim3 grid((T + se::kAQ - 1) / se::kAQ, heads, B);
   se::ProfScope prof(se::kProfMhsaBwd, 14.0 * B * (double)heads * T * (double)T * se::kHD, st);
-  hipLaunchKernelGGL(se::mhsa_bwd_dq_kernel<2>, grid, dim3(256), 0, st, qkv, ctx, d_ctx, lse, lengths, T, H, dqkv, dvec);
-  SE_LAUNCH_CHECK();
-  hipLaunchKernelGGL(se::mhsa_bwd_dkv_kernel<2>, grid, dim3(256), 0, st, qkv, d_ctx, lse, dvec, lengths, T, H, dqkv);
-  SE_LAUNCH_CHECK();
+  const se::DropoutCfg d = se::make_dropout(dropout_p, seed);
+  if (d.thr16) {
+    SE_REQUIRE((double)B * heads * T * ((T + 1) / 2) < 4294967296.0, "se_mhsa_bwd_bf16: dropout pair index exceeds 32 bits");
+    const uint32_t dkey = se::dropout_key(seed, site);
+    hipLaunchKernelGGL((se::mhsa_bwd_dq_kernel<2, 1>), grid, dim3(256), 0, st, qkv, ctx, d_ctx, lse, lengths, T, H, dqkv, dvec, dkey, d.thr16, d.scale);
+    SE_LAUNCH_CHECK();
+    hipLaunchKernelGGL((se::mhsa_bwd_dkv_kernel<2, 1>), grid, dim3(256), 0, st, qkv, d_ctx, lse, dvec, lengths, T, H, dqkv, dkey, d.thr16, d.scale);
+    SE_LAUNCH_CHECK();
+  } else {
+    hipLaunchKernelGGL((se::mhsa_bwd_dq_kernel<2, 0>), grid, dim3(256), 0, st, qkv, ctx, d_ctx, lse, lengths, T, H, dqkv, dvec, 0u, 0u, 1.f);
+    SE_LAUNCH_CHECK();
+    hipLaunchKernelGGL((se::mhsa_bwd_dkv_kernel<2, 0>), grid, dim3(256), 0, st, qkv, d_ctx, lse, dvec, lengths, T, H, dqkv, 0u, 0u, 1.f);
+    SE_LAUNCH_CHECK();
+  }
   return SE_OK;
 }

@@ -12,7 +12,8 @@ ckpt['Transformer'] (state_dict of TransformerModel), ckpt['SpecHead'] (state_di
 The forward pass runs on libse_amd.so only (bf16 MFMA GEMMs + flash MHSA, fp32 residual stream); there is no
 CPU fallback.  Under torch.no_grad() (the reference's upstream role, runner.py:273-284) the fused inference path runs;
 with gradients enabled (Mockingjay fine-tuning, model.py:163-171) the training path keeps the activations and the
-backward pass runs on the HIP kernels too (se_encoder_fwd_train_bf16 / se_encoder_bwd_bf16).  Dropout is not applied.
+backward pass runs on the HIP kernels too (se_encoder_fwd_train_bf16 / se_encoder_bwd_bf16).  In train() mode BERT's
+dropout sites are active (rates from the checkpoint's config) with counter-based masks that the backward regenerates.
 """
 import ctypes
 import warnings
@@ -169,20 +170,21 @@ class _EncoderTrainFn(torch.autograd.Function):
     preprocessor)."""
 
     @staticmethod
-    def forward(ctx, engine, model, feats, lengths, *params):
+    def forward(ctx, engine, model, feats, lengths, dropout_p, seed, *params):
         lib = _lib.load()
         B, T, D = feats.shape
         dev = feats.device
         h = engine._ensure(model, None, dev)
         H = model.config.hidden_size
         nsaved = lib.se_encoder_saved_bytes(h, B, T)
-        nws = B * T * H * 4 + 256
+        nws = 2 * ((B * T * H * 4 + 255) // 256 * 256) + 256
         saved = torch.empty(nsaved, device=dev, dtype=torch.uint8)
         ws = torch.empty(nws, device=dev, dtype=torch.uint8)
         hidden = torch.empty(B, T, H, device=dev, dtype=torch.float32)
         _lib.check(lib.se_encoder_fwd_train_bf16(h, _lib.ptr(feats), _lib.ptr(lengths), B, T, _lib.ptr(hidden), _lib.ptr(saved), nsaved,
-                                                 _lib.ptr(ws), nws, _lib.stream()), 'se_encoder_fwd_train_bf16')
+                                                 _lib.ptr(ws), nws, float(dropout_p), int(seed), _lib.stream()), 'se_encoder_fwd_train_bf16')
         ctx.engine, ctx.model, ctx.buf, ctx.lengths, ctx.shape, ctx.handle = engine, model, saved, lengths, (B, T), h
+        ctx.dropout = (float(dropout_p), int(seed))
         return hidden
 
     @staticmethod
@@ -202,12 +204,12 @@ class _EncoderTrainFn(torch.autograd.Function):
         nws = lib.se_encoder_train_workspace_bytes(h, B, T)
         ws = torch.empty(nws, device=dev, dtype=torch.uint8)
         _lib.check(lib.se_encoder_bwd_bf16(h, _lib.ptr(ctx.lengths), B, T, _lib.ptr(d_hidden), _lib.ptr(saved), saved.numel(), gs,
-                                           _lib.ptr(ws), nws, _lib.stream()), 'se_encoder_bwd_bf16')
+                                           _lib.ptr(ws), nws, ctx.dropout[0], ctx.dropout[1], _lib.stream()), 'se_encoder_bwd_bf16')
         ctx.buf = None
         grads = [ghead[k] for k in ('in_w', 'in_b', 'in_ln_w', 'in_ln_b')]
         for k in _TRUNK_FIELDS:
             grads.extend(gper[k])
-        return (None, None, None, None) + tuple(grads)
+        return (None, None, None, None, None, None) + tuple(grads)
 
 
 class _Engine:
@@ -314,8 +316,9 @@ class _Engine:
             self.key = key
         return self.handle
 
-    def encode_train(self, model, feats, lengths=None):
-        """Autograd-recording forward (Mockingjay fine-tune, model.py:164): returns hidden with a grad_fn."""
+    def encode_train(self, model, feats, lengths=None, dropout_p=0.0, seed=0):
+        """Autograd-recording forward (Mockingjay fine-tune, model.py:164): returns hidden with a grad_fn.  dropout_p > 0:
+        training-mode dropout with counter-based masks of `seed` (regenerated, not stored, in the backward)."""
         if not feats.is_cuda:
             raise _lib.SEError('TRANSFORMER runs on MI355X only (no CPU fallback): move the module and inputs to the GPU')
         lib = _lib.load()
@@ -324,7 +327,7 @@ class _Engine:
         if lengths is None:
             lengths = torch.empty(B, device=feats.device, dtype=torch.int32)
             _lib.check(lib.se_valid_lengths_i32(_lib.ptr(feats), B, T, D, _lib.ptr(lengths), _lib.stream()), 'se_valid_lengths_i32')
-        return _EncoderTrainFn.apply(self, model, feats, lengths, *_trunk_param_list(model))
+        return _EncoderTrainFn.apply(self, model, feats, lengths, dropout_p, seed, *_trunk_param_list(model))
 
     def _workspace(self, handle, B, T, device):
         lib = _lib.load()
@@ -421,17 +424,24 @@ class TRANSFORMER(nn.Module):
         self.all_states = None      # free the checkpoint copy
 
     def forward(self, x):
-        if self.training and not self._warned and self.model_config.hidden_dropout_prob > 0:
-            warnings.warn('TRANSFORMER.forward in training mode: dropout is not applied by the MI355X encoder')
-            self._warned = True
         train = torch.is_grad_enabled() and not self.no_grad and any(p.requires_grad for p in self.model.parameters())
+        dropout_p = self.model_config.hidden_dropout_prob if self.training else 0.0
+        if dropout_p > 0:
+            if self.model_config.attention_probs_dropout_prob != dropout_p:
+                raise NotImplementedError('hidden_dropout_prob != attention_probs_dropout_prob (config/pretrain_sample.yaml:9-10 sets both to 0.1)')
+            if not train and not self._warned:
+                warnings.warn('TRANSFORMER in train() mode without gradients: the fused inference path runs, dropout is not applied')
+                self._warned = True
         if self.permute_input:
             x = x.permute(1, 0, 2)
         if hasattr(self, 'preprocessor') and x.size(-1) != self.inp_dim:
             # waveform input (B, T, C): the internal preprocessor extracts the pre-training input feature
             x = self.preprocessor(x.transpose(1, 2).contiguous())[0]
         if train:
-            out = self._engine.encode_train(self.model, x)
+            # one 63-bit seed per forward from torch's CPU generator (torch.manual_seed reproduces a run)
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if dropout_p > 0 else 0
+            self.last_dropout = (dropout_p, seed)
+            out = self._engine.encode_train(self.model, x, dropout_p=dropout_p, seed=seed)
         else:
             with torch.no_grad():
                 out = self._engine.encode(self.model, None, x)

@@ -24,8 +24,9 @@ def rel_l2(a, b):
     return ((a - b).norm() / b.norm()).item()
 
 
-@pytest.mark.parametrize('B,T,heads,lens', [(2, 300, 12, [300, 177]), (1, 129, 4, None), (3, 64, 2, [64, 1, 33])])
-def test_mhsa_backward_vs_autograd(gpu, B, T, heads, lens):
+@pytest.mark.parametrize('B,T,heads,lens,drop', [(2, 300, 12, [300, 177], 0.0), (1, 129, 4, None, 0.0), (3, 64, 2, [64, 1, 33], 0.0),
+                                                  (2, 301, 12, [301, 190], 0.1), (1, 130, 4, None, 0.25)])
+def test_mhsa_backward_vs_autograd(gpu, B, T, heads, lens, drop):
     L = _L()
     lib = L.load()
     torch.manual_seed(T)
@@ -36,11 +37,12 @@ def test_mhsa_backward_vs_autograd(gpu, B, T, heads, lens):
     qkv_g, do_g, len_g = qkv.to(gpu), d_o.to(gpu), lengths.to(gpu)
     ctx = torch.empty(B * T, H, device=gpu, dtype=torch.bfloat16)
     lse = torch.empty(B, heads, T, device=gpu, dtype=torch.float32)
-    L.check(lib.se_mhsa_fwd_lse_bf16(L.ptr(qkv_g), L.ptr(len_g), B, T, heads, L.ptr(ctx), L.ptr(lse), L.stream()), 'fwd')
+    seed, site = 0x1234567890abcdef % (1 << 63), 7
+    L.check(lib.se_mhsa_fwd_lse_bf16(L.ptr(qkv_g), L.ptr(len_g), B, T, heads, L.ptr(ctx), L.ptr(lse), drop, seed, site, L.stream()), 'fwd')
     dqkv = torch.full((B * T, 3 * H), float('nan'), device=gpu, dtype=torch.bfloat16)
     dvec = torch.empty(B, heads, T, device=gpu, dtype=torch.float32)
     L.check(lib.se_mhsa_bwd_bf16(L.ptr(qkv_g), L.ptr(ctx), L.ptr(do_g), L.ptr(lse), L.ptr(len_g), B, T, heads, L.ptr(dqkv), L.ptr(dvec),
-                                 L.stream()), 'bwd')
+                                 drop, seed, site, L.stream()), 'bwd')
     # fp64 autograd on the same (bf16-valued) operands
     x = qkv.double().requires_grad_(True)
     q, k, v = [t.reshape(B, T, heads, 64).permute(0, 2, 1, 3) for t in x.reshape(B, T, 3 * H).split(H, dim=-1)]
@@ -48,6 +50,10 @@ def test_mhsa_backward_vs_autograd(gpu, B, T, heads, lens):
     mask = torch.arange(T)[None, :] >= lengths[:, None].long()
     s = s.masked_fill(mask[:, None, None, :], float('-inf'))
     p = torch.softmax(s, dim=-1)
+    if drop > 0:                     # the same counter-based mask (oracle restatement of csrc/dropout.h)
+        keep = oenc.keep_mask(seed, site, B * heads * T, T, drop).reshape(B, heads, T, T)
+        assert abs(keep.float().mean().item() - (1 - drop)) < 0.01
+        p = p * keep.double() / (1.0 - drop)
     o = (p @ v).permute(0, 2, 1, 3).reshape(B * T, H)
     (o * d_o.double()).sum().backward()
     # forward pieces
@@ -82,7 +88,7 @@ def test_gelu_forward_backward(gpu):
     assert (dx.double().cpu() - xd.grad).abs().max().item() < 2 ** -7 * xd.grad.abs().max().item()
 
 
-def _encoder_grads_vs_oracle(gpu, cfg, ckpt, B, T, lens, tol):
+def _encoder_grads_vs_oracle(gpu, cfg, ckpt, B, T, lens, tol, train_mode=False):
     from speech_enhancement_by_s3prl_amd import pipeline
     from speech_enhancement_by_s3prl_amd.transformer import TRANSFORMER
     options = {'ckpt_file': '', 'load_pretrain': 'False', 'no_grad': 'False', 'dropout': 'default', 'spec_aug': 'False',
@@ -90,6 +96,8 @@ def _encoder_grads_vs_oracle(gpu, cfg, ckpt, B, T, lens, tol):
     up = TRANSFORMER(options, 80, config=ckpt['Settings']['Config'])
     up.model.load_state_dict(ckpt['Transformer'])
     up = up.to(gpu).eval()
+    if train_mode:
+        up.train()                        # dropout 0.1 at BERT's four sites (config/pretrain_sample.yaml:9-10)
     torch.manual_seed(T)
     feats = torch.randn(B, T, 80)
     if lens:
@@ -102,7 +110,9 @@ def _encoder_grads_vs_oracle(gpu, cfg, ckpt, B, T, lens, tol):
     (hidden * G.to(gpu)).sum().backward()
     sd = {k: v.double().clone().requires_grad_(True) for k, v in ckpt['Transformer'].items()}
     ocfg = oenc.Config(cfg)
-    ref = oenc.encoder_forward(feats.double(), sd, ocfg)
+    p_drop, seed = up.last_dropout if train_mode else (0.0, 0)
+    assert (p_drop > 0) == train_mode
+    ref = oenc.encoder_forward(feats.double(), sd, ocfg, dropout_p=p_drop, seed=seed)     # same counter-based masks
     assert rel_l2(hidden.detach(), ref.detach()) < 2e-2
     (ref * G.double()).sum().backward()
     worst = 0.0
@@ -135,6 +145,43 @@ def test_encoder_gradients_full_width(gpu):
     cfg = pipeline.make_config(layers=2)
     ckpt = pipeline.synthetic_checkpoint(cfg, seed=4)
     _encoder_grads_vs_oracle(gpu, cfg, ckpt, 2, 200, [200, 150], tol=4e-2)
+
+
+def test_encoder_gradients_with_dropout(gpu):
+    """train() mode: hidden states and every parameter gradient against the oracle run with the SAME dropout masks (the
+    oracle regenerates them from the seed: oracle/encoder.py keep_mask == csrc/dropout.h), small and full width."""
+    from speech_enhancement_by_s3prl_amd import pipeline
+    cfg = pipeline.make_config(layers=2, hidden=256, heads=4, intermediate=512)
+    _encoder_grads_vs_oracle(gpu, cfg, pipeline.synthetic_checkpoint(cfg, seed=3), 3, 131, [131, 100, 64], tol=4e-2, train_mode=True)
+    cfg = pipeline.make_config(layers=2)
+    _encoder_grads_vs_oracle(gpu, cfg, pipeline.synthetic_checkpoint(cfg, seed=4), 2, 150, [150, 99], tol=4e-2, train_mode=True)
+
+
+def test_dropout_is_resampled_and_off_in_eval(gpu):
+    from speech_enhancement_by_s3prl_amd import pipeline
+    from speech_enhancement_by_s3prl_amd.transformer import TRANSFORMER
+    cfg = pipeline.make_config(layers=1)
+    ckpt = pipeline.synthetic_checkpoint(cfg, seed=9)
+    options = {'ckpt_file': '', 'load_pretrain': 'False', 'no_grad': 'False', 'dropout': 'default', 'spec_aug': 'False',
+               'spec_aug_prev': 'True', 'weighted_sum': 'False', 'select_layer': -1, 'permute_input': 'False'}
+    up = TRANSFORMER(options, 80, config=ckpt['Settings']['Config'])
+    up.model.load_state_dict(ckpt['Transformer'])
+    up = up.to(gpu)
+    feats = torch.randn(2, 100, 80, device=gpu)
+    up.train()
+    a, b = up(feats).detach(), up(feats).detach()
+    assert not torch.equal(a, b)                          # a fresh seed per forward
+    torch.manual_seed(11)
+    c = up(feats).detach()
+    torch.manual_seed(11)
+    d = up(feats).detach()
+    assert torch.equal(c, d)                              # torch.manual_seed reproduces the masks
+    up.eval()
+    e, f = up(feats).detach(), up(feats).detach()
+    assert torch.equal(e, f)
+    with torch.no_grad():
+        g = up(feats)
+    assert rel_l2(e, g) < 1e-2                            # training-path forward (no dropout) vs fused inference path
 
 
 def test_mockingjay_finetune_step(gpu, tmp_path):
