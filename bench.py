@@ -176,7 +176,7 @@ def main():
     }
     if args.workload == 'finetune':
         out['config']['workload'] = ('configs[3]: Mockingjay fine-tune step (6x768x12x3072 encoder + spec head, 43 M params): STFT/features, '
-                                     'forward, masked log-L1, backward, flat-buffer gradient all-reduce, clip 1.0, BertAdam; dropout off')
+                                     'forward (train mode, dropout 0.1), masked log-L1, backward, flat-buffer gradient all-reduce, clip 1.0, BertAdam')
         out['config']['parallelism'] = f'dp{world} (replicated parameters, one gradient all-reduce per step)'
 
     if rank == 0 and not args.no_roofline:
