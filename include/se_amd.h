@@ -329,6 +329,23 @@ int se_bertadam_step_f32(float* const* params, const float* const* grads, float*
                          double max_grad_norm, double global_max_norm, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * The stages either side of the hot path, batched on the device.
+ * ---------------------------------------------------------------------------------------------- */
+/* OnlineDataset.__getitem__'s arithmetic (dataset.py:141-161): per utterance b, speech (len_s[b] samples of row b) and
+ * noise (len_n[b] samples of row b starting at off_n[b] -- `half_noise`, dataset.py:147-152; off_n may be NULL) are
+ * level-normalised (normalize != 0: normalize_wav_decibel, dataset.py:106-111), the noise is tiled / cut to the speech
+ * length and mixed at snr_db[b] (add_noise, dataset.py:54-74, eps as OnlineDataset.eps), and written as
+ * wavs (B, 3, T_out) = (noisy, clean, scaled noise), zero padded past len_s[b] (collate_fn, dataset.py:169-179).
+ * sums: device double[3 B] scratch.  lengths of the batch are len_s. */
+int se_mix_f32(const float* speech, int ld_s, const int64_t* len_s, const float* noise, int ld_n, const int64_t* len_n,
+               const int64_t* off_n, const float* snr_db, int B, int T_out, int normalize, float target_level_db, float eps,
+               float* wavs, double* sums, void* stream);
+/* evaluation.sisdr_eval (evaluation.py:5-10) for each utterance over its first lengths[b] samples (runner.py:597-603);
+ * src, tar (B, ld) fp32; sums: device double[3 B] scratch; sisdr (B) fp32 in dB. */
+int se_sisdr_f32(const float* src, const float* tar, int ld, const int64_t* lengths, int B, float eps, double* sums, float* sisdr,
+                 void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Optional in-library timing for bench.py's roofline leg: HIP events recorded on the launch stream around
  * every kernel of a family while enabled.  kind: 0 = bf16 GEMM (work = 2MNK flop), 1 = MHSA (4 B h T^2 64 flop),
  * 2 = STFT, 3 = iSTFT (work = algorithmic bytes), 4 = LayerNorm, 5 = head, 6 = MHSA backward (14 B h T^2 64 flop).  se_prof_read synchronises on the recorded events.

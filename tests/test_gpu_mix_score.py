@@ -1,0 +1,68 @@
+"""GPU parity of the stages either side of the hot path against the reference's own outputs
+(tests/golden/reference_golden.npz: add_noise, normalize_wav_decibel, sisdr_eval run from /root/reference) and against the
+host restatement (synth.py) on batches the reference cannot run (its add_noise only works at batch 1)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_add_noise_golden(gpu, golden):
+    from speech_enhancement_by_s3prl_amd.mixing import mix_batch
+    sp = torch.from_numpy(golden['an_speech']).to(gpu)
+    for tag in ('short', 'long'):              # noise shorter (tiled) and longer (cut) than the speech
+        nz = torch.from_numpy(golden[f'an_noise_{tag}']).to(gpu)
+        lengths, wavs = mix_batch(sp, torch.tensor([sp.shape[1]]), nz, torch.tensor([nz.shape[1]]), torch.from_numpy(golden['an_snrs']),
+                                  normalize=False, eps=1e-10)
+        noisy, scaled = golden[f'an_noisy_{tag[0]}'], golden[f'an_scaled_{tag[0]}']
+        assert int(lengths[0]) == sp.shape[1]
+        assert torch.allclose(wavs[0, 0].cpu(), torch.from_numpy(noisy[0]), rtol=1e-5, atol=1e-6)
+        assert torch.equal(wavs[0, 1].cpu(), torch.from_numpy(golden['an_speech'][0]))
+        assert torch.allclose(wavs[0, 2].cpu(), torch.from_numpy(scaled[0]), rtol=1e-5, atol=1e-6)
+
+
+def test_normalize_golden(gpu, golden):
+    from speech_enhancement_by_s3prl_amd.mixing import mix_batch
+    x = torch.from_numpy(golden['nwd_in']).to(gpu).reshape(1, -1)
+    _, wavs = mix_batch(x, torch.tensor([x.shape[1]]), x, torch.tensor([x.shape[1]]), torch.zeros(1), target_level=-25)
+    assert torch.allclose(wavs[0, 1].cpu(), torch.from_numpy(golden['nwd_out']), rtol=1e-5, atol=1e-7)
+
+
+def test_mix_batch_vs_host_restatement(gpu):
+    """ragged batch incl. half_noise offsets and zero padding, against synth.py's per-utterance torch arithmetic"""
+    from speech_enhancement_by_s3prl_amd import synth
+    from speech_enhancement_by_s3prl_amd.mixing import mix_batch
+    g = torch.Generator().manual_seed(0)
+    B, Ts, Tn = 5, 40000, 30000
+    ls = torch.tensor([40000, 31234, 777, 20000, 1])
+    ln = torch.tensor([30000, 9000, 30000, 123, 5000])
+    off = torch.tensor([0, 4500, 0, 10, 2500])
+    speech, noise = torch.randn(B, Ts, generator=g) * 0.3, torch.randn(B, Tn, generator=g)
+    snrs = torch.tensor([-8.0, 0.0, 8.0, 3.0, -2.0])
+    lengths, wavs = mix_batch(speech.to(gpu), ls, noise.to(gpu), ln, snrs, target_level=-25, eps=1e-8, noise_offsets=off)
+    assert torch.equal(lengths.cpu(), ls)
+    for b in range(B):
+        s = synth.normalize_wav_decibel(speech[b, :ls[b]], -25)
+        n = synth.normalize_wav_decibel(noise[b, off[b]:off[b] + ln[b]], -25)
+        noisy, scaled = synth.add_noise(s[None], n[None], snrs[b:b + 1], eps=1e-8)
+        L = int(ls[b])
+        for ch, ref in ((0, noisy[0]), (1, s), (2, scaled[0])):
+            got = wavs[b, ch].cpu()
+            assert (got[:L] - ref).abs().max().item() <= 2e-5 * ref.abs().max().item() + 1e-7, (b, ch)
+            assert torch.count_nonzero(got[L:]) == 0
+
+
+def test_sisdr_golden_and_batch(gpu, golden):
+    from oracle import objective as oobj
+    from speech_enhancement_by_s3prl_amd.evaluation import sisdr_batch, sisdr_eval
+    src, tar = torch.from_numpy(golden['se_src']).to(gpu), torch.from_numpy(golden['se_tar']).to(gpu)
+    assert abs(sisdr_eval(src, tar) - float(golden['se_val'])) < 1e-3          # dB
+    g = torch.Generator().manual_seed(1)
+    B, T = 6, 50000
+    tar = torch.randn(B, T, generator=g)
+    src = tar * torch.linspace(0.5, 2.0, B)[:, None] + torch.randn(B, T, generator=g) * torch.logspace(-3, 0, B)[:, None]
+    lens = torch.tensor([50000, 40000, 1234, 50000, 10, 25000])
+    got = sisdr_batch(src.to(gpu), tar.to(gpu), lens).cpu()
+    for b in range(B):
+        ref = oobj.sisdr_eval(src[b, :lens[b]].double(), tar[b, :lens[b]].double())
+        assert abs(got[b].item() - ref) < 2e-3, (b, got[b].item(), ref)
