@@ -225,11 +225,14 @@ __global__ __launch_bounds__(k4Threads) __attribute__((amdgpu_waves_per_eu(2, 2)
   }
   // normalise + store (stores only in this loop; the per-column vectors come from LDS)
   const bool interior = m0 + k4BM <= M;
+  const bool godd = cq & 1;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int gm = m0 + wr * 64 + i * 16 + mrow;
     const bool ok = interior || gm < M;
     const size_t o = (size_t)min(gm, M - 1) * k4N + col0;
+    const size_t orow8 = (size_t)min(gm, M - 1) * k4N + wc * 192 + 4 * (cq & ~1);      // first of this lane's 8 consecutive bf16 columns
+    uint2 pk_prev = make_uint2(0u, 0u);
 #pragma unroll
     for (int t = 0; t < 12; ++t) {
       if ((t & 3) == 0) __builtin_amdgcn_sched_barrier(0);
@@ -239,9 +242,20 @@ __global__ __launch_bounds__(k4Threads) __attribute__((amdgpu_waves_per_eu(2, 2)
       const float y1 = lw.y * ((acc[i][t][1] - mean[i]) * rstd[i]) + lb.y;
       const float y2 = lw.z * ((acc[i][t][2] - mean[i]) * rstd[i]) + lb.z;
       const float y3 = lw.w * ((acc[i][t][3] - mean[i]) * rstd[i]) + lb.w;
-      if (ok) {
-        if (out_f32) *reinterpret_cast<float4*>(out_f32 + o + 16 * t) = make_float4(y0, y1, y2, y3);
-        if (out_bf16) *reinterpret_cast<uint2*>(out_bf16 + o + 16 * t) = make_uint2(pack_bf16x2(y0, y1), pack_bf16x2(y2, y3));
+      if (ok && out_f32) *reinterpret_cast<float4*>(out_f32 + o + 16 * t) = make_float4(y0, y1, y2, y3);
+      if (out_bf16) {
+        // 16-B bf16 stores (as gemm3.hip): lanes l, l ^ 16 trade 4-column pieces of the MFMA tile pair (t - 1, t), so a lane owns 8
+        // consecutive columns and one wave instruction writes 16 rows x 64 contiguous bytes instead of 16 x 32
+        const uint2 pk = make_uint2(pack_bf16x2(y0, y1), pack_bf16x2(y2, y3));
+        if (t & 1) {
+          const uint2 keep = godd ? pk : pk_prev, send = godd ? pk_prev : pk;
+          uint2 recv;
+          recv.x = __shfl_xor(send.x, 16);
+          recv.y = __shfl_xor(send.y, 16);
+          const uint4 o16 = godd ? make_uint4(recv.x, recv.y, keep.x, keep.y) : make_uint4(keep.x, keep.y, recv.x, recv.y);
+          if (ok) *reinterpret_cast<uint4*>(out_bf16 + orow8 + 16 * (godd ? t : t - 1)) = o16;
+        }
+        pk_prev = pk;
       }
     }
   }
