@@ -85,6 +85,27 @@ def cpu_baseline(batch, layers, seconds_budget=25.0):
                       f'{dt:.2f} s per batch on {cpu_name}'}
 
 
+PMC_FILE = os.path.join(ROOT, 'profiles', 'r01_e_pmc_fetch_write.json')
+
+
+def pmc_traffic(substrings):
+    """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes of this same command (separate
+    `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs, KB per dispatch; bench.py cannot run counter passes on itself).
+    gfx950 correction (MI355X_MICROARCH.md, HBM / rocprofv3): FETCH_SIZE tallies 128-B requests at 64 B for 16-B-per-lane
+    streams, so it is doubled; WRITE_SIZE is exact.  Returns None when the file is absent."""
+    try:
+        with open(PMC_FILE) as fh:
+            d = json.load(fh)
+    except (OSError, ValueError):
+        return None
+    tot, n = 0.0, 0
+    for name, v in d.items():
+        if any(sub in name for sub in substrings) and 'FETCH_SIZE_KB_mean' in v and 'WRITE_SIZE_KB_mean' in v:
+            tot += (2.0 * v['FETCH_SIZE_KB_mean'] + v['WRITE_SIZE_KB_mean']) * 1024.0 * v['launches']
+            n += v['launches']
+    return tot / n if n else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -195,8 +216,10 @@ def main():
             fam[name] = (ms.value, work.value, n.value)
         g_ms, g_flop, g_n = fam['gemm_bf16']
         achieved = g_flop / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
+        traffic = pmc_traffic(('gemm2_bf16_kernel', 'gemm3_bf16_kernel', 'gemm4_res_ln_kernel')) if args.workload == 'enhance' else None
         out['roofline'] = {'bound': 'mfma', 'kernel': 'gemm_bf16_kernel', 'achieved': achieved, 'peak': MFMA_BF16_PEAK_TFLOPS,
-                           'unit': 'TFLOP/s', 'frac': achieved / MFMA_BF16_PEAK_TFLOPS, 'traffic': None,
+                           'unit': 'TFLOP/s', 'frac': achieved / MFMA_BF16_PEAK_TFLOPS, 'traffic': traffic,
+                           'traffic_unit': 'HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, committed PMC passes: profiles/r01_e_pmc_fetch_write.json)',
                            'launches': g_n, 'avg_launch_ms': g_ms / max(g_n, 1),
                            'algorithmic_flop_per_launch': g_flop / max(g_n, 1)}
         others = {}
