@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
       }                                                                                                                    \
     }                                                                                                                      \
     float mx = fmaxf(s0[0], s1[0]);                                                                                        \
-    _Pragma("unroll") for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s0[r], s1[r]));                                    \
+    _Pragma("unroll") for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, s0[r]), s1[r]);       /* v_max3_f32 */            \
     mx = fmaxf(mx, __shfl_xor(mx, 32));                                                                                    \
     const float m_new = fmaxf(m_run, mx);                                                                                  \
     const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);                                                       \
