@@ -90,6 +90,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
     *reinterpret_cast<uint4*>(v_w + so1) = rv1;                         \
   } while (0)
 
+  const f32x16 kZero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   f32x16 o0, o1;                      // O^T d-blocks 0 / 1: col = query (lane & 31), row = d
 #pragma unroll
   for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
@@ -125,12 +126,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
     if (kt + 1 < nkt) SE_A_ISSUE(kt + 1);                                                                                  \
     const char* t_s = smem + (CUR) * 16384;                                                                                \
     f32x16 s0, s1;                                                                                                         \
-    _Pragma("unroll") for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }                                           \
     _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                                        \
       const bf16x8 ka = *reinterpret_cast<const bf16x8*>(t_s + koff[s]);                                                   \
       const bf16x8 kb_ = *reinterpret_cast<const bf16x8*>(t_s + koff[s] + 4096);                                           \
-      s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[s], s0, 0, 0, 0);                                                \
-      s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb_, qf[s], s1, 0, 0, 0);                                               \
+      /* first product of the chain takes the inline constant 0 as C: no 32 v_mov per tile to clear the accumulators */      \
+      s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[s], s == 0 ? kZero16 : s0, 0, 0, 0);                              \
+      s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb_, qf[s], s == 0 ? kZero16 : s1, 0, 0, 0);                             \
     }                                                                                                                      \
     if ((kt + 1) * kAK > len) {                                                                                            \
       const int kbase = kt * kAK + 4 * hh;                                                                                 \

@@ -21,6 +21,7 @@
 
 namespace se {
 
+static constexpr f32x16 kZero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #define SE_TR(ptr) __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(ptr))
 
 // XCD-aware work mapping shared with the forward: all tiles of one (utterance, head) on ONE XCD (they re-read the same
@@ -136,17 +137,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
     const char* t_s = smem + cur * 16384;
     f32x16 s0, s1, p0, p1;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; p0[r] = 0.f; p1[r] = 0.f; }
-#pragma unroll
     for (int s = 0; s < 4; ++s) {
       const bf16x8 ka = *reinterpret_cast<const bf16x8*>(t_s + koff[s]);
       const bf16x8 kb_ = *reinterpret_cast<const bf16x8*>(t_s + koff[s] + 4096);
       const bf16x8 va = *reinterpret_cast<const bf16x8*>(t_s + 8192 + koff[s]);
       const bf16x8 vb = *reinterpret_cast<const bf16x8*>(t_s + 8192 + koff[s] + 4096);
-      s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[s], s0, 0, 0, 0);
-      s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb_, qf[s], s1, 0, 0, 0);
-      p0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, dof[s], p0, 0, 0, 0);
-      p1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb, dof[s], p1, 0, 0, 0);
+      // the first product of each chain takes the inline constant 0 as C (no v_mov per register to clear the accumulators)
+      s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[s], s == 0 ? kZero16 : s0, 0, 0, 0);
+      s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb_, qf[s], s == 0 ? kZero16 : s1, 0, 0, 0);
+      p0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, dof[s], s == 0 ? kZero16 : p0, 0, 0, 0);
+      p1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb, dof[s], s == 0 ? kZero16 : p1, 0, 0, 0);
     }
     if ((kt + 1) * kAK > len) {
       const int kbase = kt * kAK + 4 * hh;
@@ -331,13 +331,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
       // 32 qb + (r&3) + 8 (r>>2) + 4 hh
       f32x16 sa, da;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { sa[r] = 0.f; da[r] = 0.f; }
-#pragma unroll
       for (int s = 0; s < 4; ++s) {
         const bf16x8 qa = *reinterpret_cast<const bf16x8*>(t_s + koff[s] + qb * 4096);
         const bf16x8 oa = *reinterpret_cast<const bf16x8*>(t_s + 8192 + koff[s] + qb * 4096);
-        sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[s], sa, 0, 0, 0);
-        da = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oa, vf[s], da, 0, 0, 0);
+        sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[s], s == 0 ? kZero16 : sa, 0, 0, 0);
+        da = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oa, vf[s], s == 0 ? kZero16 : da, 0, 0, 0);
       }
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
