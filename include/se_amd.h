@@ -258,6 +258,10 @@ int se_wgrad_bf16(const uint16_t* dYt, const uint16_t* Xt, int Mp, int N, int K,
  * from row-major LDS panels with the hardware-transposed LDS read.  N, K, ldy, ldx multiples of 8; workspace >= splits*N*K floats. */
 int se_wgrad_tn_bf16(const uint16_t* dY, int ldy, const uint16_t* X, int ldx, int M, int N, int K, int splits, float* dW,
                      int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+/* per-group weight gradients (no reduce): slabs[g] (N, K) = dY[g R .. (g+1) R)^T . X[same rows], R = rows_per_slab -- with R = frames
+ * per utterance these are the PER-UTTERANCE gradients active sampling scores with (sampler.py:59-111) from one launch. */
+int se_wgrad_tn_slabs_bf16(const uint16_t* dY, int ldy, const uint16_t* X, int ldx, int M, int N, int K, int rows_per_slab,
+                           float* slabs, void* stream);
 /* bias gradient: out[c] (+)= sum_r x[r][c] */
 int se_colsum_f32(const float* x, int rows, int cols, int ld, float* out, int accumulate, void* stream);
 /* LayerNorm backward (TF style).  x_in = LayerNorm input (gelu_in: its pre-GELU value, i.e. y = LN(gelu(x_in)), and

@@ -82,6 +82,7 @@ SIGNATURES = {
     'se_transpose_f32_bf16': (c_int, [_P, c_int, c_int, c_int, _P, c_int, _P]),
     'se_wgrad_bf16': (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, c_int, _P, c_size_t, _P]),
     'se_wgrad_tn_bf16': (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, c_size_t, _P]),
+    'se_wgrad_tn_slabs_bf16': (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     'se_colsum_f32': (c_int, [_P, c_int, c_int, c_int, _P, c_int, _P]),
     'se_layernorm_bwd_f32': (c_int, [_P, _P, _P, c_int, c_int, c_float, c_int, _P, _P, _P, _P, c_int, _P]),
     'se_gelu_layernorm_f32': (c_int, [_P, _P, _P, c_int, c_int, c_float, _P, _P, _P]),

@@ -243,3 +243,31 @@ extern "C" int se_wgrad_tn_bf16(const uint16_t* dY, int ldy, const uint16_t* X, 
   SE_LAUNCH_CHECK();
   return SE_OK;
 }
+
+// Per-group weight gradients: slabs[g][N][K] = dY[g R .. (g+1) R)^T . X[same rows]  for g = 0 .. ceil(M / R) - 1 -- the m-split
+// slabs of the kernel above with the split boundaries put on utterance boundaries (R = frames per utterance) and NO reduce:
+// one launch gives every utterance's own gradient (active-sampling scoring, sampler.py:59-111, which the reference obtains by
+// B sequential backward passes with retain_graph).
+extern "C" int se_wgrad_tn_slabs_bf16(const uint16_t* dY, int ldy, const uint16_t* X, int ldx, int M, int N, int K, int rows_per_slab,
+                                      float* slabs, void* stream) {
+  SE_REQUIRE(dY && X && slabs, "se_wgrad_tn_slabs_bf16: null argument");
+  SE_REQUIRE(M > 0 && N > 0 && K > 0 && rows_per_slab > 0, "se_wgrad_tn_slabs_bf16: bad shape");
+  SE_REQUIRE(N % 8 == 0 && K % 8 == 0 && ldy % 8 == 0 && ldx % 8 == 0 && ldy >= N && ldx >= K,
+             "se_wgrad_tn_slabs_bf16: N, K and the leading dimensions must be multiples of 8");
+  SE_REQUIRE((((uintptr_t)dY | (uintptr_t)X | (uintptr_t)slabs) % 16) == 0, "se_wgrad_tn_slabs_bf16: operands must be 16-B aligned");
+  const int groups = (M + rows_per_slab - 1) / rows_per_slab;
+  SE_REQUIRE(groups <= 65535, "se_wgrad_tn_slabs_bf16: too many groups");
+  hipStream_t st = se::as_stream(stream);
+  static bool attr_set = false;
+  if (!attr_set) {
+    SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::wgrad_tn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, se::kWLds));
+    attr_set = true;
+  }
+  const int tiles_n = (N + se::kWN - 1) / se::kWN, tiles_k = (K + se::kWK - 1) / se::kWK;
+  const int tiles = tiles_n * tiles_k, work = tiles * groups;
+  se::ProfScope prof(se::kProfGemm, 2.0 * M * (double)N * K, st);
+  hipLaunchKernelGGL(se::wgrad_tn_kernel, dim3(work), dim3(512), se::kWLds, st, dY, ldy, X, ldx, M, N, K, rows_per_slab, tiles_k, tiles, work,
+                     slabs, (unsigned long long*)nullptr);
+  SE_LAUNCH_CHECK();
+  return SE_OK;
+}

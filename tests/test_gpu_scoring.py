@@ -1,0 +1,64 @@
+"""GPU parity of per-utterance gradient scoring (sampler.py:59-116): one batched backward sweep with
+per-utterance weight-gradient slabs vs the reference's procedure -- B sequential per-utterance backward passes -- run with
+fp64 autograd on the CPU oracle.  The forward runs on bf16 GEMM operands and the L1 gradient is a sign, so the bound is on
+the direction (cosine) and norm of each utterance's gradient and on the resulting matching scores, not element-wise."""
+import pytest
+import torch
+
+from oracle import encoder as oenc
+from oracle import heads as oheads
+from oracle import objective as oobj
+
+pytestmark = pytest.mark.gpu
+
+
+def test_wgrad_slabs_per_group(gpu):
+    from speech_enhancement_by_s3prl_amd import _lib as L
+    lib = L.load()
+    torch.manual_seed(0)
+    G, R, N, K = 5, 101, 256, 768
+    dY = torch.randn(G * R, N, device=gpu).bfloat16()
+    X = torch.randn(G * R, K, device=gpu).bfloat16()
+    slabs = torch.full((G, N, K), float('nan'), device=gpu)
+    L.check(lib.se_wgrad_tn_slabs_bf16(L.ptr(dY), N, L.ptr(X), K, G * R, N, K, R, L.ptr(slabs), L.stream()), 'slabs')
+    for g in range(G):
+        ref = dY[g * R:(g + 1) * R].double().T @ X[g * R:(g + 1) * R].double()
+        assert (slabs[g].double() - ref).abs().max().item() < 2e-5 * ref.abs().max().item() + 1e-4
+
+
+def test_per_sample_gradients_vs_sequential_autograd(gpu):
+    from speech_enhancement_by_s3prl_amd import pipeline, scoring
+    from speech_enhancement_by_s3prl_amd.heads import SpecHead
+    cfg = pipeline.make_config(layers=1)
+    ckpt = pipeline.synthetic_checkpoint(cfg, seed=12)
+    head = SpecHead(201, ckpt).to(gpu)
+    torch.manual_seed(7)
+    B, T = 4, 80
+    feats = torch.randn(B, T, 768)
+    tar = torch.rand(B, T, 201) + 0.05
+    lens = torch.tensor([80, 51, 17, 64])
+    got = scoring.per_sample_gradients(head, feats.to(gpu), tar.to(gpu), lens.to(gpu)).double().cpu()
+    names = [n for n, _ in head.named_parameters()]
+    assert got.shape == (B, sum(p.numel() for p in head.parameters()))
+    # the reference's procedure (sampler.py:84-109): one loss per utterance, one backward each, gradients flattened in
+    # named_parameters order
+    ocfg = oenc.Config(cfg)
+    sd = {k: v.double().clone().requires_grad_(True) for k, v in ckpt['SpecHead'].items()}
+    _, res = oheads.spec_head(feats.double(), sd, ocfg, log=True)
+    masks = (torch.arange(T)[None] < lens[:, None]).long()
+    ref = []
+    for b in range(B):
+        loss = oobj.l1(res['log_predicted'][b:b + 1], tar[b:b + 1].double(), masks[b:b + 1])
+        grads = torch.autograd.grad(loss, [sd[n.replace('spechead.', '')] for n in names], retain_graph=True)
+        ref.append(torch.cat([g.reshape(-1) for g in grads]))
+    ref = torch.stack(ref)
+    for b in range(B):
+        cos = torch.nn.functional.cosine_similarity(got[b], ref[b], dim=0).item()
+        ratio = (got[b].norm() / ref[b].norm()).item()
+        assert cos > 0.99, (b, cos)
+        assert abs(ratio - 1) < 0.05, (b, ratio)
+    # matching scores (sampler.py:113-116): keys = the 4 utterances, queries = the first two
+    m_got = scoring.matching(got[:2].float(), got.float())
+    m_ref = scoring.matching(ref[:2].float(), ref.float())
+    assert (m_got - m_ref).abs().max().item() < 0.02
+    assert torch.equal(scoring.thresholding(m_got), scoring.thresholding(m_ref))
