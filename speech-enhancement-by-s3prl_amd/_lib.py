@@ -101,6 +101,9 @@ SIGNATURES = {
     'se_bertadam_step_f32': (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, c_double, c_double, c_double, c_double, c_double, c_double, _P]),
     'se_mix_f32': (c_int, [_P, c_int, _P, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_float, c_float, _P, _P, _P]),
     'se_sisdr_f32': (c_int, [_P, _P, c_int, _P, c_int, c_float, _P, _P, _P]),
+    'se_lstm_fwd_bf16': (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P]),
+    'se_lstm_bwd_bf16': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
+    'se_colsum_bf16': (c_int, [_P, c_int, c_int, c_int, _P, _P]),
     'se_prof_enable': (c_int, [c_int]),
     'se_prof_reset': (c_int, []),
     'se_prof_read': (c_int, [c_int, POINTER(c_double), POINTER(c_double), POINTER(ctypes.c_longlong)]),

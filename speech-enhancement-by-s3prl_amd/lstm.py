@@ -1,0 +1,195 @@
+"""(Bi)LSTM downstream heads on the MI355X kernels: `LSTM` (model.py:37-59) -- the head the
+reference's scripts train (run_active.sh `--downstream LSTM`, pseudo_noise.yaml:50-53: hidden 256, 3 layers, bidirectional).
+
+Parameter names / shapes are nn.LSTM's (`lstm.weight_ih_l0`, `lstm.weight_hh_l0_reverse`, ...) and `scaling_layer.0.*`, so the
+reference's `--dckpt` checkpoints load unchanged.  hidden_size must be 256 (the kernels keep W_hh of one direction resident in
+one CU's registers + LDS).  Forward and backward run on libse_amd.so: input projections, the output linear and every gradient
+GEMM on the bf16 GEMM / TN weight-gradient kernels, the recurrence on se_lstm_fwd_bf16 / se_lstm_bwd_bf16.  No CPU fallback."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib
+from . import spechead_train as st
+
+_H = 256
+
+
+def _pad8k(d):          # GEMM reduction dims are multiples of 64
+    return (d + 63) // 64 * 64
+
+
+def _pack_hh_fwd(w_hh):
+    """(1024, 256) fp32 -> (128, 1024) int32: bf16 pairs (W[j][2kk], W[j][2kk+1])."""
+    w16 = w_hh.detach().to(torch.bfloat16).contiguous()                       # (1024, 256)
+    return w16.view(torch.int32).t().contiguous()                              # (1024, 128) -> (128, 1024)
+
+
+def _pack_hh_bwd(w_hh):
+    """(1024, 256) fp32 -> (4, 128, 256) int32: bf16 pairs (W[256q + 2jj][k], W[256q + 2jj + 1][k])."""
+    w16 = w_hh.detach().to(torch.bfloat16).view(4, 128, 2, _H)                  # [q][jj][e][k]
+    return w16.permute(0, 1, 3, 2).contiguous().view(torch.int32).squeeze(-1).contiguous()      # [q][jj][k]
+
+
+class _LSTMFn(torch.autograd.Function):
+    """nn.LSTM(batch_first=True) forward / backward.  apply(x, num_layers, ndir, *weights) with weights in nn.LSTM's
+    parameter order (per layer: w_ih, w_hh, b_ih, b_hh [, the same four for the reverse direction])."""
+
+    @staticmethod
+    def forward(ctx, x, num_layers, ndir, *weights):
+        lib = _lib.load()
+        if not x.is_cuda:
+            raise _lib.SEError('LSTM heads run on MI355X only (no CPU fallback)')
+        B, T, D = x.shape
+        M = B * T
+        dev = x.device
+        inp = x.reshape(M, D).float()
+        saved = []
+        Dp = _pad8k(D)
+        inp16 = F.pad(inp, (0, Dp - D)).to(torch.bfloat16).contiguous()          # layer-0 operand, zero padded to the GEMM K granule
+        for l in range(num_layers):
+            ws = weights[4 * ndir * l: 4 * ndir * (l + 1)]
+            K = inp16.shape[1]
+            xproj = torch.empty(ndir, M, 4 * _H, device=dev, dtype=torch.float32)
+            wp = torch.empty(ndir, 128, 4 * _H, device=dev, dtype=torch.int32)
+            for d in range(ndir):
+                w_ih, w_hh, b_ih, b_hh = ws[4 * d: 4 * d + 4]
+                if w_hh.shape != (4 * _H, _H):
+                    raise NotImplementedError(f'the LSTM kernels are built for hidden_size {_H} (pseudo_noise.yaml:50-58), got {tuple(w_hh.shape)}')
+                w16 = F.pad(w_ih.detach().float(), (0, K - w_ih.shape[1])).to(torch.bfloat16).contiguous()
+                bias = (b_ih.detach() + b_hh.detach()).float().contiguous()
+                _lib.check(lib.se_gemm_bf16(_lib.ptr(inp16), K, _lib.ptr(w16), K, _lib.ptr(bias), None, M, 4 * _H, K, 0, None,
+                                            _lib.ptr(xproj) + d * M * 4 * _H * 4, 4 * _H, _lib.stream()), 'se_gemm_bf16')
+                wp[d] = _pack_hh_fwd(w_hh)
+            h16 = torch.empty(M, ndir * _H, device=dev, dtype=torch.bfloat16)
+            gates = torch.empty(ndir, M, 4 * _H, device=dev, dtype=torch.float32)
+            cst = torch.empty(ndir, M, _H, device=dev, dtype=torch.float32)
+            _lib.check(lib.se_lstm_fwd_bf16(_lib.ptr(wp), _lib.ptr(xproj), B, T, ndir, _lib.ptr(h16), _lib.ptr(gates), _lib.ptr(cst), _lib.stream()),
+                       'se_lstm_fwd_bf16')
+            saved.append((inp16, h16, gates, cst))
+            inp16 = h16
+        ctx.saved = saved
+        ctx.meta = (B, T, D, num_layers, ndir)
+        ctx.weights = weights
+        return inp16.float().view(B, T, ndir * _H)
+
+    @staticmethod
+    def backward(ctx, d_out):
+        lib = _lib.load()
+        B, T, D, num_layers, ndir = ctx.meta
+        M = B * T
+        weights = ctx.weights
+        dev = d_out.device
+        dh = d_out.reshape(M, ndir * _H).contiguous().float()
+        grads = [None] * len(weights)
+        for l in range(num_layers - 1, -1, -1):
+            inp16, h16, gates, cst = ctx.saved[l]
+            ws = weights[4 * ndir * l: 4 * ndir * (l + 1)]
+            K = inp16.shape[1]
+            wq = torch.stack([_pack_hh_bwd(ws[4 * d + 1]) for d in range(ndir)]).contiguous()
+            dg = torch.empty(ndir, M, 4 * _H, device=dev, dtype=torch.bfloat16)
+            _lib.check(lib.se_lstm_bwd_bf16(_lib.ptr(wq), _lib.ptr(gates), _lib.ptr(cst), _lib.ptr(dh), ndir * _H, B, T, ndir, _lib.ptr(dg),
+                                            _lib.stream()), 'se_lstm_bwd_bf16')
+            hv = h16.view(B, T, ndir * _H)
+            dx = None
+            for d in range(ndir):
+                w_ih, w_hh, b_ih, b_hh = ws[4 * d: 4 * d + 4]
+                dgd = dg[d]                                                      # (M, 1024) bf16
+                # h of the previous step (in this direction's order), zero at the sequence start
+                hprev = torch.zeros(B, T, _H, device=dev, dtype=torch.bfloat16)
+                if d == 0:
+                    hprev[:, 1:] = hv[:, :-1, :_H]
+                else:
+                    hprev[:, :-1] = hv[:, 1:, _H:]
+                g_ih = st.wgrad_tn(dgd, inp16, 4 * _H, K)[:, :w_ih.shape[1]].contiguous()
+                g_hh = st.wgrad_tn(dgd, hprev.view(M, _H), 4 * _H, _H)
+                g_b = torch.empty(4 * _H, device=dev, dtype=torch.float32)
+                _lib.check(lib.se_colsum_bf16(_lib.ptr(dgd), M, 4 * _H, 4 * _H, _lib.ptr(g_b), _lib.stream()), 'se_colsum_bf16')
+                base = 4 * ndir * l + 4 * d
+                grads[base], grads[base + 1], grads[base + 2], grads[base + 3] = g_ih, g_hh, g_b, g_b.clone()
+                if l > 0:     # dx = sum over directions of dgates . W_ih ; the second direction rides the GEMM's residual input
+                    Din = ndir * _H
+                    wt = st.transpose_f32_bf16(w_ih.detach().float().contiguous(), 4 * _H)      # (Din, 1024) = W_ih^T
+                    nxt = torch.empty(M, Din, device=dev, dtype=torch.float32)
+                    _lib.check(lib.se_gemm_bf16(_lib.ptr(dgd), 4 * _H, _lib.ptr(wt), 4 * _H, None, _lib.ptr(dx), M, Din, 4 * _H, 0, None, _lib.ptr(nxt),
+                                                Din, _lib.stream()), 'se_gemm_bf16')
+                    dx = nxt
+            dh = dx
+        ctx.saved = None
+        return (None, None, None) + tuple(grads)
+
+
+class _DenseLogExpFn(torch.autograd.Function):
+    """scaling_layer (Linear, Identity activation) + LSTM.forward's epilogue (model.py:56-58): log_predicted = x W^T + b,
+    predicted = exp(log_predicted); bf16 GEMM, HIP backward incl. the gradient wrt x."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        lib = _lib.load()
+        lead, K = x.shape[:-1], x.shape[-1]
+        N = w.shape[0]
+        x16 = st.cast_bf16(x.reshape(-1, K))
+        M = x16.shape[0]
+        p = st._gemm(x16, st.cast_bf16(w.detach()), b.detach().contiguous().float(), M, N, K)
+        pred = torch.empty(M, N, device=x.device, dtype=torch.float32)
+        _lib.check(lib.se_spec_epilogue_f32(_lib.ptr(p), M * N, 1, _lib.SE_ACT['Identity'], 0.0, _lib.ptr(pred), None, _lib.stream()), 'se_spec_epilogue_f32')
+        ctx.save_for_backward(x16, p, w)
+        ctx.lead = lead
+        return pred.view(*lead, N), p.view(*lead, N)
+
+    @staticmethod
+    def backward(ctx, d_pred, d_logp):
+        lib = _lib.load()
+        x16, p, w = ctx.saved_tensors
+        M, K = x16.shape
+        N = p.shape[1]
+        NP = max(128, (N + 63) // 64 * 64)
+        dev = p.device
+        dp32 = torch.empty(M, N, device=dev, dtype=torch.float32)
+        dp16 = torch.empty(M, NP, device=dev, dtype=torch.bfloat16)
+        gp = None if d_pred is None else d_pred.reshape(M, N).contiguous().float()
+        gl = None if d_logp is None else d_logp.reshape(M, N).contiguous().float()
+        _lib.check(lib.se_spec_epilogue_bwd_f32(_lib.ptr(p), _lib.ptr(gp), _lib.ptr(gl), M, N, NP, 1, _lib.SE_ACT['Identity'], 0.0, _lib.ptr(dp32),
+                                                _lib.ptr(dp16), _lib.stream()), 'se_spec_epilogue_bwd_f32')
+        g_w = st.wgrad_tn(dp16, x16, NP, K)[:N].contiguous()
+        g_b = st.colsum(dp32)
+        wt = st.transpose_f32_bf16(w.detach().float().contiguous(), NP)             # (K, NP) = W^T zero padded
+        d_x = st._gemm(dp16, wt, None, M, K, NP).view(*ctx.lead, K)
+        return d_x, g_w, g_b
+
+
+class LSTM(nn.Module):
+    """model.py:37-59"""
+
+    def __init__(self, input_size=201, output_size=201, hidden_size=201, num_layers=3, bidirectional=False, activation='Identity', **kwargs):
+        super().__init__()
+        if hidden_size != _H:
+            raise NotImplementedError(f'the MI355X LSTM kernels are built for hidden_size {_H} (config/pseudo_noise.yaml:50-58), got {hidden_size}')
+        if activation != 'Identity':
+            raise NotImplementedError("LSTM head: only the reference's default activation 'Identity' is supported")
+        self.lstm = nn.LSTM(input_size=input_size, hidden_size=hidden_size, num_layers=num_layers, batch_first=True, bidirectional=bidirectional)
+        self.scaling_layer = nn.Sequential(nn.Linear(max(1, int(bidirectional) * 2) * hidden_size, output_size), nn.Identity())
+        self.bidirectional = bidirectional
+        self.num_layers = num_layers
+        self.init_weights()
+
+    def init_weights(self):
+        for name, param in self.named_parameters():
+            if 'weight_ih' in name or 'scaling_layer.0.weight' in name:
+                nn.init.xavier_uniform_(param.data)
+            elif 'weight_hh' in name:
+                nn.init.orthogonal_(param.data)
+            elif 'bias' in name:
+                nn.init.constant_(param.data, 0)
+
+    def _flat_weights(self):
+        ws = []
+        for l in range(self.num_layers):
+            for suffix in ([''] + (['_reverse'] if self.bidirectional else [])):
+                ws += [getattr(self.lstm, f'{n}_l{l}{suffix}') for n in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh')]
+        return ws
+
+    def forward(self, features, **kwargs):
+        h = _LSTMFn.apply(features, self.num_layers, 2 if self.bidirectional else 1, *self._flat_weights())
+        predicted, log_predicted = _DenseLogExpFn.apply(h, self.scaling_layer[0].weight, self.scaling_layer[0].bias)
+        return predicted, {'log_predicted': log_predicted}

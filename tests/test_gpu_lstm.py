@@ -1,0 +1,81 @@
+"""GPU parity of the (Bi)LSTM downstream head (model.py:37-59) against torch.nn.LSTM itself -- the very module
+the reference's head wraps -- run on the CPU in fp64 with the same parameters.  bf16 recurrent / projection weights and bf16
+h operands on the HIP side: bounds are relative L2 per tensor, stated at the asserts."""
+import copy
+
+import pytest
+import torch
+import torch.nn as nn
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_l2(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).norm() / b.norm()).item()
+
+
+class RefLSTM(nn.Module):      # the reference's class body (model.py:37-59), fp64 on the CPU
+    def __init__(self, input_size, output_size, hidden_size, num_layers, bidirectional):
+        super().__init__()
+        self.lstm = nn.LSTM(input_size=input_size, hidden_size=hidden_size, num_layers=num_layers, batch_first=True, bidirectional=bidirectional)
+        self.scaling_layer = nn.Sequential(nn.Linear(max(1, int(bidirectional) * 2) * hidden_size, output_size), nn.Identity())
+
+    def forward(self, features):
+        predicted, _ = self.lstm(features)
+        log_predicted = self.scaling_layer(predicted)
+        return log_predicted.exp(), log_predicted
+
+
+@pytest.mark.parametrize('B,T,D,layers,bidir', [(3, 50, 120, 3, True), (2, 37, 120, 2, False), (2, 1001, 120, 1, True)])
+def test_lstm_head_forward_backward_vs_torch(gpu, B, T, D, layers, bidir):
+    from speech_enhancement_by_s3prl_amd.lstm import LSTM
+    torch.manual_seed(B * 1000 + T)
+    head = LSTM(input_size=D, output_size=201, hidden_size=256, num_layers=layers, bidirectional=bidir)
+    with torch.no_grad():                      # non-zero biases, recurrent weights at a realistic scale
+        for n, p in head.named_parameters():
+            if 'bias' in n:
+                p.normal_(0, 0.05)
+            if 'scaling_layer.0.weight' in n:
+                p.mul_(0.3)
+    ref = RefLSTM(D, 201, 256, layers, bidir).double()
+    ref.load_state_dict({k: v.double() for k, v in head.state_dict().items()})       # same parameter names: checkpoints interchange
+    head = head.to(gpu)
+    feats = torch.randn(B, T, D)
+    G1, G2 = torch.randn(B, T, 201) * 0.1, torch.randn(B, T, 201)
+    pred, res = head(features=feats.to(gpu))
+    logp = res['log_predicted']
+    ((pred * G1.to(gpu)).sum() + (logp * G2.to(gpu)).sum()).backward()
+    rpred, rlogp = ref(feats.double())
+    ((rpred * G1.double()).sum() + (rlogp * G2.double()).sum()).backward()
+    assert rel_l2(logp, rlogp) < 1.5e-2
+    assert rel_l2(pred, rpred) < 2.5e-2
+    refp = dict(ref.named_parameters())
+    for n, p in head.named_parameters():
+        assert p.grad is not None, n
+        r = rel_l2(p.grad, refp[n].grad)
+        assert r < 4e-2, (n, r)
+
+
+def test_lstm_head_trains(gpu):
+    from speech_enhancement_by_s3prl_amd.lstm import LSTM
+    from speech_enhancement_by_s3prl_amd.objective import L1
+    from speech_enhancement_by_s3prl_amd.solver import get_optimizer
+    torch.manual_seed(0)
+    head = LSTM(input_size=120, output_size=201, hidden_size=256, num_layers=3, bidirectional=True).to(gpu)
+    opt = get_optimizer(list(head.named_parameters()), lr=1e-3, warmup_proportion=0.07, training_steps=100)
+    feats = torch.randn(2, 120, 120, device=gpu)
+    tar = torch.rand(2, 120, 201, device=gpu) + 0.05
+    lens = torch.tensor([120, 77], device=gpu)
+    crit = L1()
+    losses = []
+    for _ in range(8):
+        pred, res = head(features=feats)
+        loss, _ = crit(log_predicted=res['log_predicted'], linear_tar=tar, stft_lengths=lens)
+        loss.backward()
+        gn = torch.nn.utils.clip_grad_norm_(list(head.parameters()), 1.0)
+        assert torch.isfinite(gn)
+        opt.step()
+        opt.zero_grad()
+        losses.append(loss.item())
+    assert losses[-1] < losses[0], losses
