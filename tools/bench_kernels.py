@@ -84,6 +84,24 @@ def bench_wgrad():
         print(line, flush=True)
 
 
+def bench_lstm():
+    """the reference's LSTM head at its configured size (pseudo_noise.yaml:50-53), B = 32 x 10 s: forward and forward + backward"""
+    from speech_enhancement_by_s3prl_amd.lstm import LSTM
+    head = LSTM(input_size=120, output_size=201, hidden_size=256, num_layers=3, bidirectional=True).to(dev)
+    feats = torch.randn(32, 1001, 120, device=dev)
+    G = torch.randn(32, 1001, 201, device=dev)
+
+    def fwd():
+        with torch.no_grad():
+            head(features=feats)
+
+    def fwd_bwd():
+        pred, res = head(features=feats)
+        (res['log_predicted'] * G).sum().backward()
+        head.zero_grad()
+    print(f'LSTM head 3 x BiLSTM-256, B=32 T=1001: forward {timeit(fwd, iters=5, warm=2):8.2f} ms   forward+backward {timeit(fwd_bwd, iters=5, warm=2):8.2f} ms', flush=True)
+
+
 def bench_gemm_ln():
     M, N = 32 * 1001, 768
     for K in (768, 3072):
@@ -138,3 +156,5 @@ if __name__ == '__main__':
         bench_stft()
     if what in ('wgrad',):
         bench_wgrad()
+    if what in ('lstm',):
+        bench_lstm()
