@@ -149,12 +149,14 @@ int se_head_linear_f32(const float* feats, const float* W, const float* bias, co
 
 /*
  * se_head_linear_bwd_f32 -- autograd of C1/C2 wrt the head parameters (runner.py:459 loss.backward()):
- *   given d_offset-pre-activation gradient inputs:  grad_predicted (B,F,N), linears (or NULL), offset (B,F,N)
+ *   inputs: grad_predicted (B,F,N) = d loss / d predicted and / or grad_offset (B,F,N) = d loss / d offset (either may be NULL:
+ *   L1 / SISDR score `predicted`, WSD scores the mask `offset`), linears (or NULL), offset (B,F,N);
+ *   g_pre = (grad_predicted (.) linears + grad_offset) (.) act'(offset)
  *   computes gW (N, D) and gb (N) (accumulated over all frames of all utterances; zeroed inside).
  *   Needs the same feats / cmvn / eps as the forward (the normalised features are recomputed).
  */
 int se_head_linear_bwd_f32(const float* feats, const float* linears, const float* offset, const float* grad_predicted,
-                           int B, int F, int D, int N, int act, int cmvn, float eps,
+                           const float* grad_offset, int B, int F, int D, int N, int act, int cmvn, float eps,
                            float* gW, float* gb, void* workspace, size_t workspace_bytes, void* stream);
 
 /*
@@ -365,6 +367,23 @@ int se_lstm_bwd_bf16(const uint32_t* w_hh_gate_pairs, const float* gates, const 
                      int ndir, uint16_t* dgates_out, void* stream);
 /* column sums of a bf16 matrix (bias gradients): out[c] = sum_r x[r][c]; cols and ld multiples of 8 */
 int se_colsum_bf16(const uint16_t* x, int rows, int cols, int ld, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Spectrogram-domain criteria besides L1: what the mask heads are trained with.
+ * frame_lengths (B) int64 = valid frames per utterance (the stft_length_masks of runner.py:216-220 as counts).
+ * ---------------------------------------------------------------------------------------------- */
+/* objective.SISDR (objective.py:81-100): loss_b[b] per utterance (the criterion is their mean over the batch); grad (B,F,N),
+ * optional, = grad_scale * d loss_b / d predicted (pass 1/B, or 1/global_B under data parallelism). scratch: device double[5 B]. */
+int se_sisdr_spec_f32(const float* predicted, const float* linear_tar, const int64_t* frame_lengths, int B, int F, int N, float eps,
+                      float grad_scale, double* scratch, float* loss_b, float* grad, void* stream);
+/* objective.WSD (objective.py:119-153) in two steps, so that a data-parallel caller can all-reduce(MAX) the batch-wide energy
+ * maximum in between: energy (B*F) = sum_n linear_tar, energy_max (1 float) = its maximum over every frame of the batch; then
+ * sums[0..1] = (sum_b speech_b, sum_b noise_b) (device double[3]) and grad (optional) = grad_scale * d(alpha sums[0] +
+ * (1 - alpha) sums[1]) / d offset. */
+int se_wsd_energy_f32(const float* linear_tar, int B, int F, int N, float* energy, float* energy_max, void* stream);
+int se_wsd_f32(const float* linear_inp, const float* offset, const float* linear_tar, const int64_t* frame_lengths, const float* energy,
+               const float* energy_max, int B, int F, int N, float alpha, float db_interval, float eps, float grad_scale, double* sums,
+               float* grad, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Optional in-library timing for bench.py's roofline leg: HIP events recorded on the launch stream around

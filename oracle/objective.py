@@ -32,6 +32,19 @@ def sisdr_objective(predicted, linear_tar, stft_length_masks, eps=1e-10):
     return loss.mean()
 
 
+def wsd_objective(linear_inp, offset, linear_tar, stft_length_masks, alpha=0.5, db_interval=30, eps=1e-10):
+    """objective.py:119-153 (without the TensorBoard logger)"""
+    S, G = linear_tar, offset
+    N = torch.clamp(linear_inp - linear_tar, min=0.0)
+    energy = S.sum(dim=-1, keepdim=True)
+    db_thres = 10 * torch.log10(energy.max() + eps) - db_interval
+    voice_mask = ((10 * torch.log10(energy + eps)) > db_thres).to(S.dtype)
+    m = stft_length_masks.unsqueeze(-1).to(S.dtype)
+    speech_loss = ((S - G * S) * voice_mask * m).pow(2).sum(-1).sum(-1).mean()
+    noise_loss = (G * N * m).pow(2).sum(-1).sum(-1).mean()
+    return alpha * speech_loss + (1 - alpha) * noise_loss
+
+
 def sisdr_eval(src, tar, eps=1e-10):
     """evaluation.py:5-10"""
     alpha = (src * tar).sum() / ((tar * tar).sum() + eps)

@@ -65,7 +65,7 @@ SIGNATURES = {
     'se_length_masks_i64': (c_int, [_P, c_int, c_int, _P, _P]),
     'se_head_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int]),
     'se_head_linear_f32': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P, _P, _P, c_size_t, _P]),
-    'se_head_linear_bwd_f32': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P, _P, _P, c_size_t, _P]),
+    'se_head_linear_bwd_f32': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P, _P, _P, c_size_t, _P]),
     'se_l1_masked_f32': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_float, _P, _P, _P]),
     'se_encoder_create': (c_int, [POINTER(EncoderConfig), POINTER(EncoderWeights), POINTER(_P)]),
     'se_encoder_destroy': (None, [_P]),
@@ -104,6 +104,9 @@ SIGNATURES = {
     'se_lstm_fwd_bf16': (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P]),
     'se_lstm_bwd_bf16': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     'se_colsum_bf16': (c_int, [_P, c_int, c_int, c_int, _P, _P]),
+    'se_sisdr_spec_f32': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_float, c_float, _P, _P, _P, _P]),
+    'se_wsd_energy_f32': (c_int, [_P, c_int, c_int, c_int, _P, _P, _P]),
+    'se_wsd_f32': (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, c_float, c_float, c_float, _P, _P, _P]),
     'se_prof_enable': (c_int, [c_int]),
     'se_prof_reset': (c_int, []),
     'se_prof_read': (c_int, [c_int, POINTER(c_double), POINTER(c_double), POINTER(ctypes.c_longlong)]),

@@ -1,5 +1,5 @@
 // head_bwd.hip -- autograd of rows C1 / C2 wrt the head parameters (runner.py:459 loss.backward()):
-//   g_pre = grad_predicted (.) linears (.) act'(offset);   gW[n][d] = sum_rows g_pre[row][n] xn[row][d];  gb[n] = sum_rows g_pre[row][n]
+//   g_pre = (grad_predicted (.) linears + grad_offset) (.) act'(offset);   gW[n][d] = sum_rows g_pre[row][n] xn[row][d];  gb[n] = sum_rows g_pre[row][n]
 // (xn = CMVN-normalised features, recomputed from the forward's statistics; the normalisation has no parameters).
 // A long-K reduction (K = B*F rows) done in exact fp32 on v_mfma_f32_32x32x2_f32: each workgroup reduces 256 rows
 // into NT x 4 accumulator tiles (n-tiles x 128 feature dims) and adds them to gW with one fp32 atomic per element
@@ -25,7 +25,7 @@ __device__ __forceinline__ float act_grad_from_out(float o, int act) {
 template <int NT>
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ feats, const float* __restrict__ linears,
                                                        const float* __restrict__ offset, const float* __restrict__ gp,
-                                                       const float* __restrict__ stats, int rows, int F, int D, int N, int act,
+                                                       const float* __restrict__ goff, const float* __restrict__ stats, int rows, int F, int D, int N, int act,
                                                        float* __restrict__ gW, float* __restrict__ gb) {
   constexpr int GP = NT * 32 + 1;     // odd pitches
   constexpr int XP = kBD + 1;
@@ -49,8 +49,10 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
       float g = 0.f;
       if (row < rows && n < N) {
         const size_t idx = (size_t)row * N + n;
-        g = gp[idx] * act_grad_from_out(offset[idx], act);
+        g = gp ? gp[idx] : 0.f;                      // d loss / d predicted, predicted = linears (.) offset
         if (linears) g *= linears[idx];
+        if (goff) g += goff[idx];                      // d loss / d offset directly (WSD scores the mask itself)
+        g *= act_grad_from_out(offset[idx], act);
       }
       Gs[r * GP + n] = g;
     }
@@ -109,18 +111,18 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
 extern "C" int se_head_colstats_f32(const float* feats, int B, int F, int D, float eps, float* stats, void* stream);
 
 template <int NT>
-static int launch_bwd(const float* feats, const float* linears, const float* offset, const float* gp, const float* stats,
+static int launch_bwd(const float* feats, const float* linears, const float* offset, const float* gp, const float* goff, const float* stats,
                       int rows, int F, int D, int N, int act, float* gW, float* gb, hipStream_t st) {
   dim3 grid((rows + se::kBR - 1) / se::kBR, (D + se::kBD - 1) / se::kBD);
-  hipLaunchKernelGGL((se::head_bwd_kernel<NT>), grid, dim3(256), 0, st, feats, linears, offset, gp, stats, rows, F, D, N, act, gW, gb);
+  hipLaunchKernelGGL((se::head_bwd_kernel<NT>), grid, dim3(256), 0, st, feats, linears, offset, gp, goff, stats, rows, F, D, N, act, gW, gb);
   SE_LAUNCH_CHECK();
   return SE_OK;
 }
 
 extern "C" int se_head_linear_bwd_f32(const float* feats, const float* linears, const float* offset, const float* grad_predicted,
-                                      int B, int F, int D, int N, int act, int cmvn, float eps,
+                                      const float* grad_offset, int B, int F, int D, int N, int act, int cmvn, float eps,
                                       float* gW, float* gb, void* workspace, size_t workspace_bytes, void* stream) {
-  SE_REQUIRE(feats && offset && grad_predicted && gW && gb, "se_head_linear_bwd_f32: null argument");
+  SE_REQUIRE(feats && offset && (grad_predicted || grad_offset) && gW && gb, "se_head_linear_bwd_f32: null argument");
   SE_REQUIRE(B > 0 && F >= 2 && D > 0 && N > 0 && N <= 256, "se_head_linear_bwd_f32: bad shape (N <= 256)");
   SE_REQUIRE(act == SE_ACT_IDENTITY || act == SE_ACT_RELU || act == SE_ACT_SIGMOID || act == SE_ACT_EXP,
              "se_head_linear_bwd_f32: activation %d has no output-only derivative", act);
@@ -136,13 +138,13 @@ extern "C" int se_head_linear_bwd_f32(const float* feats, const float* linears, 
   }
   const int rows = B * F;
   switch ((N + 31) / 32) {
-    case 1: return launch_bwd<1>(feats, linears, offset, grad_predicted, stats, rows, F, D, N, act, gW, gb, st);
-    case 2: return launch_bwd<2>(feats, linears, offset, grad_predicted, stats, rows, F, D, N, act, gW, gb, st);
-    case 3: return launch_bwd<3>(feats, linears, offset, grad_predicted, stats, rows, F, D, N, act, gW, gb, st);
-    case 4: return launch_bwd<4>(feats, linears, offset, grad_predicted, stats, rows, F, D, N, act, gW, gb, st);
-    case 5: return launch_bwd<5>(feats, linears, offset, grad_predicted, stats, rows, F, D, N, act, gW, gb, st);
-    case 6: return launch_bwd<6>(feats, linears, offset, grad_predicted, stats, rows, F, D, N, act, gW, gb, st);
-    case 7: return launch_bwd<7>(feats, linears, offset, grad_predicted, stats, rows, F, D, N, act, gW, gb, st);
-    default: return launch_bwd<8>(feats, linears, offset, grad_predicted, stats, rows, F, D, N, act, gW, gb, st);
+    case 1: return launch_bwd<1>(feats, linears, offset, grad_predicted, grad_offset, stats, rows, F, D, N, act, gW, gb, st);
+    case 2: return launch_bwd<2>(feats, linears, offset, grad_predicted, grad_offset, stats, rows, F, D, N, act, gW, gb, st);
+    case 3: return launch_bwd<3>(feats, linears, offset, grad_predicted, grad_offset, stats, rows, F, D, N, act, gW, gb, st);
+    case 4: return launch_bwd<4>(feats, linears, offset, grad_predicted, grad_offset, stats, rows, F, D, N, act, gW, gb, st);
+    case 5: return launch_bwd<5>(feats, linears, offset, grad_predicted, grad_offset, stats, rows, F, D, N, act, gW, gb, st);
+    case 6: return launch_bwd<6>(feats, linears, offset, grad_predicted, grad_offset, stats, rows, F, D, N, act, gW, gb, st);
+    case 7: return launch_bwd<7>(feats, linears, offset, grad_predicted, grad_offset, stats, rows, F, D, N, act, gW, gb, st);
+    default: return launch_bwd<8>(feats, linears, offset, grad_predicted, grad_offset, stats, rows, F, D, N, act, gW, gb, st);
   }
 }

@@ -14,8 +14,9 @@ from .transformer import TRANSFORMER, TransformerConfig, TransformerSpecPredicti
 
 class _HeadLinearFn(torch.autograd.Function):
     """offset = act(norm(x) W^T + b); predicted = linears * offset.  Forward: se_head_linear_f32,
-    backward wrt (W, b): se_head_linear_bwd_f32.  Gradients wrt features / linears are not needed by the
-    reference (only downstream parameters are optimised, runner.py:110-115) and are not produced."""
+    backward wrt (W, b): se_head_linear_bwd_f32, from the gradient of `predicted` (L1 / SISDR) and / or of the mask `offset`
+    itself (WSD).  Gradients wrt features / linears are not needed by the reference (only downstream parameters are
+    optimised, runner.py:110-115) and are not produced."""
 
     @staticmethod
     def forward(ctx, feats, linears, weight, bias, act, cmvn, eps):
@@ -34,22 +35,22 @@ class _HeadLinearFn(torch.autograd.Function):
                                           _lib.stream()), 'se_head_linear_f32')
         ctx.save_for_backward(feats, lin if lin is not None else torch.empty(0, device=feats.device), offset)
         ctx.meta = (act, int(cmvn), float(eps), lin is not None, weight.shape)
-        ctx.mark_non_differentiable(offset)
         return predicted, offset
 
     @staticmethod
-    def backward(ctx, grad_predicted, _grad_offset):
+    def backward(ctx, grad_predicted, grad_offset):
         lib = _lib.load()
         feats, lin, offset = ctx.saved_tensors
         act, cmvn, eps, has_lin, wshape = ctx.meta
         B, F, D = feats.shape
         N = wshape[0]
-        gp = grad_predicted.contiguous().float()
+        gp = None if grad_predicted is None else grad_predicted.contiguous().float()
+        go = None if grad_offset is None else grad_offset.contiguous().float()
         gW = torch.empty(N, D, device=feats.device, dtype=torch.float32)
         gb = torch.empty(N, device=feats.device, dtype=torch.float32)
         nbytes = lib.se_head_workspace_bytes(B, F, D, N)
         ws = torch.empty(nbytes, device=feats.device, dtype=torch.uint8)
-        _lib.check(lib.se_head_linear_bwd_f32(_lib.ptr(feats), _lib.ptr(lin) if has_lin else None, _lib.ptr(offset), _lib.ptr(gp),
+        _lib.check(lib.se_head_linear_bwd_f32(_lib.ptr(feats), _lib.ptr(lin) if has_lin else None, _lib.ptr(offset), _lib.ptr(gp), _lib.ptr(go),
                                               B, F, D, N, act, cmvn, eps, _lib.ptr(gW), _lib.ptr(gb), _lib.ptr(ws), nbytes,
                                               _lib.stream()), 'se_head_linear_bwd_f32')
         return None, None, gW, gb, None, None, None

@@ -48,3 +48,88 @@ class L1(nn.Module):
             stft_lengths = stft_length_masks.sum(dim=-1)
         loss = _L1Fn.apply(log_predicted, linear_tar, stft_lengths, self.eps, self.reduce_fn)
         return loss, {}
+
+
+def _frame_lengths(stft_length_masks, stft_lengths, device):
+    if stft_lengths is None:
+        stft_lengths = stft_length_masks.sum(dim=-1)
+    return stft_lengths.to(device=device, dtype=torch.int64).contiguous()
+
+
+class _SISDRFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, predicted, linear_tar, lens, eps, reduce_fn):
+        lib = _lib.load()
+        p, t = predicted.contiguous().float(), linear_tar.contiguous().float()
+        B, F, N = p.shape
+        scratch = torch.empty(5 * B, device=p.device, dtype=torch.float64)
+        loss_b = torch.empty(B, device=p.device, dtype=torch.float32)
+        grad = torch.empty_like(p) if predicted.requires_grad else None
+        _lib.check(lib.se_sisdr_spec_f32(_lib.ptr(p), _lib.ptr(t), _lib.ptr(lens), B, F, N, float(eps), 1.0, _lib.ptr(scratch), _lib.ptr(loss_b),
+                                         _lib.ptr(grad), _lib.stream()), 'se_sisdr_spec_f32')
+        sums = torch.stack([loss_b.double().sum(), torch.tensor(float(B), device=p.device, dtype=torch.float64)])
+        if reduce_fn is not None:
+            sums = reduce_fn(sums)          # (sum of per-utterance losses, utterance count) across ranks: a global mean over utterances
+        ctx.save_for_backward(grad if grad is not None else torch.empty(0), sums)
+        return (sums[0] / sums[1]).float()
+
+    @staticmethod
+    def backward(ctx, g):
+        grad, sums = ctx.saved_tensors
+        return grad * (g / sums[1].float()), None, None, None, None
+
+
+class SISDR(nn.Module):
+    """objective.py:81-100: scale-invariant SDR between sqrt-power spectrograms, mean over the utterances of the batch."""
+
+    def __init__(self, eps=1e-10, **kwargs):
+        super().__init__()
+        self.eps = eps
+        self.reduce_fn = None
+
+    def forward(self, predicted, linear_tar, stft_length_masks=None, stft_lengths=None, **kwargs):
+        lens = _frame_lengths(stft_length_masks, stft_lengths, predicted.device)
+        return _SISDRFn.apply(predicted, linear_tar, lens, self.eps, self.reduce_fn), {}
+
+
+class _WSDFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, linear_inp, offset, linear_tar, lens, alpha, db_interval, eps, reduce_fn, max_reduce_fn):
+        lib = _lib.load()
+        inp, off, tar = linear_inp.contiguous().float(), offset.contiguous().float(), linear_tar.contiguous().float()
+        B, F, N = off.shape
+        dev = off.device
+        energy = torch.empty(B * F, device=dev, dtype=torch.float32)
+        emax = torch.empty(1, device=dev, dtype=torch.float32)
+        _lib.check(lib.se_wsd_energy_f32(_lib.ptr(tar), B, F, N, _lib.ptr(energy), _lib.ptr(emax), _lib.stream()), 'se_wsd_energy_f32')
+        if max_reduce_fn is not None:
+            emax = max_reduce_fn(emax)      # the reference's threshold is relative to the loudest frame of the WHOLE batch
+        sums = torch.empty(3, device=dev, dtype=torch.float64)
+        grad = torch.empty_like(off) if offset.requires_grad else None
+        _lib.check(lib.se_wsd_f32(_lib.ptr(inp), _lib.ptr(off), _lib.ptr(tar), _lib.ptr(lens), _lib.ptr(energy), _lib.ptr(emax), B, F, N, float(alpha),
+                                  float(db_interval), float(eps), 1.0, _lib.ptr(sums), _lib.ptr(grad), _lib.stream()), 'se_wsd_f32')
+        tot = torch.stack([alpha * sums[0] + (1.0 - alpha) * sums[1], torch.tensor(float(B), device=dev, dtype=torch.float64)])
+        if reduce_fn is not None:
+            tot = reduce_fn(tot)
+        ctx.save_for_backward(grad if grad is not None else torch.empty(0), tot)
+        return (tot[0] / tot[1]).float()
+
+    @staticmethod
+    def backward(ctx, g):
+        grad, tot = ctx.saved_tensors
+        return None, grad * (g / tot[1].float()), None, None, None, None, None, None, None
+
+
+class WSD(nn.Module):
+    """objective.py:119-153: weighted speech-distortion loss on the mask (`offset`), without the TensorBoard logger."""
+
+    def __init__(self, alpha=0.5, db_interval=30, eps=1e-10, **kwargs):
+        super().__init__()
+        self.alpha, self.db_interval, self.eps = alpha, db_interval, eps
+        self.reduce_fn = None
+        self.max_reduce_fn = None
+
+    def forward(self, linear_inp, offset, linear_tar, stft_length_masks=None, stft_lengths=None, **kwargs):
+        lens = _frame_lengths(stft_length_masks, stft_lengths, offset.device)
+        loss = _WSDFn.apply(linear_inp, offset, linear_tar, lens, self.alpha, self.db_interval, self.eps, self.reduce_fn, self.max_reduce_fn)
+        return loss, {}

@@ -8,7 +8,7 @@ called.  Inputs are seeded synthetic tensors; inputs + outputs are written to
 tests/golden/reference_golden.npz (small: B=3, T=16, 201 bins).
 
 Rows pinned: C1 LinearResidual, C2 Linear, D1 length masks,
-D2 masked_mean / masked_normalize_decibel, E1 L1, SISDR objective, add_noise,
+D2 masked_mean / masked_normalize_decibel, E1 L1, SISDR and WSD objectives (values and gradients), add_noise,
 OnlineDataset.normalize_wav_decibel, OnlineDataset.collate_fn, sampler.matching,
 evaluation.sisdr_eval.
 
@@ -156,6 +156,18 @@ def main():
     a = torch.randn(3000, generator=g)
     b = a + 0.3 * torch.randn(3000, generator=g)
     out.update(se_src=b, se_tar=a, se_val=torch.tensor(ref_eval.sisdr_eval(b, a)))
+
+    # ---- appended (new generator draws only AFTER everything above, so the older entries keep their values):
+    # SISDR gradient wrt predicted and WSD value / gradient wrt offset (objective.py:81-100, 119-153)
+    pred_leaf = (linears.detach().clone() * (torch.rand(B, T, K, generator=g) + 0.5)).requires_grad_(True)
+    sis2, _ = ref_objective.SISDR()(predicted=pred_leaf, linear_tar=linear_tar, stft_length_masks=masks)
+    sis2.backward()
+    out.update(sis_pred=pred_leaf.detach(), sis_loss=sis2.detach(), sis_grad=pred_leaf.grad.clone())
+    off_leaf = torch.rand(B, T, K, generator=g).requires_grad_(True)
+    lin_inp = linear_tar + 0.3 * torch.randn(B, T, K, generator=g).abs() * torch.rand(B, T, K, generator=g).round()   # noisy >= clean on ~half the bins
+    wsd, _ = ref_objective.WSD()(linear_inp=lin_inp, offset=off_leaf, linear_tar=linear_tar, stft_length_masks=masks)
+    wsd.backward()
+    out.update(wsd_inp=lin_inp, wsd_offset=off_leaf.detach(), wsd_loss=wsd.detach(), wsd_grad=off_leaf.grad.clone())
 
     np.savez_compressed(OUT, **{k: (v.detach().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in out.items()})
     print('wrote', OUT, {k: tuple(np.asarray(v).shape) for k, v in out.items()})

@@ -59,6 +59,20 @@ def test_sisdr_objective_and_eval_and_matching(golden):
     assert torch.allclose(oobj.matching(T(golden['match_q']), T(golden['match_k'])), T(golden['match_scores']), rtol=1e-5, atol=1e-7)
 
 
+def test_sisdr_gradient_and_wsd(golden):
+    """appended fixtures: the oracle's SISDR / WSD against the reference's values and autograd gradients"""
+    pred = T(golden['sis_pred']).clone().requires_grad_(True)
+    v = oobj.sisdr_objective(pred, T(golden['e1_linear_tar']), T(golden['d1_masks']))
+    v.backward()
+    assert torch.allclose(v.detach(), T(golden['sis_loss']), rtol=1e-5)
+    assert torch.allclose(pred.grad, T(golden['sis_grad']), rtol=1e-4, atol=1e-7)
+    off = T(golden['wsd_offset']).clone().requires_grad_(True)
+    w = oobj.wsd_objective(T(golden['wsd_inp']), off, T(golden['e1_linear_tar']), T(golden['d1_masks']))
+    w.backward()
+    assert torch.allclose(w.detach(), T(golden['wsd_loss']), rtol=1e-5)
+    assert torch.allclose(off.grad, T(golden['wsd_grad']), rtol=1e-4, atol=1e-6)
+
+
 def test_input_contract_add_noise_collate(golden):
     """the synthetic-input generator restates dataset.py:54-74,106-111,169-179 exactly"""
     from speech_enhancement_by_s3prl_amd import synth
