@@ -158,6 +158,12 @@ int se_head_linear_f32(const float* feats, const float* W, const float* bias, co
 int se_head_linear_bwd_f32(const float* feats, const float* linears, const float* offset, const float* grad_predicted,
                            const float* grad_offset, int B, int F, int D, int N, int act, int cmvn, float eps,
                            float* gW, float* gb, void* workspace, size_t workspace_bytes, void* stream);
+/* gradient wrt the FEATURES of the same head (needed when it sits on a trainable stack: the Residual head's LSTM, model.py:62-91):
+ *   dx (B,F,D) = CMVN'( g_pre . W ), g_pre as above; the product runs on the bf16 GEMM.  workspace: se_head_dx_workspace_bytes. */
+size_t se_head_dx_workspace_bytes(int B, int F, int D, int N);
+int se_head_linear_dx_f32(const float* feats, const float* linears, const float* offset, const float* grad_predicted,
+                          const float* grad_offset, const float* W, int B, int F, int D, int N, int act, int cmvn, float eps,
+                          float* dx, void* workspace, size_t workspace_bytes, void* stream);
 
 /*
  * se_l1_masked_f32 -- row E1: L1.forward (objective.py:103-117) in un-normalised form:

@@ -4,6 +4,7 @@
 // A long-K reduction (K = B*F rows) done in exact fp32 on v_mfma_f32_32x32x2_f32: each workgroup reduces 256 rows
 // into NT x 4 accumulator tiles (n-tiles x 128 feature dims) and adds them to gW with one fp32 atomic per element
 // (256-B contiguous per wave-instruction).  Summation order across workgroups is not fixed (atomics).
+#include <algorithm>
 #include "common.h"
 
 namespace se {
@@ -105,6 +106,59 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
   if (blockIdx.y == 0 && tid < NT * 32 && tid < N) atomicAdd(&gb[tid], gb_acc);
 }
 
+// g_pre = (grad_predicted (.) linears + grad_offset) (.) act'(offset) as a bf16 GEMM operand (M, ldp), columns N.. zeroed
+__global__ __launch_bounds__(256) void head_gpre_kernel(const float* __restrict__ linears, const float* __restrict__ offset,
+                                                        const float* __restrict__ gp, const float* __restrict__ goff, size_t rows, int N, int ldp,
+                                                        int act, uint16_t* __restrict__ out) {
+  const size_t n = rows * (size_t)ldp;
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const size_t r = i / ldp;
+    const int c = (int)(i - r * ldp);
+    float g = 0.f;
+    if (c < N) {
+      const size_t idx = r * N + c;
+      g = gp ? gp[idx] : 0.f;
+      if (linears) g *= linears[idx];
+      if (goff) g += goff[idx];
+      g *= act_grad_from_out(offset[idx], act);
+    }
+    __bf16 h = (__bf16)g;
+    out[i] = __builtin_bit_cast(uint16_t, h);
+  }
+}
+
+// backward of the CMVN over time y = (x - mean_t x) / (std_t x + eps) (unbiased std), in place on g (B, F, D):
+//   dx = r (g - mean_t g) - (x - mu) r^2 / (s (F - 1)) sum_t g_t (x_t - mu),   r = 1 / (s + eps)  [stats = (mu, r) per (b, d)]
+__global__ __launch_bounds__(256) void cmvn_time_bwd_kernel(const float* __restrict__ x, const float* __restrict__ stats, int F, int D, float eps,
+                                                            float* __restrict__ g) {
+  __shared__ float red[2][4][64];
+  const int b = blockIdx.y, d = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+  const bool ok = d < D;
+  const float mu = ok ? stats[((size_t)b * D + d) * 2] : 0.f, r = ok ? stats[((size_t)b * D + d) * 2 + 1] : 0.f;
+  const size_t base = (size_t)b * F * D + d;
+  float s0 = 0.f, s1 = 0.f;
+  if (ok)
+    for (int t = rg; t < F; t += 4) {
+      const float gv = g[base + (size_t)t * D];
+      s0 += gv;
+      s1 += gv * (x[base + (size_t)t * D] - mu);
+    }
+  red[0][rg][threadIdx.x & 63] = s0;
+  red[1][rg][threadIdx.x & 63] = s1;
+  __syncthreads();
+  const int c = threadIdx.x & 63;
+  const float sg = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
+  const float sgx = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
+  if (!ok) return;
+  const float sd = 1.f / r - eps;                       // the standard deviation itself
+  const float k2 = sd > 0.f ? r * r / (sd * (float)(F - 1)) * sgx : 0.f;
+  const float mg = sg / (float)F;
+  for (int t = rg; t < F; t += 4) {
+    const size_t o = base + (size_t)t * D;
+    g[o] = r * (g[o] - mg) - (x[o] - mu) * k2;
+  }
+}
+
 }  // namespace se
 
 // defined in head.hip
@@ -147,4 +201,44 @@ extern "C" int se_head_linear_bwd_f32(const float* feats, const float* linears, 
     case 7: return launch_bwd<7>(feats, linears, offset, grad_predicted, grad_offset, stats, rows, F, D, N, act, gW, gb, st);
     default: return launch_bwd<8>(feats, linears, offset, grad_predicted, grad_offset, stats, rows, F, D, N, act, gW, gb, st);
   }
+}
+
+extern "C" size_t se_head_dx_workspace_bytes(int B, int F, int D, int N) {
+  const size_t M = (size_t)B * F, NP = ((size_t)N + 63) / 64 * 64;
+  return se_head_workspace_bytes(B, F, D, N) + M * NP * 2 + 256 + (size_t)D * NP * 2 + 256;
+}
+
+// d loss / d features of rows C1 / C2 (needed when the head sits on top of a trainable stack: the Residual head's LSTM):
+//   dx = CMVN'( g_pre . W ),   g_pre as in se_head_linear_bwd_f32.  The product runs on the bf16 GEMM.
+extern "C" int se_head_linear_dx_f32(const float* feats, const float* linears, const float* offset, const float* grad_predicted,
+                                     const float* grad_offset, const float* W, int B, int F, int D, int N, int act, int cmvn, float eps,
+                                     float* dx, void* workspace, size_t workspace_bytes, void* stream) {
+  SE_REQUIRE(feats && offset && (grad_predicted || grad_offset) && W && dx && workspace, "se_head_linear_dx_f32: null argument");
+  SE_REQUIRE(B > 0 && B <= 65535 && F >= 2 && D > 0 && N > 0 && N <= 256, "se_head_linear_dx_f32: bad shape (N <= 256)");
+  SE_REQUIRE(workspace_bytes >= se_head_dx_workspace_bytes(B, F, D, N) && (uintptr_t)workspace % 256 == 0, "se_head_linear_dx_f32: workspace too small / unaligned");
+  SE_REQUIRE(act == SE_ACT_IDENTITY || act == SE_ACT_RELU || act == SE_ACT_SIGMOID || act == SE_ACT_EXP,
+             "se_head_linear_dx_f32: activation %d has no output-only derivative", act);
+  hipStream_t st = se::as_stream(stream);
+  const size_t M = (size_t)B * F;
+  const int NP = (N + 63) / 64 * 64;
+  char* base = reinterpret_cast<char*>(workspace);
+  float* stats = reinterpret_cast<float*>(base);
+  size_t off = (se_head_workspace_bytes(B, F, D, N) + 255) & ~(size_t)255;
+  uint16_t* gpre = reinterpret_cast<uint16_t*>(base + off);
+  off += (M * NP * 2 + 255) & ~(size_t)255;
+  uint16_t* wt = reinterpret_cast<uint16_t*>(base + off);
+  hipLaunchKernelGGL(se::head_gpre_kernel, dim3((unsigned)std::min<size_t>((M * NP + 255) / 256, 8192)), dim3(256), 0, st, linears, offset,
+                     grad_predicted, grad_offset, M, N, NP, act, gpre);
+  SE_LAUNCH_CHECK();
+  int rc = se_transpose_f32_bf16(W, N, D, D, wt, NP, stream);          // (D, NP) = W^T, zero padded
+  if (rc) return rc;
+  rc = se_gemm_bf16(gpre, NP, wt, NP, nullptr, nullptr, (int)M, D, NP, SE_ACT_IDENTITY, nullptr, dx, D, stream);
+  if (rc) return rc;
+  if (cmvn) {
+    rc = se_head_colstats_f32(feats, B, F, D, eps, stats, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(se::cmvn_time_bwd_kernel, dim3((D + 63) / 64, B), dim3(256), 0, st, feats, stats, F, D, eps, dx);
+    SE_LAUNCH_CHECK();
+  }
+  return SE_OK;
 }

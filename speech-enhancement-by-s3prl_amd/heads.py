@@ -33,14 +33,14 @@ class _HeadLinearFn(torch.autograd.Function):
         _lib.check(lib.se_head_linear_f32(_lib.ptr(feats), _lib.ptr(w), _lib.ptr(b), _lib.ptr(lin), B, F, D, N, act,
                                           int(cmvn), float(eps), _lib.ptr(predicted), _lib.ptr(offset), _lib.ptr(ws), nbytes,
                                           _lib.stream()), 'se_head_linear_f32')
-        ctx.save_for_backward(feats, lin if lin is not None else torch.empty(0, device=feats.device), offset)
+        ctx.save_for_backward(feats, lin if lin is not None else torch.empty(0, device=feats.device), offset, w)
         ctx.meta = (act, int(cmvn), float(eps), lin is not None, weight.shape)
         return predicted, offset
 
     @staticmethod
     def backward(ctx, grad_predicted, grad_offset):
         lib = _lib.load()
-        feats, lin, offset = ctx.saved_tensors
+        feats, lin, offset, w = ctx.saved_tensors
         act, cmvn, eps, has_lin, wshape = ctx.meta
         B, F, D = feats.shape
         N = wshape[0]
@@ -53,7 +53,15 @@ class _HeadLinearFn(torch.autograd.Function):
         _lib.check(lib.se_head_linear_bwd_f32(_lib.ptr(feats), _lib.ptr(lin) if has_lin else None, _lib.ptr(offset), _lib.ptr(gp), _lib.ptr(go),
                                               B, F, D, N, act, cmvn, eps, _lib.ptr(gW), _lib.ptr(gb), _lib.ptr(ws), nbytes,
                                               _lib.stream()), 'se_head_linear_bwd_f32')
-        return None, None, gW, gb, None, None, None
+        d_feats = None
+        if ctx.needs_input_grad[0]:      # the head sits on a trainable stack (Residual: LSTM below): dx = CMVN'(g_pre W)
+            d_feats = torch.empty_like(feats)
+            nb = lib.se_head_dx_workspace_bytes(B, F, D, N)
+            ws2 = torch.empty(nb, device=feats.device, dtype=torch.uint8)
+            _lib.check(lib.se_head_linear_dx_f32(_lib.ptr(feats), _lib.ptr(lin) if has_lin else None, _lib.ptr(offset), _lib.ptr(gp), _lib.ptr(go),
+                                                 _lib.ptr(w), B, F, D, N, act, cmvn, eps, _lib.ptr(d_feats), _lib.ptr(ws2), nb, _lib.stream()),
+                       'se_head_linear_dx_f32')
+        return d_feats, None, gW, gb, None, None, None
 
 
 def _act_id(name):

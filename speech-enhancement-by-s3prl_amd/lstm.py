@@ -11,6 +11,7 @@ import torch.nn.functional as F
 
 from . import _lib
 from . import spechead_train as st
+from .heads import _HeadLinearFn, _act_id
 
 _H = 256
 
@@ -193,3 +194,26 @@ class LSTM(nn.Module):
         h = _LSTMFn.apply(features, self.num_layers, 2 if self.bidirectional else 1, *self._flat_weights())
         predicted, log_predicted = _DenseLogExpFn.apply(h, self.scaling_layer[0].weight, self.scaling_layer[0].bias)
         return predicted, {'log_predicted': log_predicted}
+
+
+class Residual(nn.Module):
+    """model.py:62-91: LSTM -> (CMVN over time) -> Linear + activation = mask `offset`; predicted = linears * offset.
+    The mask stage is the LinearResidual kernel (exact fp32) with its gradient wrt the LSTM output switched on."""
+
+    def __init__(self, input_size=201, output_size=201, hidden_size=201, num_layers=3, bidirectional=False, activation='Sigmoid', cmvn=False,
+                 eps=1e-6, **kwargs):
+        super().__init__()
+        if hidden_size != _H:
+            raise NotImplementedError(f'the MI355X LSTM kernels are built for hidden_size {_H} (config/pseudo_noise.yaml:54-59), got {hidden_size}')
+        self.lstm = nn.LSTM(input_size=input_size, hidden_size=hidden_size, num_layers=num_layers, batch_first=True, bidirectional=bidirectional)
+        self.scaling_layer = nn.Sequential(nn.Linear(max(1, int(bidirectional) * 2) * hidden_size, output_size), eval(f'nn.{activation}()'))
+        self._act = _act_id(activation)
+        self.bidirectional, self.num_layers, self.cmvn, self.eps = bidirectional, num_layers, cmvn, eps
+        LSTM.init_weights(self)
+
+    _flat_weights = LSTM._flat_weights
+
+    def forward(self, features, linears, **kwargs):
+        h = _LSTMFn.apply(features, self.num_layers, 2 if self.bidirectional else 1, *self._flat_weights())
+        predicted, offset = _HeadLinearFn.apply(h, linears, self.scaling_layer[0].weight, self.scaling_layer[0].bias, self._act, self.cmvn, self.eps)
+        return predicted, {'offset': offset}
