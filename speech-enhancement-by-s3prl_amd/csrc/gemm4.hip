@@ -81,6 +81,16 @@ __global__ __launch_bounds__(k4Threads) __attribute__((amdgpu_waves_per_eu(2, 2)
                                      (lds4_ptr_t)(smem + k4WBytes + ((g) & 3) * k4APiece + wave * 1024), 16, 0, 0);         \
   } while (0)
 
+  // ring prologue FIRST: pieces 0..4 = (0,0) (0,1) (0,2) (1,0) (1,1), A steps 0..2 -- the 393 KB of residual rows read below for the
+  // accumulator initialisation then travel concurrently with it (one HBM latency instead of two before the first MFMA)
+  SE4_ISSUE_A(0);
+  SE4_ISSUE_W(0, 0, 0);
+  SE4_ISSUE_A(1);
+  SE4_ISSUE_A(2);
+  SE4_ISSUE_W(0, 1, 1);
+  SE4_ISSUE_W(0, 2, 2);
+  SE4_ISSUE_W(1, 0, 3);
+  SE4_ISSUE_W(1, 1, 4);
   // C^T accumulators: acc[i][t][r] = C[row wr*64 + 16 i + (lane & 15)][col wc*192 + 16 t + 4 (lane >> 4) + r].
   // They are INITIALISED with bias + residual (the registers are free now and the loads overlap the DMA prologue); adding
   // them in the epilogue, next to 192 live accumulators, spilled ~1 KB per lane.
@@ -111,15 +121,6 @@ __global__ __launch_bounds__(k4Threads) __attribute__((amdgpu_waves_per_eu(2, 2)
   for (int jj = 0; jj < 4; ++jj) b_off[jj] = swz4(wc * 64 + jj * 16 + frow, fch);
 
   const int nk = K / k4BK;                 // >= 4 (launcher)
-  // prologue: pieces 0..4 = (0,0) (0,1) (0,2) (1,0) (1,1), A steps 0..2
-  SE4_ISSUE_A(0);
-  SE4_ISSUE_W(0, 0, 0);
-  SE4_ISSUE_A(1);
-  SE4_ISSUE_A(2);
-  SE4_ISSUE_W(0, 1, 1);
-  SE4_ISSUE_W(0, 2, 2);
-  SE4_ISSUE_W(1, 0, 3);
-  SE4_ISSUE_W(1, 1, 4);
   const bool late = wave >= 4;
   asm volatile("s_waitcnt vmcnt(10)" ::: "memory");        // A(0), W piece 0 landed
   __builtin_amdgcn_s_barrier();
