@@ -359,8 +359,11 @@ __global__ __launch_bounds__(k3Threads) __attribute__((amdgpu_waves_per_eu(2, 2)
   if (late) __builtin_amdgcn_s_barrier();
 
   constexpr bool RES = EF & 1, OBF = EF & 2, OF32 = EF & 4;
-  constexpr int kStores = 32;              // store instructions of one interior-tile epilogue (8 x 4, one output type)
+  // store instructions of one interior-tile epilogue: 8 x 4 fp32 (16 B per lane), or 8 x 2 bf16 after the lane-pair exchange
+  constexpr int kStores = OBF ? 16 : 32;
   const int mrow = lane & 15, ncol = 4 * (lane >> 4);
+  const bool godd = (lane >> 4) & 1;
+  const int ncol8 = 4 * ((lane >> 4) & ~1);
   int st = 0;
   bool stores_pending = false;             // the previous tile's epilogue left exactly kStores stores in flight
   for (int ti = 0; ti < my_tiles; ++ti) {
@@ -392,7 +395,10 @@ __global__ __launch_bounds__(k3Threads) __attribute__((amdgpu_waves_per_eu(2, 2)
       // wait until the NEXT K-step of the stream has landed.  VMEM ops younger than its 4 DMAs, in issue order:
       //   [previous tile's epilogue stores, only while g < 2] + the DMA groups of the two following steps.
       if (issued) {
-        if (stores_pending && g < 2) asm volatile("s_waitcnt vmcnt(40) lgkmcnt(0)" ::: "memory");   // 8 + kStores
+        if (stores_pending && g < 2) {
+          if constexpr (kStores == 16) asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)" ::: "memory");   // 8 + kStores
+          else asm volatile("s_waitcnt vmcnt(40) lgkmcnt(0)" ::: "memory");
+        }
         else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
       } else if (g + 2 < nk) {
         asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");      // stream tail: only step g+2 remains younger
@@ -423,7 +429,7 @@ __global__ __launch_bounds__(k3Threads) __attribute__((amdgpu_waves_per_eu(2, 2)
       const int gn = min(n0 + wc * 64 + j * 16 + ncol, N - 4);
       bb[j] = bias ? *reinterpret_cast<const float4*>(bias + gn) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    const bool interior = (m0 + k3BM <= M) && (n0 + k3BN <= N);      // wave-uniform
+    const bool interior = (m0 + k3BM <= M) && (n0 + k3BN <= N) && (!OBF || ((ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(out_bf16) & 15) == 0));
 #define SE3P_EPILOGUE_BODY(PRED)                                                                                           \
   _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                                          \
     const int gm = m0 + wr * 128 + i * 16 + mrow;                                                                          \
@@ -436,14 +442,31 @@ __global__ __launch_bounds__(k3Threads) __attribute__((amdgpu_waves_per_eu(2, 2)
         rr[j] = *reinterpret_cast<const float4*>(residual + orow + gn);                                                    \
       }                                                                                                                    \
     }                                                                                                                      \
+    uint2 pk[4];                                                                                                           \
     _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                        \
       const int gn = n0 + wc * 64 + j * 16 + ncol;                                                                         \
       float v0 = acc[i][j][0] + bb[j].x, v1 = acc[i][j][1] + bb[j].y, v2 = acc[i][j][2] + bb[j].z, v3 = acc[i][j][3] + bb[j].w; \
       v0 = act3(v0, ACT); v1 = act3(v1, ACT); v2 = act3(v2, ACT); v3 = act3(v3, ACT);                                      \
       if constexpr (RES) { v0 += rr[j].x; v1 += rr[j].y; v2 += rr[j].z; v3 += rr[j].w; }                                   \
+      pk[j] = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));                                                        \
       if (!(PRED) || (mok && gn < N)) {                                                                                    \
         if constexpr (OF32) *reinterpret_cast<float4*>(out_f32 + orow + gn) = make_float4(v0, v1, v2, v3);                 \
-        if constexpr (OBF) *reinterpret_cast<uint2*>(out_bf16 + orow + gn) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3)); \
+        if constexpr (OBF) {                                                                                               \
+          if (PRED) *reinterpret_cast<uint2*>(out_bf16 + orow + gn) = pk[j];                                               \
+        }                                                                                                                  \
+      }                                                                                                                    \
+    }                                                                                                                      \
+    if constexpr (OBF) {                                                                                                   \
+      if (!(PRED)) {      /* 16-B stores through the lane-pair exchange, as in the one-tile kernel above */                 \
+        _Pragma("unroll") for (int p2 = 0; p2 < 2; ++p2) {                                                                 \
+          const uint2 keep = godd ? pk[2 * p2 + 1] : pk[2 * p2];                                                           \
+          const uint2 send = godd ? pk[2 * p2] : pk[2 * p2 + 1];                                                           \
+          uint2 recv;                                                                                                      \
+          recv.x = __shfl_xor(send.x, 16);                                                                                 \
+          recv.y = __shfl_xor(send.y, 16);                                                                                 \
+          const uint4 o16 = godd ? make_uint4(recv.x, recv.y, keep.x, keep.y) : make_uint4(keep.x, keep.y, recv.x, recv.y); \
+          *reinterpret_cast<uint4*>(out_bf16 + orow + n0 + wc * 64 + 16 * (2 * p2 + (godd ? 1 : 0)) + ncol8) = o16;        \
+        }                                                                                                                  \
       }                                                                                                                    \
     }                                                                                                                      \
   }
@@ -458,7 +481,6 @@ __global__ __launch_bounds__(k3Threads) __attribute__((amdgpu_waves_per_eu(2, 2)
       stores_pending = false;
     }
 #undef SE3P_EPILOGUE_BODY
-    static_assert(kStores == 8 * 4, "one store per (i, j) tile and output type");
     if (has_next) {
       tile_id += wpx;
 #pragma unroll
