@@ -36,4 +36,24 @@ __device__ __forceinline__ float erf_as(float x) {
 }
 __device__ __forceinline__ float gelu_erf(float v) { return v * 0.5f * (1.0f + erf_as(v * 0.70710678118654752f)); }
 
+// two values at once: the polynomial, the squares and the final scaling go through the packed fp32 pipe (v_pk_fma_f32 /
+// v_pk_mul_f32: one instruction for both lanes of the pair); only rcp / exp2 stay per element.  Same arithmetic as gelu_erf.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 gelu_erf2(f32x2 v) {
+  const f32x2 x = v * 0.70710678118654752f;
+  const f32x2 ax = {fabsf(x.x), fabsf(x.y)};
+  const f32x2 one = {1.0f, 1.0f};
+  const f32x2 d = __builtin_elementwise_fma(ax, (f32x2){0.3275911f, 0.3275911f}, one);
+  const f32x2 t = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+  f32x2 p = __builtin_elementwise_fma(t, (f32x2){1.061405429f, 1.061405429f}, (f32x2){-1.453152027f, -1.453152027f});
+  p = __builtin_elementwise_fma(p, t, (f32x2){1.421413741f, 1.421413741f});
+  p = __builtin_elementwise_fma(p, t, (f32x2){-0.284496736f, -0.284496736f});
+  p = __builtin_elementwise_fma(p, t, (f32x2){0.254829592f, 0.254829592f});
+  const f32x2 q = ax * ax * -1.44269504088896f;
+  const f32x2 e = {__builtin_amdgcn_exp2f(q.x), __builtin_amdgcn_exp2f(q.y)};
+  const f32x2 r = __builtin_elementwise_fma(p * t * -1.0f, e, one);            // erf(|x|)
+  const f32x2 er = {copysignf(r.x, x.x), copysignf(r.y, x.y)};
+  return v * 0.5f * (er + one);
+}
+
 }  // namespace se

@@ -251,7 +251,12 @@ __global__ __launch_bounds__(k3Threads) __attribute__((amdgpu_waves_per_eu(2, 2)
     _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                        \
       const int gn = n0 + wc * 64 + j * 16 + ncol;                                                                         \
       float v0 = acc[i][j][0] + bb[j].x, v1 = acc[i][j][1] + bb[j].y, v2 = acc[i][j][2] + bb[j].z, v3 = acc[i][j][3] + bb[j].w; \
-      v0 = act3(v0, ACT); v1 = act3(v1, ACT); v2 = act3(v2, ACT); v3 = act3(v3, ACT);                                      \
+      if constexpr (ACT == SE_ACT_GELU) {                                                                                  \
+        const f32x2 ga = gelu_erf2((f32x2){v0, v1}), gb = gelu_erf2((f32x2){v2, v3});                                      \
+        v0 = ga.x; v1 = ga.y; v2 = gb.x; v3 = gb.y;                                                                        \
+      } else {                                                                                                             \
+        v0 = act3(v0, ACT); v1 = act3(v1, ACT); v2 = act3(v2, ACT); v3 = act3(v3, ACT);                                    \
+      }                                                                                                                    \
       if constexpr (RES) { v0 += rr[j].x; v1 += rr[j].y; v2 += rr[j].z; v3 += rr[j].w; }                                   \
       pk[j] = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));                                                        \
       if (!(PRED) || (mok && gn < N)) {                                                                                    \
@@ -446,7 +451,12 @@ __global__ __launch_bounds__(k3Threads) __attribute__((amdgpu_waves_per_eu(2, 2)
     _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                        \
       const int gn = n0 + wc * 64 + j * 16 + ncol;                                                                         \
       float v0 = acc[i][j][0] + bb[j].x, v1 = acc[i][j][1] + bb[j].y, v2 = acc[i][j][2] + bb[j].z, v3 = acc[i][j][3] + bb[j].w; \
-      v0 = act3(v0, ACT); v1 = act3(v1, ACT); v2 = act3(v2, ACT); v3 = act3(v3, ACT);                                      \
+      if constexpr (ACT == SE_ACT_GELU) {                                                                                  \
+        const f32x2 ga = gelu_erf2((f32x2){v0, v1}), gb = gelu_erf2((f32x2){v2, v3});                                      \
+        v0 = ga.x; v1 = ga.y; v2 = gb.x; v3 = gb.y;                                                                        \
+      } else {                                                                                                             \
+        v0 = act3(v0, ACT); v1 = act3(v1, ACT); v2 = act3(v2, ACT); v3 = act3(v3, ACT);                                    \
+      }                                                                                                                    \
       if constexpr (RES) { v0 += rr[j].x; v1 += rr[j].y; v2 += rr[j].z; v3 += rr[j].w; }                                   \
       pk[j] = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));                                                        \
       if (!(PRED) || (mok && gn < N)) {                                                                                    \
