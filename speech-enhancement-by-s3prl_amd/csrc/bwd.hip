@@ -344,7 +344,7 @@ extern "C" int se_wgrad_bf16(const uint16_t* dYt, const uint16_t* Xt, int Mp, in
 extern "C" int se_colsum_f32(const float* x, int rows, int cols, int ld, float* out, int accumulate, void* stream) {
   SE_REQUIRE(x && out && rows > 0 && cols > 0 && ld >= cols, "se_colsum_f32: bad argument");
   hipStream_t st = se::as_stream(stream);
-  if (!accumulate) SE_HIP(hipMemsetAsync(out, 0, sizeof(float) * cols, st));
+  if (!accumulate) { const int zrc_ = se::zero_async(out, sizeof(float) * cols, st); if (zrc_) return zrc_; }
   const int rpb = 256;
   dim3 grid((rows + rpb - 1) / rpb, (cols + 255) / 256);
   hipLaunchKernelGGL(se::colsum_kernel, grid, dim3(256), 0, st, x, rows, cols, ld, rpb, out);
@@ -357,9 +357,9 @@ int se::launch_layernorm_bwd(const float* x_in, const float* pe, int T, const fl
                              uint32_t key_dy, uint32_t key_dx, uint32_t thr16, float dscale) {
   SE_REQUIRE(H == 768 || H == 256, "layernorm backward: only H = 768 / 256 are built (got %d)", H);
   if (!accumulate) {
-    if (dgamma) SE_HIP(hipMemsetAsync(dgamma, 0, sizeof(float) * H, st));
-    if (dbeta) SE_HIP(hipMemsetAsync(dbeta, 0, sizeof(float) * H, st));
-    if (dbias) SE_HIP(hipMemsetAsync(dbias, 0, sizeof(float) * H, st));
+    if (dgamma) { const int zrc_ = se::zero_async(dgamma, sizeof(float) * H, st); if (zrc_) return zrc_; }
+    if (dbeta) { const int zrc_ = se::zero_async(dbeta, sizeof(float) * H, st); if (zrc_) return zrc_; }
+    if (dbias) { const int zrc_ = se::zero_async(dbias, sizeof(float) * H, st); if (zrc_) return zrc_; }
   }
   const int rows_per_wave = 16;
   const int grid = (M + 4 * rows_per_wave - 1) / (4 * rows_per_wave);
@@ -386,7 +386,7 @@ extern "C" int se_layernorm_bwd_f32(const float* x_in, const float* dy, const fl
 
 int se::launch_colsum_bf16(const uint16_t* x, int rows, int cols, int ld, float* out, hipStream_t st) {
   SE_REQUIRE(cols % 8 == 0 && ld % 8 == 0, "bf16 column sum: cols and ld must be multiples of 8");
-  SE_HIP(hipMemsetAsync(out, 0, sizeof(float) * cols, st));
+  { const int zrc_ = se::zero_async(out, sizeof(float) * cols, st); if (zrc_) return zrc_; }
   const int rpb = 128;
   dim3 grid((rows + rpb - 1) / rpb, (cols + 511) / 512);
   hipLaunchKernelGGL((se::colsum8_bf16_kernel<0>), grid, dim3(256), 0, st, x, nullptr, nullptr, rows, cols, ld, rpb, out);
@@ -397,7 +397,7 @@ int se::launch_colsum_bf16(const uint16_t* x, int rows, int cols, int ld, float*
 // dx = dy * gelu'(pre) (bf16, in place allowed) and colsum[c] = sum_rows dx  (FFN: activation backward + bias gradient)
 int se::launch_gelu_bwd_colsum(const uint16_t* dy, const uint16_t* pre, uint16_t* dx, int rows, int cols, float* colsum, hipStream_t st) {
   SE_REQUIRE(cols % 8 == 0, "gelu backward: cols must be a multiple of 8");
-  SE_HIP(hipMemsetAsync(colsum, 0, sizeof(float) * cols, st));
+  { const int zrc_ = se::zero_async(colsum, sizeof(float) * cols, st); if (zrc_) return zrc_; }
   const int rpb = 128;
   dim3 grid((rows + rpb - 1) / rpb, (cols + 511) / 512);
   hipLaunchKernelGGL((se::colsum8_bf16_kernel<1>), grid, dim3(256), 0, st, dy, pre, dx, rows, cols, cols, rpb, colsum);

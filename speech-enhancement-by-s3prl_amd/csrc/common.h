@@ -1,6 +1,7 @@
 // common.h -- host-side helpers shared by the C-ABI translation units (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -14,6 +15,9 @@ void set_error(const char* fmt, ...);   // stores a thread-local message (se_las
 int hip_fail(hipError_t e, const char* what, const char* file, int line);   // -> SE_ERR_HIP / SE_ERR_OOM
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// clears a device buffer with a kernel (graph-capture safe; see zero.hip)
+int zero_async(void* ptr, size_t bytes, hipStream_t st);
 
 }  // namespace se
 

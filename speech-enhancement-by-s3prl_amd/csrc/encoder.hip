@@ -277,7 +277,7 @@ extern "C" int se_cast_f32_bf16(const float* x, size_t n, uint16_t* out, void* s
 
 extern "C" int se_valid_lengths_i32(const float* feats, int B, int T, int D, int32_t* lengths, void* stream) {
   SE_REQUIRE(feats && lengths && B > 0 && T > 0 && D > 0, "se_valid_lengths_i32: bad argument");
-  SE_HIP(hipMemsetAsync(lengths, 0, sizeof(int32_t) * B, se::as_stream(stream)));
+  { const int zrc_ = se::zero_async(lengths, sizeof(int32_t) * B, se::as_stream(stream)); if (zrc_) return zrc_; }
   hipLaunchKernelGGL(se::valid_lengths_kernel, dim3(std::min(32, (T + 3) / 4), B), dim3(256), 0, se::as_stream(stream), feats, T, D, lengths);
   SE_LAUNCH_CHECK();
   return SE_OK;

@@ -181,8 +181,8 @@ extern "C" int se_head_linear_bwd_f32(const float* feats, const float* linears, 
   SE_REQUIRE(act == SE_ACT_IDENTITY || act == SE_ACT_RELU || act == SE_ACT_SIGMOID || act == SE_ACT_EXP,
              "se_head_linear_bwd_f32: activation %d has no output-only derivative", act);
   hipStream_t st = se::as_stream(stream);
-  SE_HIP(hipMemsetAsync(gW, 0, sizeof(float) * (size_t)N * D, st));
-  SE_HIP(hipMemsetAsync(gb, 0, sizeof(float) * (size_t)N, st));
+  { const int zrc_ = se::zero_async(gW, sizeof(float) * (size_t)N * D, st); if (zrc_) return zrc_; }
+  { const int zrc_ = se::zero_async(gb, sizeof(float) * (size_t)N, st); if (zrc_) return zrc_; }
   float* stats = nullptr;
   if (cmvn) {
     SE_REQUIRE(workspace && workspace_bytes >= se_head_workspace_bytes(B, F, D, N), "se_head_linear_bwd_f32: workspace too small");

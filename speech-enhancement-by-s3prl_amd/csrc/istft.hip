@@ -237,7 +237,7 @@ extern "C" int se_istft_f32(const se_plan* plan, const float* power, const float
   SE_REQUIRE(linear_power > 0.f, "se_istft_f32: linear_power must be positive");
   SE_REQUIRE(sumsq_out == nullptr || lengths != nullptr, "se_istft_f32: sumsq_out needs lengths");
   hipStream_t st = se::as_stream(stream);
-  if (sumsq_out) SE_HIP(hipMemsetAsync(sumsq_out, 0, sizeof(float) * B, st));
+  if (sumsq_out) { const int zrc_ = se::zero_async(sumsq_out, sizeof(float) * B, st); if (zrc_) return zrc_; }
   dim3 grid((n_out + se::kISpan - 1) / se::kISpan, B);
   se::ProfScope prof(se::kProfIstft, (double)B * (8.0 * F * se::kBins + 4.0 * n_out), st);
   hipLaunchKernelGGL(se::istft_kernel, grid, dim3(se::kIThreads), 0, st, power, phase, F, 1.0f / linear_power,
@@ -249,7 +249,7 @@ extern "C" int se_istft_f32(const se_plan* plan, const float* power, const float
 extern "C" int se_masked_sumsq_f32(const float* x, int B, int T, int x_stride, const int64_t* lengths, float* sums, void* stream) {
   SE_REQUIRE(x && lengths && sums && B > 0 && B <= 65535 && T > 0 && x_stride >= T, "se_masked_sumsq_f32: bad argument");
   hipStream_t st = se::as_stream(stream);
-  SE_HIP(hipMemsetAsync(sums, 0, sizeof(float) * B, st));
+  { const int zrc_ = se::zero_async(sums, sizeof(float) * B, st); if (zrc_) return zrc_; }
   dim3 grid(std::min(64, (T + 255) / 256), B);
   hipLaunchKernelGGL(se::masked_sumsq_kernel, grid, dim3(256), 0, st, x, T, x_stride, lengths, sums);
   SE_LAUNCH_CHECK();

@@ -43,7 +43,7 @@ extern "C" int se_l1_masked_f32(const float* log_pred, const float* linear_tar, 
   SE_REQUIRE(log_pred && linear_tar && frame_lengths && sums, "se_l1_masked_f32: null argument");
   SE_REQUIRE(B > 0 && B <= 65535 && F > 0 && K > 0, "se_l1_masked_f32: bad shape");
   hipStream_t st = se::as_stream(stream);
-  SE_HIP(hipMemsetAsync(sums, 0, 2 * sizeof(double), st));
+  { const int zrc_ = se::zero_async(sums, 2 * sizeof(double), st); if (zrc_) return zrc_; }
   const int n = F * K;
   dim3 grid(std::min(64, (n + 255) / 256), B);
   hipLaunchKernelGGL(se::l1_kernel, grid, dim3(256), 0, st, log_pred, linear_tar, frame_lengths, F, K, eps, sums, grad);

@@ -132,7 +132,7 @@ extern "C" int se_mix_f32(const float* speech, int ld_s, const int64_t* len_s, c
   SE_REQUIRE(speech && len_s && noise && len_n && snr_db && wavs && sums, "se_mix_f32: null argument");
   SE_REQUIRE(B > 0 && B <= 65535 && T_out > 0 && ld_s > 0 && ld_n > 0, "se_mix_f32: bad shape");
   hipStream_t st = se::as_stream(stream);
-  SE_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 3 * B, st));
+  { const int zrc_ = se::zero_async(sums, sizeof(double) * 3 * B, st); if (zrc_) return zrc_; }
   const int span = ld_s > ld_n ? ld_s : ld_n;
   const int chunks = std::max(1, std::min(64, (span + 4095) / 4096));
   hipLaunchKernelGGL(se::mix_sums_kernel, dim3(chunks, B), dim3(256), 0, st, speech, ld_s, len_s, noise, ld_n, len_n, off_n, sums);
@@ -148,7 +148,7 @@ extern "C" int se_sisdr_f32(const float* src, const float* tar, int ld, const in
                             void* stream) {
   SE_REQUIRE(src && tar && sums && sisdr && B > 0 && B <= 65535 && ld > 0, "se_sisdr_f32: bad argument");
   hipStream_t st = se::as_stream(stream);
-  SE_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 3 * B, st));
+  { const int zrc_ = se::zero_async(sums, sizeof(double) * 3 * B, st); if (zrc_) return zrc_; }
   const int chunks = std::max(1, std::min(64, (ld + 4095) / 4096));
   hipLaunchKernelGGL(se::sisdr_sums_kernel, dim3(chunks, B), dim3(256), 0, st, src, tar, ld, lengths, sums);
   SE_LAUNCH_CHECK();

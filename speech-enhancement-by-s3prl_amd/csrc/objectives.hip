@@ -128,7 +128,7 @@ extern "C" int se_sisdr_spec_f32(const float* predicted, const float* linear_tar
   SE_REQUIRE(predicted && linear_tar && frame_lengths && scratch && loss_b, "se_sisdr_spec_f32: null argument");
   SE_REQUIRE(B > 0 && B <= 65535 && F > 0 && N > 0, "se_sisdr_spec_f32: bad shape");
   hipStream_t st = se::as_stream(stream);
-  SE_HIP(hipMemsetAsync(scratch, 0, sizeof(double) * 5 * B, st));
+  { const int zrc_ = se::zero_async(scratch, sizeof(double) * 5 * B, st); if (zrc_) return zrc_; }
   const int chunks = (int)std::max<int64_t>(1, std::min<int64_t>(64, ((int64_t)F * N + 8191) / 8192));
   hipLaunchKernelGGL(se::sisdr_spec_sums_kernel, dim3(chunks, B), dim3(256), 0, st, predicted, linear_tar, frame_lengths, F, N, scratch);
   SE_LAUNCH_CHECK();
@@ -145,7 +145,7 @@ extern "C" int se_sisdr_spec_f32(const float* predicted, const float* linear_tar
 extern "C" int se_wsd_energy_f32(const float* linear_tar, int B, int F, int N, float* energy, float* energy_max, void* stream) {
   SE_REQUIRE(linear_tar && energy && energy_max && B > 0 && F > 0 && N > 0, "se_wsd_energy_f32: bad argument");
   hipStream_t st = se::as_stream(stream);
-  SE_HIP(hipMemsetAsync(energy_max, 0, sizeof(float), st));
+  { const int zrc_ = se::zero_async(energy_max, sizeof(float), st); if (zrc_) return zrc_; }
   const int rows = B * F;
   hipLaunchKernelGGL(se::wsd_energy_kernel, dim3(std::min(1024, (rows + 3) / 4)), dim3(256), 0, st, linear_tar, rows, N, energy,
                      reinterpret_cast<unsigned int*>(energy_max));
@@ -159,7 +159,7 @@ extern "C" int se_wsd_f32(const float* linear_inp, const float* offset, const fl
   SE_REQUIRE(linear_inp && offset && linear_tar && frame_lengths && energy && energy_max && sums, "se_wsd_f32: null argument");
   SE_REQUIRE(B > 0 && B <= 65535 && F > 0 && N > 0, "se_wsd_f32: bad shape");
   hipStream_t st = se::as_stream(stream);
-  SE_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 3, st));
+  { const int zrc_ = se::zero_async(sums, sizeof(double) * 3, st); if (zrc_) return zrc_; }
   const int chunks = (int)std::max<int64_t>(1, std::min<int64_t>(64, ((int64_t)F * N + 8191) / 8192));
   hipLaunchKernelGGL(se::wsd_kernel, dim3(chunks, B), dim3(256), 0, st, linear_inp, offset, linear_tar, frame_lengths, energy,
                      reinterpret_cast<const unsigned int*>(energy_max), F, N, alpha, db_interval, eps, grad_scale, sums, grad);

@@ -149,7 +149,7 @@ int for_batches(float* const* params, const float* const* grads, float* const* m
 extern "C" int se_multi_sumsq_f32(const float* const* grads, const uint64_t* sizes, int n_tensors, double* sumsq, void* stream) {
   SE_REQUIRE(grads && sizes && sumsq && n_tensors > 0, "se_multi_sumsq_f32: bad argument");
   hipStream_t st = se::as_stream(stream);
-  SE_HIP(hipMemsetAsync(sumsq, 0, sizeof(double) * n_tensors, st));
+  { const int zrc_ = se::zero_async(sumsq, sizeof(double) * n_tensors, st); if (zrc_) return zrc_; }
   return se::for_batches(nullptr, grads, nullptr, nullptr, sizes, nullptr, n_tensors, [&](const se::OptBatch& b, uint32_t chunks) {
     hipLaunchKernelGGL(se::multi_sumsq_kernel, dim3(chunks), dim3(256), 0, st, b, sumsq);
     SE_LAUNCH_CHECK();

@@ -1,0 +1,26 @@
+"""The evaluate()-style pass captured as one hipGraph (torch.cuda.CUDAGraph) replays to the eager pass's results, replay after
+replay with changing inputs (the accumulators are cleared by kernels, which -- unlike small memset nodes -- are replayed)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_graphed_enhance_step_matches_eager(gpu):
+    from speech_enhancement_by_s3prl_amd import pipeline, synth
+    cfg = pipeline.make_config(layers=2)
+    ckpt = pipeline.synthetic_checkpoint(cfg, seed=2)
+    up = pipeline.build_upstream(ckpt, gpu)
+    pre = pipeline.build_preprocessor(cfg, gpu)
+    eager = pipeline.UpstreamEnhanceStep(pre, up)
+    lengths, wavs = synth.fast_batch(2, 32000, seed=5, device=gpu)
+    lengths2, wavs2 = synth.fast_batch(2, 32000, seed=6, device=gpu)
+    graphed = pipeline.GraphedStep(eager, wavs, lengths, 32000)
+    for w, l in ((wavs, lengths), (wavs2, lengths2), (wavs, lengths), (wavs2, lengths2)):
+        ref_wav, ref_loss, ref_pred = [t.clone() for t in eager(w, l, 32000)]
+        got_wav, got_loss, got_pred = graphed(w, l)
+        torch.cuda.synchronize()
+        assert torch.equal(got_pred, ref_pred)
+        # the level normalisation and the loss reduce with atomics (order-dependent in the last bit), eager vs eager too
+        assert (got_wav - ref_wav).abs().max().item() <= 1e-6 * ref_wav.abs().max().item()
+        assert abs(got_loss.item() - ref_loss.item()) <= 1e-6 * abs(ref_loss.item())
