@@ -211,6 +211,10 @@ extern "C" int se_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, int l
     g_gemm_variant = (e && e[0] >= '1' && e[0] <= '5') ? (e[0] - '0') : 5;
   }
   if (g_gemm_variant == 5) {      // 256 x 256 kernel for wide outputs (enough tiles to fill 256 CUs several times), 256 x 128 ping-pong otherwise
+    // serving-size batches (M = B*T <= 8 utterances of 10 s): a 1 001-row GEMM makes 4 row tiles of 256 -- 36 workgroups for the QKV
+    // projection on 256 CUs.  128 x 128 tiles at two workgroups per CU fill the chip 4x better: 0.85 vs 1.85 ms per utterance pass
+    // at B = 1, 1.81 vs 2.61 ms at B = 8 (tools/small_batch_sweep.sh); from B = 16 on the large tiles win again.
+    if (M <= 8192) return se_gemm2_launch(A, lda, W, ldw, bias, residual_f32, M, N, K, act, out_bf16, out_f32, ldc, vec_ok, 4, stream);
     const int rc = (N >= 1536) ? se_gemm3_launch(A, lda, W, ldw, bias, residual_f32, M, N, K, act, out_bf16, out_f32, ldc, vec_ok, stream) : 1;
     if (rc <= 0) return rc;
     return se_gemm2_launch(A, lda, W, ldw, bias, residual_f32, M, N, K, act, out_bf16, out_f32, ldc, vec_ok, 3, stream);
