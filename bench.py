@@ -113,9 +113,10 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=32, help='utterances per GPU per step (configs[1]: 32)')
     ap.add_argument('--layers', type=int, default=6, help='encoder depth (6 = config/pretrain_sample.yaml; 3 = "base")')
-    ap.add_argument('--workload', choices=('enhance', 'finetune'), default='enhance',
+    ap.add_argument('--workload', choices=('enhance', 'finetune', 'lstm'), default='enhance',
                     help="enhance = configs[1] (the headline metric); finetune = configs[3]'s Mockingjay training step "
-                         '(fwd + L1 + bwd + gradient all-reduce + clip + BertAdam), reported as a side measurement')
+                         '(fwd + L1 + bwd + gradient all-reduce + clip + BertAdam); lstm = the same step for the 3 x BiLSTM-256 head of '
+                         'pseudo_noise.yaml:50-53 on raw features (run_active.sh); both reported as side measurements')
     ap.add_argument('--graph', action='store_true', help='replay the enhance pass as one hipGraph launch (serving-size batches are launch-bound)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
@@ -161,6 +162,17 @@ def main():
         def step(wavs, lengths, max_len):          # same call shape as the enhance step
             loss, gn, skipped = ft(wavs, lengths)
             return loss.reshape(1), loss, None
+    if args.workload == 'lstm':
+        from speech_enhancement_by_s3prl_amd.lstm import LSTM
+        from speech_enhancement_by_s3prl_amd.solver import get_optimizer
+        del upstream
+        head = LSTM(input_size=120, output_size=201, hidden_size=256, num_layers=3, bidirectional=True).to(dev)
+        opt = get_optimizer(list(head.named_parameters()), lr=4e-5, warmup_proportion=0.07, training_steps=100000)
+        ht = pipeline.HeadFinetuneStep(pre, head, opt)
+
+        def step(wavs, lengths, max_len):
+            loss, gn, skipped = ht(wavs, lengths)
+            return loss.reshape(1), loss, None
     lengths, wavs = synth.fast_batch(args.batch, 160000, seed=1000 + rank, device=dev)   # resident in HBM before timing
     max_len = 160000
     if args.graph and args.workload == 'enhance':
@@ -193,7 +205,8 @@ def main():
 
     total_utts = args.batch * world * args.steps
     out = {
-        'metric': 'enhanced 10s utts/sec' if args.workload == 'enhance' else 'fine-tuned 10s utts/sec (Mockingjay training step)', 'value': total_utts / elapsed, 'unit': 'utt/s', 'n_gpus': world,
+        'metric': {'enhance': 'enhanced 10s utts/sec', 'finetune': 'fine-tuned 10s utts/sec (Mockingjay training step)',
+                   'lstm': 'trained 10s utts/sec (LSTM head training step)'}[args.workload], 'value': total_utts / elapsed, 'unit': 'utt/s', 'n_gpus': world,
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1000.0 * elapsed / args.steps,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
         'config': {'workload': 'configs[1]: TERA/Mockingjay upstream (6x768x12x3072, pretrain_sample.yaml) + '
@@ -204,6 +217,10 @@ def main():
     }
     if args.graph and args.workload == 'enhance':
         out['config']['launch'] = 'one hipGraph replay per step'
+    if args.workload == 'lstm':
+        out['config']['workload'] = ('config 5 style: 3 x BiLSTM-256 + Linear(512->201) head (pseudo_noise.yaml:50-53, 4.0 M params) on mel/log/delta-2 '
+                                     'features: STFT/features, forward, masked log-L1, backward (BPTT), gradient all-reduce, clip 1.0, BertAdam')
+        out['config']['parallelism'] = f'dp{world} (replicated parameters, one gradient all-reduce per step)'
     if args.workload == 'finetune':
         out['config']['workload'] = ('configs[3]: Mockingjay fine-tune step (6x768x12x3072 encoder + spec head, 43 M params): STFT/features, '
                                      'forward (train mode, dropout 0.1), masked log-L1, backward, flat-buffer gradient all-reduce, clip 1.0, BertAdam')

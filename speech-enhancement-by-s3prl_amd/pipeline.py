@@ -203,3 +203,24 @@ class GraphedStep:
         self.lengths.copy_(lengths, non_blocking=True)
         self.graph.replay()
         return self.out
+
+
+class HeadFinetuneStep:
+    """One training step of a feature-input downstream head (config 5: `--downstream LSTM --from_rawfeature`, runner.py:431-471):
+    wavs -> downstream features (mel / log / delta-2, 120 dims) -> head -> criterion -> backward -> flat-buffer gradient
+    all-reduce -> clip / NaN skip -> BertAdam."""
+
+    def __init__(self, preprocessor, head, optimizer, criterion=None, grad_clip=1.0):
+        from .dist import DataParallelTrainStep
+        self.pre, self.head = preprocessor, head
+        self.criterion = criterion or L1()
+        self.dp = DataParallelTrainStep(head, self.criterion, optimizer, grad_clip=grad_clip)
+
+    def __call__(self, wavs, lengths):
+        with torch.no_grad():
+            feats_up, feats_down, lin_inp, ph_inp, lin_tar, ph_tar = self.pre(wavs)
+        predicted, res = self.head(features=feats_down, linears=lin_inp)
+        stft_lengths = lengths // self.pre._win_args['hop_length'] + 1
+        loss, _ = self.criterion(predicted=predicted, linear_inp=lin_inp, linear_tar=lin_tar, stft_lengths=stft_lengths, **res)
+        grad_norm, skipped = self.dp.step(loss)
+        return loss.detach(), grad_norm, skipped
