@@ -138,3 +138,26 @@ def test_head_enhance_step_fp32_1e4(gpu):
         a = oobj.sisdr_eval(wav_pred[i].cpu(), wavs[i, 1])
         r = oobj.sisdr_eval(rwav[i], wavs[i, 1])
         assert abs(a - r) < 1e-3                              # dB
+
+
+@pytest.mark.parametrize('n_samples,B', [(480, 1), (2560, 3), (10240, 2), (20640, 9), (48000, 1)])
+def test_enhance_step_odd_shapes(gpu, small, n_samples, B):
+    """edge shapes of the whole evaluate()-style pass: 4 / 17 / 65 / 130 / 301 frames (below, at and across the 64-key MHSA tile, the
+    30-frame STFT chunk, the 128-row GEMM tile), batch sizes that are not multiples of 8 (the XCD-aware mappings fall back)."""
+    from speech_enhancement_by_s3prl_amd import pipeline, synth
+    cfg, ckpt = small
+    up = pipeline.build_upstream(ckpt, gpu)
+    pre = pipeline.build_preprocessor(cfg, gpu)
+    step = pipeline.UpstreamEnhanceStep(pre, up)
+    lengths, wavs = synth.synth_batch(B, n_samples, ragged=B > 1)
+    wav_pred, loss, predicted = step(wavs.to(gpu), lengths.to(gpu))
+    assert torch.isfinite(wav_pred).all() and torch.isfinite(loss) and torch.isfinite(predicted).all()
+    geom = opre.Geometry()
+    f = opre.forward(wavs, pre.feat_list, geom)
+    ocfg = oenc.Config(cfg)
+    hid = oenc.encoder_forward(f[0], ckpt['Transformer'], ocfg)
+    rpred, rres = oheads.spec_head(hid, ckpt['SpecHead'], ocfg, log=True)
+    rwav = odec.decode_wav(rpred, f[3], lengths, geom, wavs[:, 1])
+    assert predicted.shape == rpred.shape and wav_pred.shape == rwav.shape
+    assert rel_l2(predicted, rpred) < 4e-2
+    assert rel_l2(wav_pred, rwav) < 4e-2
