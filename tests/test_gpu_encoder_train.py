@@ -139,6 +139,16 @@ def test_encoder_gradients_small_config(gpu):
     _encoder_grads_vs_oracle(gpu, cfg, ckpt, 3, 257, [257, 100, 64], tol=4e-2)
 
 
+@pytest.mark.parametrize('B,T,lens', [(1, 17, None), (5, 65, [65, 64, 3, 33, 2]), (2, 130, [130, 129])])
+def test_encoder_gradients_edge_shapes(gpu, B, T, lens):
+    """rows / frames below, at and across every tile size of the training kernels (32-row weight-gradient stages, 64-key attention
+    tiles, 128-row workgroups), batch sizes off the XCD-aware mappings"""
+    from speech_enhancement_by_s3prl_amd import pipeline
+    cfg = pipeline.make_config(layers=1, hidden=256, heads=4, intermediate=512)
+    ckpt = pipeline.synthetic_checkpoint(cfg, seed=6)
+    _encoder_grads_vs_oracle(gpu, cfg, ckpt, B, T, lens, tol=4e-2)
+
+
 def test_encoder_gradients_full_width(gpu):
     """hidden 768 / 12 heads / FFN 3072 (the sample config's widths), 2 layers, short utterances."""
     from speech_enhancement_by_s3prl_amd import pipeline
