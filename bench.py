@@ -117,6 +117,7 @@ def main():
                     help="enhance = configs[1] (the headline metric); finetune = configs[3]'s Mockingjay training step "
                          '(fwd + L1 + bwd + gradient all-reduce + clip + BertAdam); lstm = the same step for the 3 x BiLSTM-256 head of '
                          'pseudo_noise.yaml:50-53 on raw features (run_active.sh); both reported as side measurements')
+    ap.add_argument('--streams', type=int, default=1, help='process the batch as this many sub-batches on separate HIP streams (enhance workload)')
     ap.add_argument('--graph', action='store_true', help='replay the enhance pass as one hipGraph launch (serving-size batches are launch-bound)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
@@ -149,7 +150,7 @@ def main():
     ckpt = pipeline.synthetic_checkpoint(cfg, seed=0)
     upstream = pipeline.build_upstream(ckpt, dev)
     pre = pipeline.build_preprocessor(cfg, dev)
-    step = pipeline.UpstreamEnhanceStep(pre, upstream)
+    step = pipeline.UpstreamEnhanceStep(pre, upstream, streams=args.streams)
     if args.workload == 'finetune':
         import warnings
         warnings.simplefilter('ignore')
@@ -217,6 +218,8 @@ def main():
     }
     if args.graph and args.workload == 'enhance':
         out['config']['launch'] = 'one hipGraph replay per step'
+    if args.streams > 1 and args.workload == 'enhance':
+        out['config']['streams'] = f'{args.streams} sub-batches of the batch in flight on separate HIP streams'
     if args.workload == 'lstm':
         out['config']['workload'] = ('config 5 style: 3 x BiLSTM-256 + Linear(512->201) head (pseudo_noise.yaml:50-53, 4.0 M params) on mel/log/delta-2 '
                                      'features: STFT/features, forward, masked log-L1, backward (BPTT), gradient all-reduce, clip 1.0, BertAdam')

@@ -191,6 +191,9 @@ typedef struct se_encoder_config {
   int intermediate;  /* 3072 */
   float ln_eps;      /* 1e-12 */
   int spec_out;      /* 0 = no spec head; else output dim of the head (201) */
+  int fused_ln_min_rows; /* rows (B*T) from which the out-proj / FFN2 projections use the row-complete GEMM + LayerNorm kernel;
+                            0 = default (24576: one launch then makes ~a full round of workgroups).  Callers that keep two half
+                            batches in flight on two streams set it lower: two half-size launches share the chip out of phase. */
 } se_encoder_config;
 
 /* HOST pointers to fp32 weights, nn.Linear layout (out, in); arrays of `layers` pointers per-layer. */

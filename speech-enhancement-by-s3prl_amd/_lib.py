@@ -26,7 +26,7 @@ class Geometry(ctypes.Structure):
 
 class EncoderConfig(ctypes.Structure):
     _fields_ = [('input_dim', c_int), ('hidden', c_int), ('layers', c_int), ('heads', c_int), ('intermediate', c_int),
-                ('ln_eps', c_float), ('spec_out', c_int)]
+                ('ln_eps', c_float), ('spec_out', c_int), ('fused_ln_min_rows', c_int)]
 
 
 _FP = POINTER(c_float)

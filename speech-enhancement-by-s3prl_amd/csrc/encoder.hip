@@ -474,7 +474,7 @@ extern "C" int se_encoder_fwd_bf16(const se_encoder* enc, const float* feats, co
   // the row-complete GEMM + LayerNorm kernel owns 128 x 768 outputs per workgroup: M / 128 workgroups.  It needs ~a full round of the
   // 256 CUs to pay off (B = 32: 251 workgroups); below ~24 k rows the unfused GEMM + LayerNorm pair is faster (B = 16: 3.19 vs 3.31 ms,
   // B = 1: 8 workgroups, 0.85 vs 1.70 ms).  SE_AMD_FUSED_LN = 2 forces it.
-  const bool fused = fuse_env && H == 768 && I % 32 == 0 && I >= 128 && (fuse_env == 2 || M >= 24576);
+  const bool fused = fuse_env && H == 768 && I % 32 == 0 && I >= 128 && (fuse_env == 2 || M >= (enc->cfg.fused_ln_min_rows > 0 ? enc->cfg.fused_ln_min_rows : 24576));
   for (int i = 0; i < L; ++i) {
     const se_encoder::Layer& y = enc->layers[i];
     // B2

@@ -219,7 +219,8 @@ class _Engine:
     def __init__(self):
         self.handle = None
         self.key = None
-        self.ws = None
+        self.ws = {}                  # one workspace per HIP stream: concurrent passes (pipeline.UpstreamEnhanceStep(streams=2)) must not share
+        self.fused_ln_min_rows = 0    # 0 = the library's default threshold for the row-complete GEMM + LayerNorm kernel
 
     def __del__(self):
         try:
@@ -232,7 +233,7 @@ class _Engine:
         return {}
 
     def __setstate__(self, state):
-        self.handle, self.key, self.ws = None, None, None
+        self.handle, self.key, self.ws, self.fused_ln_min_rows = None, None, {}, 0
 
     def __deepcopy__(self, memo):
         return _Engine()
@@ -290,7 +291,7 @@ class _Engine:
             w.sh_out_w, w.sh_out_b = fp(head.output.weight), fp(head.output.bias)
             spec_out = head.output.out_features
         c = _lib.EncoderConfig(in_dim, cfg.hidden_size, layers, cfg.num_attention_heads, cfg.intermediate_size,
-                               cfg.layer_norm_eps, spec_out)
+                               cfg.layer_norm_eps, spec_out, int(self.fused_ln_min_rows))
         out = _lib.c_void_p()
         with torch.cuda.device(device):
             _lib.check(lib.se_encoder_create(c, w, out), 'se_encoder_create')
@@ -300,10 +301,10 @@ class _Engine:
 
     def _ensure(self, model, head, device):
         params = ([p for p in model.parameters()] if model is not None else []) + ([p for p in head.parameters()] if head is not None else [])
-        key = (device.index, tuple((p.data_ptr(), p._version) for p in params))
+        key = (device.index, self.fused_ln_min_rows, tuple((p.data_ptr(), p._version) for p in params))
         if self.handle is None or key != self.key:
-            same_storage = (self.handle is not None and self.key is not None and self.key[0] == key[0] and head is None and
-                            tuple(a for a, _ in self.key[1]) == tuple(a for a, _ in key[1]) and
+            same_storage = (self.handle is not None and self.key is not None and self.key[:2] == key[:2] and head is None and
+                            tuple(a for a, _ in self.key[2]) == tuple(a for a, _ in key[2]) and
                             all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in params))
             if same_storage:
                 keep = []
@@ -332,9 +333,11 @@ class _Engine:
     def _workspace(self, handle, B, T, device):
         lib = _lib.load()
         n = lib.se_encoder_workspace_bytes(handle, B, T)
-        if self.ws is None or self.ws.numel() < n or self.ws.device != device:
-            self.ws = torch.empty(n, device=device, dtype=torch.uint8)
-        return self.ws, n
+        sid = torch.cuda.current_stream(device).cuda_stream
+        ws = self.ws.get(sid)
+        if ws is None or ws.numel() < n or ws.device != device:
+            ws = self.ws[sid] = torch.empty(n, device=device, dtype=torch.uint8)
+        return ws, n
 
     def encode(self, model, head, feats, lengths=None):
         if not feats.is_cuda:

@@ -24,3 +24,25 @@ def test_graphed_enhance_step_matches_eager(gpu):
         # the level normalisation and the loss reduce with atomics (order-dependent in the last bit), eager vs eager too
         assert (got_wav - ref_wav).abs().max().item() <= 1e-6 * ref_wav.abs().max().item()
         assert abs(got_loss.item() - ref_loss.item()) <= 1e-6 * abs(ref_loss.item())
+
+
+def test_two_stream_enhance_step_matches_single_stream(gpu):
+    """the batch processed as two half batches on two HIP streams (per-stream workspaces, recombined global masked-mean loss)
+    gives the single-stream results, call after call"""
+    from speech_enhancement_by_s3prl_amd import pipeline, synth
+    cfg = pipeline.make_config(layers=2)
+    ckpt = pipeline.synthetic_checkpoint(cfg, seed=2)
+    pre = pipeline.build_preprocessor(cfg, gpu)
+    one = pipeline.UpstreamEnhanceStep(pre, pipeline.build_upstream(ckpt, gpu))
+    two = pipeline.UpstreamEnhanceStep(pre, pipeline.build_upstream(ckpt, gpu), streams=2)
+    for seed in (5, 6, 7):
+        lengths, wavs = synth.synth_batch(5, 24000, first=seed, ragged=True)          # odd batch: halves of 2 and 3, ragged lengths
+        lengths, wavs = lengths.to(gpu), wavs.to(gpu)
+        max_len = int(wavs.shape[-1])
+        ref_wav, ref_loss, ref_pred = one(wavs, lengths, max_len)
+        got_wav, got_loss, got_pred = two(wavs, lengths, max_len)
+        torch.cuda.synchronize()
+        assert got_pred.shape == ref_pred.shape and got_wav.shape == ref_wav.shape
+        assert (got_pred - ref_pred).abs().max().item() <= 1e-5 * ref_pred.abs().max().item()
+        assert (got_wav - ref_wav).abs().max().item() <= 1e-5 * ref_wav.abs().max().item()
+        assert abs(got_loss.item() - ref_loss.item()) <= 1e-6 * abs(ref_loss.item())
