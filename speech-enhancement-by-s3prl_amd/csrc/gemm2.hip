@@ -389,6 +389,7 @@ extern "C" int se_gemm2_splitk_launch(const uint16_t* A, int lda, const uint16_t
                                       float* partials, void* stream) {
   GArgs g{A, lda, W, ldw, nullptr, nullptr, M, N, Kc, SE_ACT_IDENTITY, nullptr, partials, N, (N % 4 == 0) ? 1 : 0, 0,
           se::as_stream(stream), 1, splits, (size_t)M * N};
+  if (M <= 8192) return launch_cfg<2, 2, 0>(g);      // 128 x 128 tiles, two workgroups per CU: the small-batch (serving) path
   if (Kc >= 2 * se::k2BK) return launch_cfg<4, 3, 1>(g);
   return launch_cfg<4, 3, 0>(g);
 }
