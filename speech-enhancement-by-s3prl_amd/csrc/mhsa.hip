@@ -96,6 +96,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
   for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
   float m_run = -INFINITY, l_run = 0.f;
   const float c = 0.125f * 1.44269504088896340736f;     // 1/sqrt(64) * log2(e)
+  constexpr float kDefer = 8.f;
   typedef float f2 __attribute__((ext_vector_type(2)));
 
   // ---- loop-invariant LDS byte offsets (buffer / key-block / k-step parts are compile-time immediates below)
@@ -144,7 +145,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
     float mx = fmaxf(s0[0], s1[0]);                                                                                        \
     _Pragma("unroll") for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, s0[r]), s1[r]);       /* v_max3_f32 */            \
     mx = fmaxf(mx, __shfl_xor(mx, 32));                                                                                    \
-    const float m_new = fmaxf(m_run, mx);                                                                                  \
+    /* deferred rescale: the reference maximum only moves when the tile maximum exceeds it by > 2^kDefer (log2 domain), */  \
+    /* so P <= 2^kDefer instead of 1 (bf16 / fp32 keep their relative precision) and the O-wide multiply is rare        */  \
+    const float m_new = ((mx - m_run) * c > kDefer) ? mx : m_run;                                                          \
     const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);                                                       \
     const f2 c2 = {c, c}, mc2 = {-m_new * c, -m_new * c};                                                                  \
     f2 rs2 = {0.f, 0.f};                                                                                                   \

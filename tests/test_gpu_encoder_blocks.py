@@ -83,6 +83,29 @@ def test_mhsa_vs_torch(gpu, B, T, heads, lens):
     assert err < 2e-2 * ref.abs().max().item(), err      # P and the output are rounded to bf16 (2^-9 relative)
 
 
+def test_mhsa_rising_maxima(gpu):
+    """Row maxima that climb tile after tile, by less than the deferred-rescale threshold for some query rows and by more for
+    others in the same wave: exercises both sides of the (rare, data-dependent) rescale branch of the online softmax."""
+    L = _lib()
+    lib = L.load()
+    B, T, heads = 1, 512, 2
+    torch.manual_seed(11)
+    u = torch.ones(64, device=gpu) / 8.0                                            # |u| = 1
+    a = torch.rand(T, device=gpu) * 8.0                                             # per-query gain: growth per tile = a (nats)
+    bk = 8.0 * (torch.arange(T, device=gpu) // 64).float() + torch.rand(T, device=gpu)
+    q = a[:, None] * u[None, :] * 8.0                                               # score / sqrt(64) = a_i * b_j
+    k = bk[:, None] * u[None, :]
+    v = torch.randn(T, 64, device=gpu)
+    one = torch.cat([q, k, v], dim=1)                                               # (T, 192) for one head
+    qkv = torch.cat([one[:, 0:64], one[:, 0:64].flip(0), one[:, 64:128], one[:, 64:128], one[:, 128:], one[:, 128:]], dim=1).bfloat16()
+    ctx = torch.empty(T, 128, device=gpu, dtype=torch.bfloat16)
+    lengths = torch.tensor([T - 30], device=gpu, dtype=torch.int32)
+    L.check(lib.se_mhsa_fwd_bf16(L.ptr(qkv), L.ptr(lengths), B, T, heads, L.ptr(ctx), L.stream()), 'se_mhsa_fwd_bf16')
+    ref = mhsa_ref(qkv, lengths, B, T, heads)
+    err = (ctx.double() - ref).abs().max().item()
+    assert err < 2e-2 * ref.abs().max().item(), err
+
+
 def test_mhsa_exact_integers(gpu):
     """uniform attention (Q = 0) over integer V: output = mean of V rows -> exercises the V^T / P operand maps."""
     L = _lib()
