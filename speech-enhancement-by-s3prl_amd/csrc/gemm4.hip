@@ -12,8 +12,8 @@
 //   LDS      : the weight K-step (768 x 32 bf16 = 48 KiB) does not fit a 3-deep ring, so it is split by the three
 //              64-column groups a wave walks: a ring of SIX 16 KiB weight pieces refilled at sub-step granularity (five
 //              pieces in flight), plus a 4-deep ring of 8 KiB A pieces: 96 + 32 KiB; 64-B rows, chunk ^ ((-(row>>2))&3)
-//   schedule : per K-step three {LDS reads + DMA issue + waits | barrier | 16 MFMAs | barrier} sub-steps, waves 4-7 one
-//              barrier behind waves 0-3 (ping-pong); counted vmcnt (9 / 10 DMAs younger than the piece needed next)
+//   schedule : per K-step three {LDS reads + waits | barrier | 16 MFMAs with the ring-refill DMAs between them | barrier} sub-steps,
+//              waves 4-7 one barrier behind waves 0-3 (ping-pong); counted vmcnt (6-8 DMAs younger than the piece needed next)
 //   epilogue : swapped operands (C^T accumulators, initialised with bias + residual before the K loop); ln_w / ln_b staged
 //              in the (then dead) ring; exact two-pass mean / variance per row (lane group -> wave -> LDS across the 4 column waves);
 //              fp32 and bf16 rows stored straight from registers
@@ -25,11 +25,9 @@
 namespace se {
 
 constexpr int k4BM = 128, k4N = 768, k4BK = 32, k4Threads = 512;
-constexpr int k4WPiece = 256 * 64, k4WSlots = 6, k4APiece = 128 * 64, k4ASlots = 4;
-constexpr int k4WBytes = k4WPiece * k4WSlots;                 // 98 304
+constexpr int k4WPiece = 256 * 64, k4APiece = 128 * 64, k4ASlots = 4;
 constexpr int k4ABytes = k4APiece * k4ASlots;                 // 32 768
-constexpr int k4RedOff = k4WBytes + k4ABytes;                 // LN partial sums: float [2 passes][2 wr][4 wc][64 rows] = 4 KiB
-constexpr int k4Lds = k4RedOff + 2 * 2 * 4 * 64 * 4;          // 135 168 B
+constexpr int k4_lds(int slots) { return k4WPiece * slots + k4ABytes + 2 * 2 * 4 * 64 * 4; }   // ring + A ring + LN partial sums (4 KiB)
 
 typedef __attribute__((address_space(3))) void* lds4_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb4_ptr_t;
@@ -37,11 +35,14 @@ typedef const __attribute__((address_space(1))) void* glb4_ptr_t;
 __device__ __forceinline__ int swz4_f(int row) { return (-(row >> 2)) & 3; }
 __device__ __forceinline__ int swz4(int row, int chunk) { return row * 64 + ((chunk ^ swz4_f(row)) << 4); }
 
+// SLOTS: weight-ring depth (pieces; SLOTS - 1 in flight).  INM: the ring-refill DMAs are issued between the MFMAs (1) or in the read phase (0)
+template <int SLOTS, int INM>
 __global__ __launch_bounds__(k4Threads) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm4_res_ln_kernel(
     const uint16_t* __restrict__ A, int lda, const uint16_t* __restrict__ W, int ldw, const float* __restrict__ bias,
     const float* __restrict__ residual, const float* __restrict__ ln_w, const float* __restrict__ ln_b, float eps, int M, int K,
     float* __restrict__ out_f32, uint16_t* __restrict__ out_bf16, int ntiles) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int k4WSlots = SLOTS, k4WBytes = k4WPiece * SLOTS, k4RedOff = k4WBytes + k4ABytes;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
@@ -75,6 +76,10 @@ __global__ __launch_bounds__(k4Threads) __attribute__((amdgpu_waves_per_eu(2, 2)
     __builtin_amdgcn_global_load_lds((glb4_ptr_t)(w_src[0] + (j) * w_jstep + (g) * k4BK), (lds4_ptr_t)(sb_), 16, 0, 0);      \
     __builtin_amdgcn_global_load_lds((glb4_ptr_t)(w_src[1] + (j) * w_jstep + (g) * k4BK), (lds4_ptr_t)(sb_ + 8192), 16, 0, 0); \
   } while (0)
+#define SE4_ISSUE_W0(g, j, slot)                                                                                             \
+  __builtin_amdgcn_global_load_lds((glb4_ptr_t)(w_src[0] + (j) * w_jstep + (g) * k4BK), (lds4_ptr_t)(smem + (slot) * k4WPiece + wave * 1024), 16, 0, 0)
+#define SE4_ISSUE_W1(g, j, slot)                                                                                             \
+  __builtin_amdgcn_global_load_lds((glb4_ptr_t)(w_src[1] + (j) * w_jstep + (g) * k4BK), (lds4_ptr_t)(smem + (slot) * k4WPiece + wave * 1024 + 8192), 16, 0, 0)
 #define SE4_ISSUE_A(g)                                                                                                       \
   do {                                                                                                                       \
     __builtin_amdgcn_global_load_lds((glb4_ptr_t)(a_src + (g) * k4BK),                                                       \
@@ -91,6 +96,7 @@ __global__ __launch_bounds__(k4Threads) __attribute__((amdgpu_waves_per_eu(2, 2)
   SE4_ISSUE_W(0, 2, 2);
   SE4_ISSUE_W(1, 0, 3);
   SE4_ISSUE_W(1, 1, 4);
+  if (SLOTS == 7) SE4_ISSUE_W(1, 2, 5);
   // C^T accumulators: acc[i][t][r] = C[row wr*64 + 16 i + (lane & 15)][col wc*192 + 16 t + 4 (lane >> 4) + r].
   // They are INITIALISED with bias + residual (the registers are free now and the loads overlap the DMA prologue); adding
   // them in the epilogue, next to 192 live accumulators, spilled ~1 KB per lane.
@@ -122,7 +128,8 @@ __global__ __launch_bounds__(k4Threads) __attribute__((amdgpu_waves_per_eu(2, 2)
 
   const int nk = K / k4BK;                 // >= 4 (launcher)
   const bool late = wave >= 4;
-  asm volatile("s_waitcnt vmcnt(10)" ::: "memory");        // A(0), W piece 0 landed
+  if (SLOTS == 7) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");        // A(0), W piece 0 landed
+  else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   if (late) __builtin_amdgcn_s_barrier();                   // stagger: waves 4-7 one barrier behind
 
@@ -140,35 +147,64 @@ __global__ __launch_bounds__(k4Threads) __attribute__((amdgpu_waves_per_eu(2, 2)
 #pragma unroll
         for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(a_s + a_off[i]);
       }
-      // refill: piece s+5 goes to the slot of piece s-1, whose last readers (waves 4-7) completed their reads
-      // (lgkmcnt(0) below) before the barrier that this wave passed at the end of the previous sub-step
-      {
-        const int g5 = g + (j == 0 ? 1 : 2), j5 = (j + 2) % 3;
-        int slot5 = wslot + 5;
-        if (slot5 >= k4WSlots) slot5 -= k4WSlots;
-        if (g5 < nk) SE4_ISSUE_W(g5, j5, slot5);
+      // ring refill: piece s+SLOTS-1 goes to the slot of piece s-1, whose last readers (waves 4-7) completed their reads (lgkmcnt(0)
+      // below) before the barrier this wave passed at the end of the previous sub-step; A(g+3) to the slot of A(g-1).  INM: issued
+      // between the MFMAs below instead (an LDS-DMA issued beside outstanding ds_reads costs the wave ~130 cycles; which phase has the
+      // slack depends on the clock the data lets the matrix pipe run at -- see se_gemm_res_ln_bf16)
+      const int gN = g + (j + SLOTS - 1) / 3, jN = (j + SLOTS - 1) % 3;
+      int slotN = wslot + SLOTS - 1;
+      if (slotN >= k4WSlots) slotN -= k4WSlots;
+      if (!INM) {
+        if (gN < nk) SE4_ISSUE_W(gN, jN, slotN);
         if (j == 0 && g + 3 < nk) SE4_ISSUE_A(g + 3);
       }
-      // piece s+1 must have landed.  DMAs younger than its two, in issue order: four pieces (8) + the A pieces issued
-      // in those sub-steps: 2 when j != 2, 1 when j == 2 (one fewer during the first K-step and once A issue stops)
-      if (g + 2 >= nk) {
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      } else if (g == 0 || g + 3 >= nk) {
-        if (j == 2 && g != 0) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory");
-      } else {
-        if (j == 2) asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
+      // piece s+1 must have landed: wait until only the DMAs issued after its second half remain.  The counts come from replaying
+      // the per-wave issue order (prologue, then per sub-step [read-phase issues | wait | MFMA-phase issues]); rows: first K-step,
+      // steady state, K-steps nk-3, nk-2, nk-1 (issue stops: A after nk-4, pieces after sub-step 3 nk - SLOTS)
+      {
+        // rows per configuration {first K-step, steady, nk-3, nk-2, nk-1} x j; selected with scalar compares only (a run-time indexed
+        // table would become a memory load inside the loop)
+        //   6 slots, read-phase issue  {9,9,9} {10,10,9} {9,9,8}    {8,6,4} {2,0,0}
+        //   6 slots, MFMA-phase issue  {6,7,7} {7,8,7}   {7,7,6}    {6,6,4} {2,0,0}
+        //   7 slots, read-phase issue  {11..}  {12..}    {11..}     {8,6,4} {2,0,0}
+        //   7 slots, MFMA-phase issue  {8,9,9} {9,10,10} {9,9,9}    {8,6,4} {2,0,0}
+        int n;
+        if (g == nk - 1) n = (j == 0) ? 2 : 0;
+        else if (g == nk - 2) n = (j == 0) ? ((SLOTS == 6 && INM) ? 6 : 8) : (j == 1 ? 6 : 4);
+        else if (SLOTS == 6 && !INM) n = (g == 0) ? 9 : (g == nk - 3) ? (j == 2 ? 8 : 9) : (j == 2 ? 9 : 10);
+        else if (SLOTS == 6 && INM) n = (g == 0) ? (j == 0 ? 6 : 7) : (g == nk - 3) ? (j == 2 ? 6 : 7) : (j == 1 ? 8 : 7);
+        else if (SLOTS == 7 && !INM) n = (g == 0 || g == nk - 3) ? 11 : 12;
+        else n = (g == 0) ? (j == 0 ? 8 : 9) : (g == nk - 3) ? 9 : (j == 0 ? 9 : 10);
+        switch (n) {
+          case 0: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); break;
+          case 2: asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory"); break;
+          case 4: asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); break;
+          case 6: asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory"); break;
+          case 7: asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory"); break;
+          case 8: asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory"); break;
+          case 9: asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory"); break;
+          case 10: asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory"); break;
+          case 11: asm volatile("s_waitcnt vmcnt(11) lgkmcnt(0)" ::: "memory"); break;
+          default: asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory"); break;
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 4; ++i) {
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj)
           acc[i][4 * j + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[jj], af[i], acc[i][4 * j + jj], 0, 0, 0);
+        if (INM) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (i == 0 && gN < nk) SE4_ISSUE_W0(gN, jN, slotN);
+          if (i == 1 && gN < nk) SE4_ISSUE_W1(gN, jN, slotN);
+          if (i == 2 && j == 0 && g + 3 < nk) SE4_ISSUE_A(g + 3);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
@@ -275,16 +311,28 @@ extern "C" int se_gemm_res_ln_bf16(const uint16_t* A, int lda, const uint16_t* W
   SE_REQUIRE(M > 0 && lda >= K && ldw >= K && lda % 8 == 0 && ldw % 8 == 0, "se_gemm_res_ln_bf16: bad leading dimensions");
   SE_REQUIRE((((uintptr_t)A | (uintptr_t)W | (uintptr_t)residual_f32 | (uintptr_t)out_f32 | (uintptr_t)out_bf16 | (uintptr_t)bias |
                (uintptr_t)ln_w | (uintptr_t)ln_b) % 16) == 0, "se_gemm_res_ln_bf16: pointers must be 16-B aligned");
-  static bool attr_set = false;
-  if (!attr_set) {
-    SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::gemm4_res_ln_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, se::k4Lds));
-    attr_set = true;
+  static int cfg = -1;
+  if (cfg < 0) {
+    const char* e = getenv("SE_AMD_GEMM4_CFG");          // developer switch: bit 0 = DMA issue between the MFMAs, bit 1 = 7-piece ring
+    cfg = e ? (atoi(e) & 3) : 1;        // default: 6 pieces, MFMA-phase issue -- equal to read-phase issue when A streams from the Infinity Cache (B = 32 bench), 17 % faster when it comes from HBM
+    SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::gemm4_res_ln_kernel<6, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, se::k4_lds(6)));
+    SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::gemm4_res_ln_kernel<6, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, se::k4_lds(6)));
+    SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::gemm4_res_ln_kernel<7, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, se::k4_lds(7)));
+    SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::gemm4_res_ln_kernel<7, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, se::k4_lds(7)));
   }
   const int ntiles = (M + se::k4BM - 1) / se::k4BM;
   hipStream_t st = se::as_stream(stream);
   se::ProfScope prof(se::kProfGemm, 2.0 * M * (double)N * K, st);
-  hipLaunchKernelGGL(se::gemm4_res_ln_kernel, dim3(ntiles), dim3(se::k4Threads), se::k4Lds, st, A, lda, W, ldw, bias, residual_f32, ln_w, ln_b,
-                     eps, M, K, out_f32, out_bf16, ntiles);
+#define SE4_LAUNCH(SL, IM)                                                                                                              \
+  hipLaunchKernelGGL((se::gemm4_res_ln_kernel<SL, IM>), dim3(ntiles), dim3(se::k4Threads), se::k4_lds(SL), st, A, lda, W, ldw, bias, residual_f32, \
+                     ln_w, ln_b, eps, M, K, out_f32, out_bf16, ntiles)
+  switch (cfg) {
+    case 1: SE4_LAUNCH(6, 1); break;
+    case 2: SE4_LAUNCH(7, 0); break;
+    case 3: SE4_LAUNCH(7, 1); break;
+    default: SE4_LAUNCH(6, 0); break;
+  }
+#undef SE4_LAUNCH
   SE_LAUNCH_CHECK();
   return SE_OK;
 }
