@@ -19,6 +19,8 @@ LIB = os.path.join(HERE, 'libse_amd.so')
 ARCH = 'gfx950'
 FLAGS = ['-O3', '-std=c++17', '-fPIC', f'--offload-arch={ARCH}', '-fno-gpu-rdc', '-Wall', '-Wno-unused-function',
          '-Wno-comment', '-I' + os.path.join(HERE, '..', 'include')]
+if os.environ.get('SE_AMD_BUILD_STAMPS') == '1':       # developer build: in-kernel s_memtime stamps (tools/*_stamps.py); never for measurements
+    FLAGS.append('-DSE_AMD_STAMPS')
 
 
 def _hipcc():

@@ -24,11 +24,15 @@ constexpr int k2BN = 128, k2BK = 64;
 //           (pure HBM traffic) overlaps the other's MFMA main loop
 // diagnostic stamps (dbg bit 4): lane 0 of every wave of workgroup `blockIdx.x < 8` appends s_memtime values to
 // the buffer passed as `residual` (timing-only build; results are garbage)
+// Compiled in only with -DSE_AMD_STAMPS (SE_AMD_BUILD_STAMPS=1 python build.py): even switched off, the exec-masked stamp sites cost the
+// hot loops measurably (13 % in gemm4.hip's sub-steps).
 __device__ __forceinline__ void stamp(unsigned long long* buf, int& idx, bool on) {
+#ifdef SE_AMD_STAMPS
   if (on) {
     const unsigned long long t = __builtin_amdgcn_s_memtime();
     buf[idx++] = t;
   }
+#endif
 }
 
 template <int WR, int STAGES>

@@ -46,7 +46,9 @@ __device__ __forceinline__ float act3(float v, int act) {
 // diagnostic stamps (dbg bit 4, SE_AMD_GEMM_DBG=16): lane 0 of every wave of workgroups 0..7 appends s_memtime values to the
 // buffer passed as `residual` (timing-only run; results are garbage)
 __device__ __forceinline__ void stamp3(unsigned long long* buf, int& idx, bool on) {
+#ifdef SE_AMD_STAMPS
   if (on) buf[idx++] = __builtin_amdgcn_s_memtime();
+#endif
 }
 
 // ACT: compile-time activation; EF bit 0: fp32 residual, bit 1: bf16 output, bit 2: fp32 output (N % 4 == 0, 16-B rows)

@@ -74,7 +74,11 @@ __global__ __launch_bounds__(kThreads) void stft_kernel(
   // developer stamps (SE_AMD_STFT_DBG=1): thread 0 of workgroups (x = 5, y < 8) records s_memtime at phase boundaries
   const bool st_on = dbgbuf != nullptr && tid == 0 && blockIdx.x == 5 && b < 8;
   int st_i = 0;
+#ifdef SE_AMD_STAMPS
 #define SE_STAMP() do { if (st_on) dbgbuf[b * 16 + st_i++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SE_STAMP() do { (void)st_on; (void)st_i; } while (0)
+#endif
   SE_STAMP();
   const float* x = wavs + ((size_t)b * C + channel) * (size_t)T;
 

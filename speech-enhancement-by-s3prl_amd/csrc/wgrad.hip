@@ -118,10 +118,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const bool st_on = stamps && lane == 0 && blockIdx.x < 8;
   unsigned long long* st_buf = stamps + ((size_t)blockIdx.x * 8 + wave) * 256;
   int st_i = 0;
+#ifdef SE_AMD_STAMPS      // -DSE_AMD_STAMPS builds only: the exec-masked sites cost the hot loop even when switched off
 #define SEW_STAMP()                                                        \
   do {                                                                     \
     if (st_on && st_i < 256) st_buf[st_i++] = __builtin_amdgcn_s_memtime(); \
   } while (0)
+#else
+#define SEW_STAMP() do { (void)st_on; (void)st_buf; (void)st_i; } while (0)
+#endif
   SEW_STAMP();
   if (nt > 0) SEW_ISSUE(0, 0);
   if (nt > 1) SEW_ISSUE(1, 1);
