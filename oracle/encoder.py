@@ -110,6 +110,18 @@ def _lowbias32(x):
     return x
 
 
+def _mix24(x):
+    """the per-pair mixer of csrc/dropout.h (lowbias32 structure with 24-bit multiplies) on int64 tensors holding uint32 values"""
+    M = 0xffffffff
+    x = x & M
+    x = x ^ (x >> 16)
+    x = ((x & 0xffffff) * 0x7feb35) & M
+    x = x ^ (x >> 15)
+    x = ((x & 0xffffff) * 0x46ca6b) & M
+    x = x ^ (x >> 16)
+    return x
+
+
 def dropout_key(seed, site):
     M = 0xffffffff
     v = ((seed & M) * 0x9E3779B9 + ((seed >> 32) & M) * 0x85EBCA6B + site) & M
@@ -127,7 +139,7 @@ def keep_mask(seed, site, rows, cols, p, pairs_per_row=None):
     r = torch.arange(rows, dtype=torch.int64)[:, None]
     c = torch.arange(cols, dtype=torch.int64)[None, :]
     pair = (r * ppr + (c >> 1)) & 0xffffffff
-    bits = _lowbias32(pair ^ key)
+    bits = _mix24(pair ^ key)
     v = torch.where((c & 1) == 1, bits >> 16, bits & 0xffff)
     return v >= thr
 
