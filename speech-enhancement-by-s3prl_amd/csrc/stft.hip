@@ -5,14 +5,16 @@
 //            neighbouring frames overlap by 60 %: the re-reads are L1/L2 hits, HBM sees each sample once
 //   pass A : 25 in-place radix-8 butterflies per frame          (fft200.h)
 //   pass B : 8 in-register 25-point DFTs per frame
-//   post   : X[k], X[200-k] from Z[k], Z[200-k]; (power, atan2 phase) written IN PLACE into the LDS slots
-//   write  : the frames of a workgroup are ONE contiguous span of (B, F, K) in each plane: streamed out with aligned
-//            16-B stores.  No global load sits in any output loop (all tables live in LDS): a load there would force
+//   post   : X[k], X[200-k] from Z[k], Z[200-k]; (power, atan2 phase) held in registers across a barrier, then written into two
+//            LDS PLANES laid out exactly like the output span (frame-major, 201 bins, shifted by the span's offset mod 4)
+//   write  : the frames of a workgroup are ONE contiguous span of (B, F, K) in each plane: a linear LDS -> global copy with
+//            aligned 16-B loads and stores (3 instructions per 4 outputs; the per-element de-interleave of the first version
+//            was 16 % of the kernel's instructions).  No global load sits in any output loop (all tables live in LDS): a load there would force
 //            vmcnt(0) per iteration, which on gfx950 also drains the previous iteration's stores (one in-order counter)
 //            and serialises the loop on the HBM write latency.
 //   mel    : sparse HTK triangles over the power kept in LDS; the filter table is staged into the unused .y halves
 //            of the power slots; written feature-major (B, n_mels, F)
-// LDS: 30 x 200 float2 + twiddles + window = 51 200 B -> 3 workgroups per CU.  Bound: HBM (2 249 608 B per
+// LDS: planes 2 x 6036 floats (>= the 30 x 200 float2 FFT buffer) + two twiddle tables + window = 53 088 B -> 3 workgroups per CU.  Bound: HBM (2 249 608 B per
 // utterance-channel).
 #include <stdlib.h>
 #include "plan.h"
@@ -26,6 +28,7 @@ constexpr int kFR = 30;          // frames per workgroup: 30 x 25 = 750 pass-A i
 constexpr int kThreads = 256;
 constexpr int kFillIters = (kFR * kHalf + kThreads - 1) / kThreads;     // 25
 constexpr int kPostIters = (kFR * 101 + kThreads - 1) / kThreads;       // 13
+constexpr int kPlane = 6036;     // floats per output plane in LDS: >= 3 (alignment shift) + 30 x 201, a multiple of 4
 
 __device__ __forceinline__ int reflect(int i, int T) {
   // numpy / torch 'reflect' (no edge repeat); valid for |overshoot| < T
@@ -58,14 +61,14 @@ __device__ __forceinline__ float fast_atan2(float y, float x) {
 
 __global__ __launch_bounds__(kThreads) void stft_kernel(
     const float* __restrict__ wavs, int C, int T, int channel, int F,
-    const float* __restrict__ window, const float2* __restrict__ tw400g,
+    const float* __restrict__ window, const float2* __restrict__ tw400g, const float2* __restrict__ tw200g,
     const int* __restrict__ mel_start, const int* __restrict__ mel_len, const float* __restrict__ mel_w, int n_mels,
     float* __restrict__ power, float* __restrict__ phase, float* __restrict__ complx, float* __restrict__ mel,
     unsigned long long* __restrict__ dbgbuf, int vec_ok) {
-  __shared__ float2 Y[kFR * kHalf];
-  __shared__ float2 tw[kHalf];        // (cos, sin)(2 pi k / 400), k < 200;  W200^t = tw[2t] (t < 100), -tw[2t-200] otherwise
+  __shared__ __attribute__((aligned(16))) float2 Y[kPlane];   // FFT buffer (30 x 200 complex), later the two output planes
+  __shared__ float2 tw[kHalf];        // (cos, sin)(2 pi k / 400), k < 200: the recombination twiddles
+  __shared__ float2 tw2[kHalf];       // (cos, sin)(2 pi t / 200): pass-A twiddles W200^(j q), j q <= 168
   __shared__ float win[kNfft];
-  __shared__ float2 tail[32];         // (power, phase) of bin 200 per frame
 
   const int tid = threadIdx.x;
   const int b = blockIdx.y;
@@ -83,7 +86,7 @@ __global__ __launch_bounds__(kThreads) void stft_kernel(
   const float* x = wavs + ((size_t)b * C + channel) * (size_t)T;
 
   // table loads are issued together with the frame loads below and written to LDS afterwards (one memory latency)
-  const float2 twv = tw400g[min(tid, kHalf - 1)];
+  const float2 twv = tw400g[min(tid, kHalf - 1)], tw2v = tw200g[min(tid, kHalf - 1)];
   const float wv0 = window[tid], wv1 = window[min(tid + kThreads, kNfft - 1)];
 
   // ---- fill: windowed samples as packed complex.  item = tid + 256 r -> (frame, n) advanced incrementally.
@@ -100,7 +103,7 @@ __global__ __launch_bounds__(kThreads) void stft_kernel(
         if (n >= kHalf) { n -= kHalf; f += 1; }
       }
     }
-    if (tid < kHalf) tw[tid] = twv;
+    if (tid < kHalf) { tw[tid] = twv; tw2[tid] = tw2v; }
     win[tid] = wv0;
     if (tid + kThreads < kNfft) win[tid + kThreads] = wv1;
     __syncthreads();                                      // window table visible
@@ -118,7 +121,7 @@ __global__ __launch_bounds__(kThreads) void stft_kernel(
       }
     }
   } else {
-    if (tid < kHalf) tw[tid] = twv;
+    if (tid < kHalf) { tw[tid] = twv; tw2[tid] = tw2v; }
     win[tid] = wv0;
     if (tid + kThreads < kNfft) win[tid + kThreads] = wv1;
     __syncthreads();
@@ -141,10 +144,8 @@ __global__ __launch_bounds__(kThreads) void stft_kernel(
     fft8<-1>(v);
 #pragma unroll
     for (int q = 1; q < 8; ++q) {
-      const int t2 = 2 * j * q;                            // < 400
-      float2 w = tw[t2 < kHalf ? t2 : t2 - kHalf];
-      const float sg = t2 < kHalf ? 1.f : -1.f;
-      v[q] = cmul(v[q], make_float2(sg * w.x, -sg * w.y)); // forward: exp(-i ...)
+      const float2 w = tw2[j * q];                         // j q <= 168
+      v[q] = cmul(v[q], make_float2(w.x, -w.y));           // forward: exp(-i ...)
     }
 #pragma unroll
     for (int q = 0; q < 8; ++q) frame[25 * q + j] = v[q];
@@ -173,14 +174,19 @@ __global__ __launch_bounds__(kThreads) void stft_kernel(
   __syncthreads();
   SE_STAMP();   // pass B done
 
-  // ---- post: pairs (k, 200-k), k = 0..100, IN PLACE: slot k <- (power, phase) of bin k; bin 200 goes to tail[f]
+  // ---- post: pairs (k, 200-k), k = 0..100 -> (power, phase) of bins k and 200-k, kept in registers until every thread has read its
+  //      inputs (the planes written next overlay OTHER frames' FFT outputs)
   const size_t obase = ((size_t)b * F + f0) * kBins;
+  const int pad = (int)(obase & 3);             // LDS float index = pad + (output index - obase): same 16-B phase as the global span
+  float2 r1[kPostIters], r2[kPostIters];
   {
     int f = tid / 101, k = tid - f * 101;
-#pragma unroll 1
+#pragma unroll
     for (int r = 0; r < kPostIters; ++r) {
+      r1[r] = make_float2(0.f, 0.f);
+      r2[r] = make_float2(0.f, 0.f);
       if (f < nf) {
-        float2* Z = Y + f * kHalf;
+        const float2* Z = Y + f * kHalf;
         const float2 zk = Z[k];
         const float2 zn = Z[k == 0 ? 0 : kHalf - k];
         // E = (zk + conj(zn))/2 ; O = (zk - conj(zn))/(2i) ; P = W^k O, W^k = (c, -s)
@@ -195,11 +201,8 @@ __global__ __launch_bounds__(kThreads) void stft_kernel(
           reinterpret_cast<float2*>(complx)[o1] = X1;
           if (k != 100) reinterpret_cast<float2*>(complx)[o1 + (kHalf - 2 * k)] = X2;
         }
-        const float2 r1 = make_float2(X1.x * X1.x + X1.y * X1.y, fast_atan2(X1.y, X1.x));
-        const float2 r2 = make_float2(X2.x * X2.x + X2.y * X2.y, fast_atan2(X2.y, X2.x));
-        Z[k] = r1;
-        if (k == 0) tail[f] = r2;
-        else if (k != 100) Z[kHalf - k] = r2;
+        r1[r] = make_float2(X1.x * X1.x + X1.y * X1.y, fast_atan2(X1.y, X1.x));
+        r2[r] = make_float2(X2.x * X2.x + X2.y * X2.y, fast_atan2(X2.y, X2.x));
       }
       k += kThreads - 2 * 101;                              // 256 = 2 * 101 + 54
       f += 2;
@@ -207,44 +210,53 @@ __global__ __launch_bounds__(kThreads) void stft_kernel(
     }
   }
   __syncthreads();
+  float* Pw = reinterpret_cast<float*>(Y) + pad;            // power plane: Pw[f * 201 + k]
+  float* Ph = Pw + kPlane;                                  // phase plane
+  {
+    int f = tid / 101, k = tid - f * 101;
+#pragma unroll
+    for (int r = 0; r < kPostIters; ++r) {
+      if (f < nf) {
+        const int o = f * kBins + k;
+        Pw[o] = r1[r].x;
+        Ph[o] = r1[r].y;
+        if (k != 100) {                                     // k = 0 pairs with bin 200
+          Pw[o + (kHalf - 2 * k)] = r2[r].x;
+          Ph[o + (kHalf - 2 * k)] = r2[r].y;
+        }
+      }
+      k += kThreads - 2 * 101;
+      f += 2;
+      if (k >= 101) { k -= 101; f += 1; }
+    }
+  }
+  __syncthreads();
   SE_STAMP();   // post done
 
-  // ---- write-out: the workgroup's nf x 201 outputs are ONE contiguous span of each plane: aligned 16-B stores for the
-  //      body, scalar head / tail (rows of 201 floats are not 16-B multiples, so the span start is arbitrary mod 4)
+  // ---- write-out: the workgroup's nf x 201 outputs are ONE contiguous span of each plane, and the LDS planes have the same layout
+  //      and 16-B phase: scalar head / tail (rows of 201 floats are not 16-B multiples), aligned float4 body
   if (power || phase) {
     const int total = nf * kBins;
-    const int head = vec_ok ? min(total, (int)((4 - (obase & 3)) & 3)) : total;
+    const int head = vec_ok ? min(total, (4 - pad) & 3) : total;
     const int nvec = (total - head) >> 2;
-    auto elem = [&](int f, int k) -> float2 { return (k < kHalf) ? Y[f * kHalf + k] : tail[f]; };
-    // head + tail elements (at most 3 + 3 in the vector case; everything in the unaligned-pointer fallback)
-    for (int i = tid; i < total; i += kThreads) {
-      if (i >= head && i < head + 4 * nvec) {
-        if (vec_ok) break;       // body handled below (i only grows)
-      }
-      const int f = i / kBins, k = i - f * kBins;
-      const float2 v = elem(f, k);
-      if (power) power[obase + i] = v.x;
-      if (phase) phase[obase + i] = v.y;
+    if (tid < head) {
+      if (power) power[obase + tid] = Pw[tid];
+      if (phase) phase[obase + tid] = Ph[tid];
     }
-    if (vec_ok) {
+    if (!vec_ok) {
+      for (int i = tid + kThreads; i < total; i += kThreads) {
+        if (power) power[obase + i] = Pw[i];
+        if (phase) phase[obase + i] = Ph[i];
+      }
+    } else {
       for (int i = head + 4 * nvec + tid; i < total; i += kThreads) {
-        const int f = i / kBins, k = i - f * kBins;
-        const float2 v = elem(f, k);
-        if (power) power[obase + i] = v.x;
-        if (phase) phase[obase + i] = v.y;
+        if (power) power[obase + i] = Pw[i];
+        if (phase) phase[obase + i] = Ph[i];
       }
       for (int v4 = tid; v4 < nvec; v4 += kThreads) {
         const int i = head + 4 * v4;
-        int f = i / kBins, k = i - f * kBins;
-        float2 e[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          e[j] = elem(f, k);
-          k += 1;
-          if (k == kBins) { k = 0; f += 1; }
-        }
-        if (power) *reinterpret_cast<float4*>(power + obase + i) = make_float4(e[0].x, e[1].x, e[2].x, e[3].x);
-        if (phase) *reinterpret_cast<float4*>(phase + obase + i) = make_float4(e[0].y, e[1].y, e[2].y, e[3].y);
+        if (power) *reinterpret_cast<float4*>(power + obase + i) = *reinterpret_cast<const float4*>(Pw + i);
+        if (phase) *reinterpret_cast<float4*>(phase + obase + i) = *reinterpret_cast<const float4*>(Ph + i);
       }
     }
   }
@@ -252,8 +264,8 @@ __global__ __launch_bounds__(kThreads) void stft_kernel(
   if (mel == nullptr) return;
   __syncthreads();
   SE_STAMP();
-  // ---- mel: stage the sparse filter table into the free .y halves of the power slots (one batched load per thread)
-  float* Yf = reinterpret_cast<float*>(Y);
+  // ---- mel: sparse HTK triangles over the power plane; the filter table is staged into the (now dead) phase plane
+  float* Tb = reinterpret_cast<float*>(Y) + kPlane + 4;     // [kMelMax * kMelMaxW weights][kMelMax starts][kMelMax lengths]
   {
     float wv[5];
 #pragma unroll
@@ -265,25 +277,23 @@ __global__ __launch_bounds__(kThreads) void stft_kernel(
 #pragma unroll
     for (int r = 0; r < 5; ++r) {
       const int i = tid + kThreads * r;
-      if (i < kMelMax * kMelMaxW) Yf[2 * i + 1] = wv[r];
+      if (i < kMelMax * kMelMaxW) Tb[i] = wv[r];
     }
     if (tid < kMelMax) {
-      Yf[2 * (kMelMax * kMelMaxW + tid) + 1] = __int_as_float(ms);
-      Yf[2 * (kMelMax * kMelMaxW + kMelMax + tid) + 1] = __int_as_float(ml);
+      Tb[kMelMax * kMelMaxW + tid] = __int_as_float(ms);
+      Tb[kMelMax * kMelMaxW + kMelMax + tid] = __int_as_float(ml);
     }
   }
   __syncthreads();
   for (int it = tid; it < n_mels * 32; it += kThreads) {
-    const int m = it >> 5, fl = it & 31;                    // lane <-> frame: conflict-free power reads (stride 400 dwords)
+    const int m = it >> 5, fl = it & 31;                    // lane <-> frame: power reads at stride 201 floats (odd: conflict-free)
     if (fl >= nf) continue;
-    const int st = __float_as_int(Yf[2 * (kMelMax * kMelMaxW + m) + 1]);
-    const int len = __float_as_int(Yf[2 * (kMelMax * kMelMaxW + kMelMax + m) + 1]);
+    const int st = __float_as_int(Tb[kMelMax * kMelMaxW + m]);
+    const int len = __float_as_int(Tb[kMelMax * kMelMaxW + kMelMax + m]);
+    const float* pr = Pw + fl * kBins + st;
+    const float* wr_ = Tb + m * kMelMaxW;
     float acc = 0.f;
-    for (int i = 0; i < len; ++i) {
-      const int k = st + i;
-      const float pk = (k < kHalf) ? Yf[2 * (fl * kHalf + k)] : 0.f;
-      acc = fmaf(Yf[2 * (m * kMelMaxW + i) + 1], pk, acc);
-    }
+    for (int i = 0; i < len; ++i) acc = fmaf(wr_[i], (st + i < kHalf) ? pr[i] : 0.f, acc);
     mel[((size_t)b * n_mels + m) * F + f0 + fl] = acc;
   }
 }
@@ -307,7 +317,7 @@ extern "C" int se_stft_f32(const se_plan* plan, const float* wavs, int B, int C,
   // algorithmic bytes: 4 T in + 4 F K per written plane
   se::ProfScope prof(se::kProfStft, (double)B * (4.0 * T + 4.0 * F * se::kBins * ((power != nullptr) + (phase != nullptr) + 2 * (complx != nullptr)) + (mel ? 4.0 * F * plan->geom.n_mels : 0.0)), se::as_stream(stream));
   hipLaunchKernelGGL(se::stft_kernel, grid, dim3(se::kThreads), 0, se::as_stream(stream), wavs, C, T, channel, F,
-                     plan->d_window, plan->d_tw400, plan->d_mel_start, plan->d_mel_len, plan->d_mel_w,
+                     plan->d_window, plan->d_tw400, plan->d_tw200, plan->d_mel_start, plan->d_mel_len, plan->d_mel_w,
                      plan->geom.n_mels, power, phase, complx, mel, dbgbuf, vec_ok);
   SE_LAUNCH_CHECK();
   return SE_OK;
