@@ -342,6 +342,9 @@ int se_multi_sumsq_f32(const float* const* grads, const uint64_t* sizes, int n_t
 int se_bertadam_step_f32(float* const* params, const float* const* grads, float* const* m, float* const* v, const uint64_t* sizes,
                          const float* weight_decay, int n_tensors, const double* sumsq, double lr_t, double b1, double b2, double e,
                          double max_grad_norm, double global_max_norm, void* stream);
+/* dsts[t][0 .. sizes[t]) = srcs[t][...] for all tensors in one launch per 96 tensors: the gather of the per-parameter gradients into the
+ * flat all-reduce buffer (the build's data-parallel step; runner.py:459-471 has no counterpart, it is single-process) */
+int se_multi_copy_f32(float* const* dsts, const float* const* srcs, const uint64_t* sizes, int n_tensors, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * The stages either side of the hot path, batched on the device.

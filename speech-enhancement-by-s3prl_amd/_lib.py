@@ -101,6 +101,7 @@ SIGNATURES = {
     'se_encoder_bwd_bf16': (c_int, [_P, _P, c_int, c_int, _P, _P, c_size_t, POINTER(EncoderGrads), _P, c_size_t, c_float, ctypes.c_uint64, _P]),
     'se_multi_sumsq_f32': (c_int, [_P, _P, c_int, _P, _P]),
     'se_bertadam_step_f32': (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, c_double, c_double, c_double, c_double, c_double, c_double, _P]),
+    'se_multi_copy_f32': (c_int, [_P, _P, _P, c_int, _P]),
     'se_mix_f32': (c_int, [_P, c_int, _P, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_float, c_float, _P, _P, _P]),
     'se_sisdr_f32': (c_int, [_P, _P, c_int, _P, c_int, c_float, _P, _P, _P]),
     'se_lstm_fwd_bf16': (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P]),

@@ -13,6 +13,7 @@
 #include <algorithm>
 #include "common.h"
 #include "encoder_impl.h"
+#include "multi_copy.h"
 #include "bf16.h"
 #include "dropout.h"
 
@@ -173,14 +174,6 @@ TrainWs carve_ws(const se_encoder* e, int B, int T, char* base) {
   return w;
 }
 
-int cast_mat(const float* src, int rows, int cols, int ld, uint16_t* dst, hipStream_t st) {
-  return se::launch_cast_pad(src, (size_t)rows, cols, ld, dst, st);
-}
-int copy_vec(const float* src, size_t n, float* dst, hipStream_t st) {
-  SE_HIP(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, st));
-  return SE_OK;
-}
-
 }  // namespace
 
 #define SE_TRY(call)                 \
@@ -194,29 +187,35 @@ extern "C" int se_encoder_refresh_bf16(se_encoder* enc, const se_encoder_weights
   SE_REQUIRE(enc && w, "se_encoder_refresh_bf16: null argument");
   const int H = enc->cfg.hidden, I = enc->cfg.intermediate, D = enc->cfg.input_dim, L = enc->cfg.layers;
   hipStream_t st = se::as_stream(stream);
-  SE_TRY(cast_mat(w->in_w, H, D, se::kInPad, enc->in_w, st));
-  SE_TRY(copy_vec(w->in_b, H, enc->in_b, st));
-  SE_TRY(copy_vec(w->in_ln_w, H, enc->in_ln_w, st));
-  SE_TRY(copy_vec(w->in_ln_b, H, enc->in_ln_b, st));
+  // two launches for the whole model (98 tensors): one batched cast of the matrices, one batched copy of the vectors
+  se::MultiCopy cast(true, st), copy(false, st);
+  auto cast_mat = [&](const float* src, int rows, int cols, int ld, uint16_t* dst) { return cast.add(dst, src, (size_t)rows * ld, cols, ld); };
+  auto copy_vec = [&](const float* src, size_t n, float* dst) { return copy.add(dst, src, n); };
+  SE_TRY(cast_mat(w->in_w, H, D, se::kInPad, enc->in_w));
+  SE_TRY(copy_vec(w->in_b, H, enc->in_b));
+  SE_TRY(copy_vec(w->in_ln_w, H, enc->in_ln_w));
+  SE_TRY(copy_vec(w->in_ln_b, H, enc->in_ln_b));
   for (int i = 0; i < L; ++i) {
     se_encoder::Layer& y = enc->layers[i];
-    SE_TRY(cast_mat(w->q_w[i], H, H, H, y.qkv_w, st));
-    SE_TRY(cast_mat(w->k_w[i], H, H, H, y.qkv_w + (size_t)H * H, st));
-    SE_TRY(cast_mat(w->v_w[i], H, H, H, y.qkv_w + (size_t)2 * H * H, st));
-    SE_TRY(copy_vec(w->q_b[i], H, y.qkv_b, st));
-    SE_TRY(copy_vec(w->k_b[i], H, y.qkv_b + H, st));
-    SE_TRY(copy_vec(w->v_b[i], H, y.qkv_b + 2 * H, st));
-    SE_TRY(cast_mat(w->ao_w[i], H, H, H, y.ao_w, st));
-    SE_TRY(copy_vec(w->ao_b[i], H, y.ao_b, st));
-    SE_TRY(copy_vec(w->aln_w[i], H, y.aln_w, st));
-    SE_TRY(copy_vec(w->aln_b[i], H, y.aln_b, st));
-    SE_TRY(cast_mat(w->ff1_w[i], I, H, H, y.ff1_w, st));
-    SE_TRY(copy_vec(w->ff1_b[i], I, y.ff1_b, st));
-    SE_TRY(cast_mat(w->ff2_w[i], H, I, I, y.ff2_w, st));
-    SE_TRY(copy_vec(w->ff2_b[i], H, y.ff2_b, st));
-    SE_TRY(copy_vec(w->oln_w[i], H, y.oln_w, st));
-    SE_TRY(copy_vec(w->oln_b[i], H, y.oln_b, st));
+    SE_TRY(cast_mat(w->q_w[i], H, H, H, y.qkv_w));
+    SE_TRY(cast_mat(w->k_w[i], H, H, H, y.qkv_w + (size_t)H * H));
+    SE_TRY(cast_mat(w->v_w[i], H, H, H, y.qkv_w + (size_t)2 * H * H));
+    SE_TRY(copy_vec(w->q_b[i], H, y.qkv_b));
+    SE_TRY(copy_vec(w->k_b[i], H, y.qkv_b + H));
+    SE_TRY(copy_vec(w->v_b[i], H, y.qkv_b + 2 * H));
+    SE_TRY(cast_mat(w->ao_w[i], H, H, H, y.ao_w));
+    SE_TRY(copy_vec(w->ao_b[i], H, y.ao_b));
+    SE_TRY(copy_vec(w->aln_w[i], H, y.aln_w));
+    SE_TRY(copy_vec(w->aln_b[i], H, y.aln_b));
+    SE_TRY(cast_mat(w->ff1_w[i], I, H, H, y.ff1_w));
+    SE_TRY(copy_vec(w->ff1_b[i], I, y.ff1_b));
+    SE_TRY(cast_mat(w->ff2_w[i], H, I, I, y.ff2_w));
+    SE_TRY(copy_vec(w->ff2_b[i], H, y.ff2_b));
+    SE_TRY(copy_vec(w->oln_w[i], H, y.oln_w));
+    SE_TRY(copy_vec(w->oln_b[i], H, y.oln_b));
   }
+  SE_TRY(cast.flush());
+  SE_TRY(copy.flush());
   return SE_OK;
 }
 
@@ -367,10 +366,12 @@ extern "C" int se_encoder_bwd_bf16(const se_encoder* enc, const int32_t* lengths
     {
       float* wdst[3] = {g->q_w[i], g->k_w[i], g->v_w[i]};
       float* bdst[3] = {g->q_b[i], g->k_b[i], g->v_b[i]};
+      se::MultiCopy split(false, st);            // one launch instead of six copies
       for (int p = 0; p < 3; ++p) {
-        SE_HIP(hipMemcpyAsync(wdst[p], w.gfused + (size_t)p * H * H, (size_t)H * H * 4, hipMemcpyDeviceToDevice, st));
-        SE_HIP(hipMemcpyAsync(bdst[p], w.bfused + (size_t)p * H, (size_t)H * 4, hipMemcpyDeviceToDevice, st));
+        SE_TRY(split.add(wdst[p], w.gfused + (size_t)p * H * H, (size_t)H * H));
+        SE_TRY(split.add(bdst[p], w.bfused + (size_t)p * H, (size_t)H));
       }
+      SE_TRY(split.flush());
     }
     SE_TRY(input_grad(w.b3, y.qkv_w, M, 3 * H, H, w.fa, nullptr, w.fb, w, stream));                // dx0 = dqkv Wqkv + dpre1
     gy = w.fb;

@@ -12,6 +12,8 @@
 #include <math.h>
 #include <algorithm>
 #include "common.h"
+#include "bf16.h"
+#include "multi_copy.h"
 
 namespace se {
 
@@ -111,6 +113,97 @@ __global__ __launch_bounds__(256) void bertadam_kernel(const OptBatch b, const d
   }
 }
 
+// ---- many small device-to-device copies / fp32 -> bf16 casts in one launch (per-step plumbing of the training path: the refresh
+//      of the encoder's bf16 weights, the split of the fused QKV gradients, the gather into the flat all-reduce buffer: ~230 launches
+//      of 3-5 us each per step otherwise)
+constexpr int kCopySlots = 96;
+constexpr uint32_t kCopyChunk = 16384;     // elements per workgroup
+struct CopySlot {
+  void* dst;
+  const float* src;
+  uint32_t n;          // copy: elements; cast: rows * ld output elements
+  uint32_t chunk0;
+  uint32_t cols, ld;   // cast only: source row length, padded output row length
+};
+struct CopyBatch {
+  CopySlot s[kCopySlots];
+  int count;
+};
+
+__device__ __forceinline__ int find_copy_slot(const CopyBatch& b, uint32_t blk) {
+  int lo = 0;
+  for (int i = 1; i < b.count; ++i)
+    if (b.s[i].chunk0 <= blk) lo = i;
+  return lo;
+}
+
+__global__ __launch_bounds__(256) void multi_copy_kernel(const CopyBatch b) {
+  const CopySlot& s = b.s[find_copy_slot(b, blockIdx.x)];
+  const uint32_t e0 = (blockIdx.x - s.chunk0) * kCopyChunk, e1 = min(s.n, e0 + kCopyChunk);
+  float* d = static_cast<float*>(s.dst);
+  const float* g = s.src;
+  if (((reinterpret_cast<uintptr_t>(d) | reinterpret_cast<uintptr_t>(g)) & 15) == 0) {
+    uint32_t i = e0 + threadIdx.x * 4;
+    for (; i + 3 < e1; i += 1024) *reinterpret_cast<float4*>(d + i) = *reinterpret_cast<const float4*>(g + i);
+    for (; i < e1; ++i) d[i] = g[i];              // ragged tail (at most 3 elements on one thread)
+  } else {
+    for (uint32_t i = e0 + threadIdx.x; i < e1; i += 256) d[i] = g[i];
+  }
+}
+
+// out[r * ld + c] = c < cols ? bf16(src[r * cols + c]) : 0      (ld % 4 == 0)
+__global__ __launch_bounds__(256) void multi_cast_pad_kernel(const CopyBatch b) {
+  const CopySlot& s = b.s[find_copy_slot(b, blockIdx.x)];
+  const uint32_t e0 = (blockIdx.x - s.chunk0) * kCopyChunk, e1 = min(s.n, e0 + kCopyChunk);
+  uint16_t* d = static_cast<uint16_t*>(s.dst);
+  const uint32_t cols = s.cols, ld = s.ld;
+  const bool vec = (cols % 4 == 0) && ((reinterpret_cast<uintptr_t>(s.src) & 15) == 0);
+  for (uint32_t i = e0 + threadIdx.x * 4; i < e1; i += 1024) {
+    const uint32_t r = i / ld, c = i - r * ld;
+    const float* xr = s.src + (size_t)r * cols;
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+    if (vec && c + 3 < cols) {
+      const float4 t = *reinterpret_cast<const float4*>(xr + c);
+      v0 = t.x; v1 = t.y; v2 = t.z; v3 = t.w;
+    } else {
+      if (c < cols) v0 = xr[c];
+      if (c + 1 < cols) v1 = xr[c + 1];
+      if (c + 2 < cols) v2 = xr[c + 2];
+      if (c + 3 < cols) v3 = xr[c + 3];
+    }
+    *reinterpret_cast<uint2*>(d + i) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+  }
+}
+
+int MultiCopy::add(void* dst, const float* src, size_t n, uint32_t cols, uint32_t ld) {
+  if (n == 0) return SE_OK;
+  if (n > 0xffffffffull) {
+    set_error("multi copy: %llu elements (> 2^32 - 1)", (unsigned long long)n);
+    return SE_ERR_INVALID;
+  }
+  if (b_->count == kCopySlots) {
+    const int rc = flush();
+    if (rc) return rc;
+  }
+  CopySlot& s = b_->s[b_->count++];
+  s.dst = dst; s.src = src; s.n = (uint32_t)n; s.chunk0 = chunks_; s.cols = cols; s.ld = ld;
+  chunks_ += ((uint32_t)n + kCopyChunk - 1) / kCopyChunk;
+  return SE_OK;
+}
+
+int MultiCopy::flush() {
+  if (b_->count == 0) return SE_OK;
+  if (cast_) hipLaunchKernelGGL(multi_cast_pad_kernel, dim3(chunks_), dim3(256), 0, st_, *b_);
+  else hipLaunchKernelGGL(multi_copy_kernel, dim3(chunks_), dim3(256), 0, st_, *b_);
+  SE_LAUNCH_CHECK();
+  b_->count = 0;
+  chunks_ = 0;
+  return SE_OK;
+}
+
+MultiCopy::MultiCopy(bool cast, hipStream_t st) : b_(new CopyBatch), chunks_(0), cast_(cast), st_(st) { b_->count = 0; }
+MultiCopy::~MultiCopy() { delete b_; }
+
 template <typename F>
 int for_batches(float* const* params, const float* const* grads, float* const* m, float* const* v, const uint64_t* sizes,
                 const float* weight_decay, int n_tensors, F&& launch) {
@@ -169,4 +262,16 @@ extern "C" int se_bertadam_step_f32(float* const* params, const float* const* gr
     SE_LAUNCH_CHECK();
     return (int)SE_OK;
   });
+}
+
+extern "C" int se_multi_copy_f32(float* const* dsts, const float* const* srcs, const uint64_t* sizes, int n_tensors, void* stream) {
+  SE_REQUIRE(dsts && srcs && sizes && n_tensors > 0, "se_multi_copy_f32: bad argument");
+  se::MultiCopy mc(false, se::as_stream(stream));
+  for (int t = 0; t < n_tensors; ++t) {
+    if (sizes[t] == 0) continue;
+    SE_REQUIRE(dsts[t] && srcs[t], "se_multi_copy_f32: null tensor %d", t);
+    const int rc = mc.add(dsts[t], srcs[t], sizes[t]);
+    if (rc) return rc;
+  }
+  return mc.flush();
 }
