@@ -366,16 +366,16 @@ int se_sisdr_f32(const float* src, const float* tar, int ld, const int64_t* leng
 /* ------------------------------------------------------------------------------------------------
  * Recurrent core of the (Bi)LSTM downstream heads (model.py:37-91, nn.LSTM hidden 256).
  * The input projection and all gradient GEMMs run on se_gemm_bf16 / se_wgrad_tn_bf16; these two kernels are the sequential
- * part: one 1024-thread workgroup per (utterance, direction) with W_hh resident in registers + LDS for all T steps.
+ * part: one 512-thread workgroup per (utterance, direction) with W_hh resident in registers + LDS as MFMA fragments for all T steps.
  * ---------------------------------------------------------------------------------------------- */
-/* w_hh_pairs [ndir][128][1024] u32 = bf16 pairs (W_hh[j][2kk], W_hh[j][2kk+1]); xproj [ndir][B][T][1024] fp32 = x W_ih^T + b_ih + b_hh
- * (gate order i, f, g, o); direction 1 runs t = T-1 .. 0.  Outputs: h_out (B, T, ndir*256) bf16 (directions concatenated, the next
+/* w_hh [ndir][1024][256] bf16 = nn.LSTM's weight_hh_l* (row-major, gate order i, f, g, o); xproj [ndir][B][T][1024] fp32 = x W_ih^T + b_ih
+ * + b_hh; direction 1 runs t = T-1 .. 0.  Outputs: h_out (B, T, ndir*256) bf16 (directions concatenated, the next
  * layer's input), gates_out [ndir][B][T][1024] fp32 post-activation gates and c_out [ndir][B][T][256] fp32 (kept for the backward). */
-int se_lstm_fwd_bf16(const uint32_t* w_hh_pairs, const float* xproj, int B, int T, int ndir, uint16_t* h_out, float* gates_out, float* c_out,
+int se_lstm_fwd_bf16(const uint16_t* w_hh, const float* xproj, int B, int T, int ndir, uint16_t* h_out, float* gates_out, float* c_out,
                      void* stream);
-/* BPTT: w_hh_gate_pairs [ndir][4][128][256] u32 = bf16 pairs (W_hh[256q+2jj][k], W_hh[256q+2jj+1][k]); dh_out (B, T, ld_dh) fp32 =
+/* BPTT: w_hh_t [ndir][256][1024] bf16 = W_hh^T (row-major); dh_out (B, T, ld_dh) fp32 =
  * gradient wrt h_out (columns dir*256 ..); dgates_out [ndir][B][T][1024] bf16 = gradient wrt the pre-activation gates. */
-int se_lstm_bwd_bf16(const uint32_t* w_hh_gate_pairs, const float* gates, const float* c_saved, const float* dh_out, int ld_dh, int B, int T,
+int se_lstm_bwd_bf16(const uint16_t* w_hh_t, const float* gates, const float* c_saved, const float* dh_out, int ld_dh, int B, int T,
                      int ndir, uint16_t* dgates_out, void* stream);
 /* column sums of a bf16 matrix (bias gradients): out[c] = sum_r x[r][c]; cols and ld multiples of 8 */
 int se_colsum_bf16(const uint16_t* x, int rows, int cols, int ld, float* out, void* stream);

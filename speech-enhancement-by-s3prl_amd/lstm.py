@@ -3,7 +3,7 @@ reference's scripts train (run_active.sh `--downstream LSTM`, pseudo_noise.yaml:
 
 Parameter names / shapes are nn.LSTM's (`lstm.weight_ih_l0`, `lstm.weight_hh_l0_reverse`, ...) and `scaling_layer.0.*`, so the
 reference's `--dckpt` checkpoints load unchanged.  hidden_size must be 256 (the kernels keep W_hh of one direction resident in
-one CU's registers + LDS).  Forward and backward run on libse_amd.so: input projections, the output linear and every gradient
+one CU's registers + LDS as MFMA fragments).  Forward and backward run on libse_amd.so: input projections, the output linear and every gradient
 GEMM on the bf16 GEMM / TN weight-gradient kernels, the recurrence on se_lstm_fwd_bf16 / se_lstm_bwd_bf16.  No CPU fallback."""
 import torch
 import torch.nn as nn
@@ -21,15 +21,13 @@ def _pad8k(d):          # GEMM reduction dims are multiples of 64
 
 
 def _pack_hh_fwd(w_hh):
-    """(1024, 256) fp32 -> (128, 1024) int32: bf16 pairs (W[j][2kk], W[j][2kk+1])."""
-    w16 = w_hh.detach().to(torch.bfloat16).contiguous()                       # (1024, 256)
-    return w16.view(torch.int32).t().contiguous()                              # (1024, 128) -> (128, 1024)
+    """(1024, 256) fp32 -> bf16 row-major: the forward kernel reads its MFMA A-fragments straight from nn.LSTM's layout."""
+    return w_hh.detach().to(torch.bfloat16).contiguous()
 
 
 def _pack_hh_bwd(w_hh):
-    """(1024, 256) fp32 -> (4, 128, 256) int32: bf16 pairs (W[256q + 2jj][k], W[256q + 2jj + 1][k])."""
-    w16 = w_hh.detach().to(torch.bfloat16).view(4, 128, 2, _H)                  # [q][jj][e][k]
-    return w16.permute(0, 1, 3, 2).contiguous().view(torch.int32).squeeze(-1).contiguous()      # [q][jj][k]
+    """(1024, 256) fp32 -> (256, 1024) bf16 = W_hh^T, the backward kernel's A operand."""
+    return w_hh.detach().to(torch.bfloat16).t().contiguous()
 
 
 class _LSTMFn(torch.autograd.Function):
@@ -52,7 +50,7 @@ class _LSTMFn(torch.autograd.Function):
             ws = weights[4 * ndir * l: 4 * ndir * (l + 1)]
             K = inp16.shape[1]
             xproj = torch.empty(ndir, M, 4 * _H, device=dev, dtype=torch.float32)
-            wp = torch.empty(ndir, 128, 4 * _H, device=dev, dtype=torch.int32)
+            wp = torch.empty(ndir, 4 * _H, _H, device=dev, dtype=torch.bfloat16)
             for d in range(ndir):
                 w_ih, w_hh, b_ih, b_hh = ws[4 * d: 4 * d + 4]
                 if w_hh.shape != (4 * _H, _H):
