@@ -12,6 +12,8 @@ pytestmark = pytest.mark.gpu
 
 def rel_l2(a, b):
     a, b = a.double().cpu(), b.double().cpu()
+    if b.norm().item() == 0.0:          # e.g. dW_hh at T = 1 (h_0 = 0): the HIP result must be exactly zero too
+        return a.norm().item()
     return ((a - b).norm() / b.norm()).item()
 
 
@@ -27,7 +29,8 @@ class RefLSTM(nn.Module):      # the reference's class body (model.py:37-59), fp
         return log_predicted.exp(), log_predicted
 
 
-@pytest.mark.parametrize('B,T,D,layers,bidir', [(3, 50, 120, 3, True), (2, 37, 120, 2, False), (2, 1001, 120, 1, True)])
+@pytest.mark.parametrize('B,T,D,layers,bidir', [(3, 50, 120, 3, True), (2, 37, 120, 2, False), (2, 1001, 120, 1, True),
+                                                  (2, 1, 120, 1, True), (1, 2, 120, 2, True), (2, 3, 120, 1, False), (1, 4, 120, 1, True)])   # T < 5: the DMA ring's special cases
 def test_lstm_head_forward_backward_vs_torch(gpu, B, T, D, layers, bidir):
     from speech_enhancement_by_s3prl_amd.lstm import LSTM
     torch.manual_seed(B * 1000 + T)
