@@ -149,17 +149,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
     /* so P <= 2^kDefer instead of 1 (bf16 / fp32 keep their relative precision) and the O-wide multiply is rare        */  \
     const float m_new = ((mx - m_run) * c > kDefer) ? mx : m_run;                                                          \
     const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);                                                       \
-    const f2 c2 = {c, c}, mc2 = {-m_new * c, -m_new * c};                                                                  \
-    f2 rs2 = {0.f, 0.f};                                                                                                   \
-    _Pragma("unroll") for (int r = 0; r < 16; r += 2) {                                                                    \
-      f2 a0 = {s0[r], s0[r + 1]}, a1 = {s1[r], s1[r + 1]};                                                                 \
-      a0 = __builtin_elementwise_fma(a0, c2, mc2);                                                                         \
-      a1 = __builtin_elementwise_fma(a1, c2, mc2);                                                                         \
-      a0.x = __builtin_amdgcn_exp2f(a0.x); a0.y = __builtin_amdgcn_exp2f(a0.y);                                            \
-      a1.x = __builtin_amdgcn_exp2f(a1.x); a1.y = __builtin_amdgcn_exp2f(a1.y);                                            \
-      rs2 += a0 + a1;                                                                                                      \
-      s0[r] = a0.x; s0[r + 1] = a0.y; s1[r] = a1.x; s1[r + 1] = a1.y;                                                      \
+    /* scalar fp32 ops on purpose (this file is built with -fno-slp-vectorize): v_pk_fma_f32 / v_pk_add_f32 cost more issue time than   */  \
+    /* the two plain instructions they replace in this VALU-bound loop (148 -> 141 us per launch)                               */  \
+    const float mc = -m_new * c;                                                                                           \
+    float rs0 = 0.f, rs1 = 0.f;                                                                                            \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                                       \
+      const float a0 = __builtin_amdgcn_exp2f(fmaf(s0[r], c, mc));                                                         \
+      const float a1 = __builtin_amdgcn_exp2f(fmaf(s1[r], c, mc));                                                         \
+      rs0 += a0;                                                                                                           \
+      rs1 += a1;                                                                                                           \
+      s0[r] = a0; s1[r] = a1;                                                                                              \
     }                                                                                                                      \
+    const f2 rs2 = {rs0, rs1};                                                                                             \
     l_run = fmaf(l_run, alpha, rs2.x + rs2.y);                                                                             \
     m_run = m_new;                                                                                                         \
     if (__any(alpha != 1.0f)) {                                                                                            \
