@@ -37,7 +37,7 @@ def _hipcc():
 def _digest(paths):
     h = hashlib.sha256()
     for p in sorted(paths):
-        h.update(p.encode())
+        h.update(os.path.basename(p).encode())      # not the absolute path: the tree is copied to another root on the GPU box
         with open(p, 'rb') as f:
             h.update(f.read())
     h.update(' '.join(FLAGS).encode())
