@@ -40,7 +40,7 @@ def _digest(paths):
         h.update(os.path.basename(p).encode())      # not the absolute path: the tree is copied to another root on the GPU box
         with open(p, 'rb') as f:
             h.update(f.read())
-    h.update(' '.join(FLAGS).encode())
+    h.update(' '.join(FLAGS).replace(HERE, '.').encode())
     h.update(repr(sorted(FILE_FLAGS.items())).encode())
     return h.hexdigest()
 
