@@ -112,3 +112,33 @@ def test_fused_train_step_global_clip(gpu):
     loss = sum((p * float('nan')).sum() for _, p in named_g)
     gn, skipped = dp.step(loss)
     assert skipped and all(torch.equal(b, p.detach()) for b, (_, p) in zip(before, named_g))
+
+
+def test_multi_copy_many_tensors(gpu):
+    """se_multi_copy_f32: more tensors than one kernel-argument table holds (96), ragged sizes, unaligned sources and
+    destinations, sizes spanning several 16 Ki-element chunks -- bit-exact copies, untouched neighbours."""
+    import ctypes
+    from speech_enhancement_by_s3prl_amd import _lib as L
+    lib = L.load()
+    torch.manual_seed(5)
+    sizes = [1, 2, 3, 5, 16384, 16385, 40000, 7] + [int(x) for x in torch.randint(1, 3000, (200,))]
+    src_flat = torch.randn(sum(sizes) + len(sizes), device=gpu)
+    dst_flat = torch.full((sum(sizes) + 2 * len(sizes),), -7.0, device=gpu)
+    srcs, dsts, so, do = [], [], 0, 1
+    for n in sizes:                                  # sources packed back to back (+1: misaligned), destinations with a guard element between
+        srcs.append(src_flat[so:so + n])
+        dsts.append(dst_flat[do:do + n])
+        so += n + 1
+        do += n + 2
+    n = len(sizes)
+    L.check(lib.se_multi_copy_f32((ctypes.c_void_p * n)(*[d.data_ptr() for d in dsts]), (ctypes.c_void_p * n)(*[s.data_ptr() for s in srcs]),
+                                  (ctypes.c_uint64 * n)(*sizes), n, L.stream()), 'se_multi_copy_f32')
+    torch.cuda.synchronize()
+    for s, d in zip(srcs, dsts):
+        assert torch.equal(s, d)
+    guard = torch.ones_like(dst_flat, dtype=torch.bool)
+    do = 1
+    for n_ in sizes:
+        guard[do:do + n_] = False
+        do += n_ + 2
+    assert (dst_flat[guard] == -7.0).all()
