@@ -194,9 +194,27 @@ __global__ __launch_bounds__(256) void masked_sumsq_kernel(const float* __restri
   const int len = (int)min((int64_t)T, lengths[b]);
   const float* row = x + (size_t)b * x_stride;
   float ss = 0.f;
-  for (int n = blockIdx.x * 256 + threadIdx.x; n < len; n += gridDim.x * 256) {
-    const float v = row[n];
-    ss = fmaf(v, v, ss);
+  if ((reinterpret_cast<uintptr_t>(row) & 15) == 0) {          // 16-B loads, two per thread in flight
+    const int len4 = len >> 2, stride = gridDim.x * 256;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int n = blockIdx.x * 256 + threadIdx.x; n < len4; n += 2 * stride) {
+      const float4 a = reinterpret_cast<const float4*>(row)[n];
+      const float4 c = (n + stride < len4) ? reinterpret_cast<const float4*>(row)[n + stride] : make_float4(0.f, 0.f, 0.f, 0.f);
+      acc.x = fmaf(a.x, a.x, fmaf(c.x, c.x, acc.x));
+      acc.y = fmaf(a.y, a.y, fmaf(c.y, c.y, acc.y));
+      acc.z = fmaf(a.z, a.z, fmaf(c.z, c.z, acc.z));
+      acc.w = fmaf(a.w, a.w, fmaf(c.w, c.w, acc.w));
+    }
+    ss = (acc.x + acc.y) + (acc.z + acc.w);
+    if (blockIdx.x == 0 && threadIdx.x < (len & 3)) {
+      const float v = row[4 * len4 + threadIdx.x];
+      ss = fmaf(v, v, ss);
+    }
+  } else {
+    for (int n = blockIdx.x * 256 + threadIdx.x; n < len; n += gridDim.x * 256) {
+      const float v = row[n];
+      ss = fmaf(v, v, ss);
+    }
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) ss += __shfl_down(ss, off);
@@ -250,7 +268,7 @@ extern "C" int se_masked_sumsq_f32(const float* x, int B, int T, int x_stride, c
   SE_REQUIRE(x && lengths && sums && B > 0 && B <= 65535 && T > 0 && x_stride >= T, "se_masked_sumsq_f32: bad argument");
   hipStream_t st = se::as_stream(stream);
   { const int zrc_ = se::zero_async(sums, sizeof(float) * B, st); if (zrc_) return zrc_; }
-  dim3 grid(std::min(64, (T + 255) / 256), B);
+  dim3 grid(std::min(32, (T + 2047) / 2048), B);
   hipLaunchKernelGGL(se::masked_sumsq_kernel, grid, dim3(256), 0, st, x, T, x_stride, lengths, sums);
   SE_LAUNCH_CHECK();
   return SE_OK;
