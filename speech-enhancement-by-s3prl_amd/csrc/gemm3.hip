@@ -24,7 +24,6 @@ namespace se {
 
 constexpr int k3BM = 256, k3BN = 256, k3BK = 32, k3Threads = 512, k3Stages = 4;
 constexpr int k3ABytes = k3BM * k3BK * 2, k3Stage = 2 * k3ABytes, k3Lds = k3Stages * k3Stage;     // 16 KiB, 32 KiB, 128 KiB
-constexpr int k3NDma = 4;                                                                        // per wave per K-step
 
 typedef __attribute__((address_space(3))) void* lds3_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb3_ptr_t;

@@ -22,15 +22,14 @@ constexpr int kIHB = 27;                 // hop-blocks of output per workgroup
 constexpr int kISpan = kIHB * kHop;      // 4320 samples
 constexpr int kIThreads = 256;
 constexpr int kILoadIters = (kIFR * kBins + kIThreads - 1) / kIThreads;   // 25
-constexpr int kIOlaIters = (kISpan + kIThreads - 1) / kIThreads;         // 18
 
 __global__ __launch_bounds__(kIThreads) void istft_kernel(
     const float* __restrict__ power, const float* __restrict__ phase, int F, float inv_lp,
     const float* __restrict__ window, const float2* __restrict__ tw400g,
     float* __restrict__ wav, int wav_stride, const int64_t* __restrict__ lengths, float* __restrict__ sumsq) {
-  __shared__ float2 Y[kIFR * kHalf];
+  __shared__ __attribute__((aligned(16))) float2 Y[kIFR * kHalf];
   __shared__ float2 tw[kHalf];            // (cos, sin)(2 pi k / 400), k < 200
-  __shared__ float win[kNfft];
+  __shared__ __attribute__((aligned(16))) float win[kNfft];
   __shared__ float red[kIThreads / 64];
 
   const int tid = threadIdx.x;
@@ -147,32 +146,45 @@ __global__ __launch_bounds__(kIThreads) void istft_kernel(
   }
   __syncthreads();
 
-  // ---- overlap-add + envelope + masked square sum; the loop contains LDS reads and global STORES only
+  // ---- overlap-add + envelope + masked square sum; the loop contains LDS reads and global STORES only.  Four consecutive samples
+  //      per thread: hop, n_fft/2 and the workgroup span are multiples of 4, so a quad shares its (up to three) frames, the LDS reads
+  //      are aligned ds_read_b128 and the store is one 16-B store (scalar fallback when the output row is not 16-B aligned)
   const float* xs = reinterpret_cast<const float*>(Y);
   const int len_b = lengths ? (int)min((int64_t)n_out, lengths[b]) : 0;
   float ss = 0.f;
-#pragma unroll 2
-  for (int r = 0; r < kIOlaIters; ++r) {
-    const int o = tid + kIThreads * r;
+  float* wrow = wav + (size_t)b * wav_stride;
+  const bool vec_out = ((reinterpret_cast<uintptr_t>(wrow) & 15) == 0);
+#pragma unroll 1
+  for (int o = 4 * tid; o < kISpan; o += 4 * kIThreads) {
     const int n = o0 + o;
-    if (o < kISpan && n < n_out) {
-      const int p = n + kHalf;                       // padded index
-      const int f_last = min(p / kHop, F - 1);
-      float acc = 0.f, env = 0.f;
+    if (n >= n_out) break;                            // n_out = 160 (F - 1): a multiple of 4, a quad is valid or invalid as a whole
+    const int p = n + kHalf;                          // padded index
+    const int f_last = min(p / kHop, F - 1);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), env = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-      for (int t = 0; t < 3; ++t) {
-        const int f = f_last - t;
-        const int rr = p - f * kHop;
-        if (f >= 0 && rr < kNfft) {
-          acc += xs[(f - fbase) * kNfft + rr];
-          const float w = win[rr];
-          env = fmaf(w, w, env);
-        }
+    for (int t = 0; t < 3; ++t) {
+      const int f = f_last - t;
+      const int rr = p - f * kHop;
+      if (f >= 0 && rr < kNfft) {
+        const float4 x4 = *reinterpret_cast<const float4*>(xs + (f - fbase) * kNfft + rr);
+        const float4 w4 = *reinterpret_cast<const float4*>(win + rr);
+        acc.x += x4.x; acc.y += x4.y; acc.z += x4.z; acc.w += x4.w;
+        env.x = fmaf(w4.x, w4.x, env.x); env.y = fmaf(w4.y, w4.y, env.y);
+        env.z = fmaf(w4.z, w4.z, env.z); env.w = fmaf(w4.w, w4.w, env.w);
       }
-      const float v = acc / env;
-      wav[(size_t)b * wav_stride + n] = v;
-      if (n < len_b) ss = fmaf(v, v, ss);
     }
+    // v_rcp_f32 (1 ulp) instead of the IEEE division sequence: ~10 instructions per sample in a VALU-bound kernel
+    const float4 v = make_float4(acc.x * __builtin_amdgcn_rcpf(env.x), acc.y * __builtin_amdgcn_rcpf(env.y),
+                                 acc.z * __builtin_amdgcn_rcpf(env.z), acc.w * __builtin_amdgcn_rcpf(env.w));
+    if (vec_out) {
+      *reinterpret_cast<float4*>(wrow + n) = v;
+    } else {
+      wrow[n] = v.x; wrow[n + 1] = v.y; wrow[n + 2] = v.z; wrow[n + 3] = v.w;
+    }
+    if (n < len_b) ss = fmaf(v.x, v.x, ss);
+    if (n + 1 < len_b) ss = fmaf(v.y, v.y, ss);
+    if (n + 2 < len_b) ss = fmaf(v.z, v.z, ss);
+    if (n + 3 < len_b) ss = fmaf(v.w, v.w, ss);
   }
   // right-pad region [n_out, wav_stride) -- zero-filled by the last workgroup of the row
   if (blockIdx.x == gridDim.x - 1)
