@@ -218,6 +218,30 @@ __global__ __launch_bounds__(256) void spec_epilogue_kernel(const float* __restr
   }
 }
 
+// the same on a row-padded input p (M, ld): the 201-column output GEMM writes rows padded to a multiple of 4 floats so that it takes
+// the specialised 16-B-store epilogue (with ldc = 201 it falls back to the all-run-time one: 59 vs 35 us at M = 32 032)
+__global__ __launch_bounds__(256) void spec_epilogue_rows_kernel(const float* __restrict__ p, int M, int N, int ld, int log_target, int act, float eps,
+                                                                 float* __restrict__ predicted, float* __restrict__ log_predicted) {
+  for (int r = blockIdx.x; r < M; r += gridDim.x) {
+    for (int c = threadIdx.x; c < N; c += 256) {
+      const float v = p[(size_t)r * ld + c];
+      float pred, lp;
+      if (log_target) {
+        pred = expf(v);
+        lp = v;
+      } else {
+        pred = v;
+        lp = logf(v + eps);
+      }
+      if (act == SE_ACT_RELU) pred = fmaxf(pred, 0.f);
+      else if (act == SE_ACT_SIGMOID) pred = 1.f / (1.f + expf(-pred));
+      const size_t o = (size_t)r * N + c;
+      if (predicted) predicted[o] = pred;
+      if (log_predicted) log_predicted[o] = lp;
+    }
+  }
+}
+
 // backward of SpecHead.forward's epilogue (model.py:121-125) wrt the raw linear output p:
 //   log_target: predicted = act(exp(p)), log_predicted = p      -> dp = d_logp + d_pred act'(exp p) exp(p)
 //   else      : predicted = act(p),      log_predicted = log(p+eps) -> dp = d_pred act'(p) + d_logp / (p + eps)
@@ -420,7 +444,9 @@ extern "C" int se_encoder_create(const se_encoder_config* cfg, const se_encoder_
     o.shl_w = put_f32(w->sh_ln_w, H);
     o.shl_b = put_f32(w->sh_ln_b, H);
     o.sho_w = put_bf16(w->sh_out_w, cfg->spec_out, H, H);
+    reserve((size_t)3 * H * 2);                    // up to three zero rows behind it: the output GEMM runs with N rounded up to a multiple of 4
     o.sho_b = put_f32(w->sh_out_b, cfg->spec_out);
+    reserve(3 * 4);
   }
   se_encoder* e = new se_encoder();
   e->cfg = *cfg;
@@ -588,15 +614,30 @@ extern "C" int se_spechead_fwd_bf16(const se_encoder* enc, const float* hidden, 
     hipLaunchKernelGGL(se::cast_pad_kernel, dim3(grid), dim3(256), 0, st, hidden, Mz, H, H, w.x_bf);
     SE_LAUNCH_CHECK();
   }
-  if ((rc = se_gemm_bf16(w.x_bf, H, enc->sh_dense_w, H, enc->sh_dense_b, nullptr, M, H, H, SE_ACT_GELU, nullptr, w.tmp, H, stream))) return rc;
-  if ((rc = se::launch_layernorm(w.tmp, nullptr, 1, enc->sh_ln_w, enc->sh_ln_b, M, H, enc->cfg.ln_eps, nullptr, w.ctx, st))) return rc;
+  // dense -> gelu -> LayerNorm: one row-complete kernel at large M (as the encoder's projections), GEMM + LayerNorm otherwise
+  static int fuse_env = -1;
+  if (fuse_env < 0) {
+    const char* e = getenv("SE_AMD_FUSED_LN");
+    fuse_env = e ? atoi(e) : 1;
+  }
+  if (fuse_env && H == 768 && (fuse_env == 2 || M >= (enc->cfg.fused_ln_min_rows > 0 ? enc->cfg.fused_ln_min_rows : 24576))) {
+    if ((rc = se::launch_gemm_gelu_ln(w.x_bf, H, enc->sh_dense_w, H, enc->sh_dense_b, enc->sh_ln_w, enc->sh_ln_b, enc->cfg.ln_eps, M, H, H, nullptr,
+                                      w.ctx, st))) return rc;
+  } else {
+    if ((rc = se_gemm_bf16(w.x_bf, H, enc->sh_dense_w, H, enc->sh_dense_b, nullptr, M, H, H, SE_ACT_GELU, nullptr, w.tmp, H, stream))) return rc;
+    if ((rc = se::launch_layernorm(w.tmp, nullptr, 1, enc->sh_ln_w, enc->sh_ln_b, M, H, enc->cfg.ln_eps, nullptr, w.ctx, st))) return rc;
+  }
   // raw linear output p (M, N) fp32: into `raw` if given, else the (free) x_f32 workspace
   float* p = raw ? raw : w.x_f32;
-  if ((rc = se_gemm_bf16(w.ctx, H, enc->sh_out_w, H, enc->sh_out_b, nullptr, M, N, H, SE_ACT_IDENTITY, nullptr, p, N, stream))) return rc;
+  // internal buffer: N rounded up to a multiple of 4 (zero weight rows / bias entries follow the real ones in the blob) and rows padded
+  // to 32 B, so the GEMM takes its specialised 16-B-store epilogue; x_f32 holds M x H floats
+  const int Np = raw ? N : (N + 3) & ~3;
+  const int ldp = raw ? N : (N + 7) & ~7;
+  SE_REQUIRE(ldp <= H, "se_spechead_fwd_bf16: spec_out %d exceeds the hidden size %d", N, H);
+  if ((rc = se_gemm_bf16(w.ctx, H, enc->sh_out_w, H, enc->sh_out_b, nullptr, M, Np, H, SE_ACT_IDENTITY, nullptr, p, ldp, stream))) return rc;
   if (predicted || log_predicted) {
-    const size_t n = Mz * N;
-    const int grid = (int)std::min<size_t>((n + 255) / 256, 8192);
-    hipLaunchKernelGGL(se::spec_epilogue_kernel, dim3(grid), dim3(256), 0, st, p, n, log_target, act, eps, predicted, log_predicted);
+    hipLaunchKernelGGL(se::spec_epilogue_rows_kernel, dim3(std::min(M, 8192)), dim3(256), 0, st, p, M, N, ldp, log_target, act, eps, predicted,
+                       log_predicted);
     SE_LAUNCH_CHECK();
   }
   return SE_OK;

@@ -36,7 +36,8 @@ __device__ __forceinline__ int swz4_f(int row) { return (-(row >> 2)) & 3; }
 __device__ __forceinline__ int swz4(int row, int chunk) { return row * 64 + ((chunk ^ swz4_f(row)) << 4); }
 
 // SLOTS: weight-ring depth (pieces; SLOTS - 1 in flight).  INM: the ring-refill DMAs are issued between the MFMAs (1) or in the read phase (0)
-template <int SLOTS, int INM>
+// GELU: x = LayerNorm(gelu(A . W^T + bias)) without a residual (the spec head's dense -> act -> LayerNorm, model.py:100-101)
+template <int SLOTS, int INM, int GELU>
 __global__ __launch_bounds__(k4Threads) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm4_res_ln_kernel(
     const uint16_t* __restrict__ A, int lda, const uint16_t* __restrict__ W, int ldw, const float* __restrict__ bias,
     const float* __restrict__ residual, const float* __restrict__ ln_w, const float* __restrict__ ln_b, float eps, int M, int K,
@@ -113,8 +114,12 @@ __global__ __launch_bounds__(k4Threads) __attribute__((amdgpu_waves_per_eu(2, 2)
       const float* rp = residual + (size_t)gm * k4N + col0;
 #pragma unroll
       for (int t = 0; t < 12; ++t) {
-        const float4 rr = *reinterpret_cast<const float4*>(rp + 16 * t);
-        acc[i][t] = (f32x4){rr.x + bb[t].x, rr.y + bb[t].y, rr.z + bb[t].z, rr.w + bb[t].w};
+        if (GELU) {
+          acc[i][t] = (f32x4){bb[t].x, bb[t].y, bb[t].z, bb[t].w};
+        } else {
+          const float4 rr = *reinterpret_cast<const float4*>(rp + 16 * t);
+          acc[i][t] = (f32x4){rr.x + bb[t].x, rr.y + bb[t].y, rr.z + bb[t].z, rr.w + bb[t].w};
+        }
       }
     }
   }
@@ -215,6 +220,15 @@ __global__ __launch_bounds__(k4Threads) __attribute__((amdgpu_waves_per_eu(2, 2)
   if (!late) __builtin_amdgcn_s_barrier();                  // re-align the two groups
   __syncthreads();                                          // ring is dead: reuse it for the per-column vectors
 
+  if (GELU) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int t = 0; t < 12; ++t) {
+        const f32x2 ga = gelu_erf2((f32x2){acc[i][t][0], acc[i][t][1]}), gb = gelu_erf2((f32x2){acc[i][t][2], acc[i][t][3]});
+        acc[i][t] = (f32x4){ga.x, ga.y, gb.x, gb.y};
+      }
+  }
   // ---- epilogue: LayerNorm on the accumulators (which already hold A.W^T + bias + residual)
   float* colv = reinterpret_cast<float*>(smem);             // [2][768]: ln_w, ln_b staged in the dead ring
   for (int c = tid; c < k4N; c += k4Threads) {
@@ -300,10 +314,11 @@ __global__ __launch_bounds__(k4Threads) __attribute__((amdgpu_waves_per_eu(2, 2)
 
 }  // namespace se
 
-extern "C" int se_gemm_res_ln_bf16(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias, const float* residual_f32,
-                                   const float* ln_w, const float* ln_b, float eps, int M, int N, int K,
-                                   float* out_f32, uint16_t* out_bf16, void* stream) {
-  SE_REQUIRE(A && W && residual_f32 && ln_w && ln_b && (out_f32 || out_bf16), "se_gemm_res_ln_bf16: null argument");
+static int gemm4_launch(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias, const float* residual_f32,
+                        const float* ln_w, const float* ln_b, float eps, int M, int N, int K,
+                        float* out_f32, uint16_t* out_bf16, bool gelu_no_residual, void* stream) {
+  SE_REQUIRE(A && W && (residual_f32 || gelu_no_residual) && ln_w && ln_b && (out_f32 || out_bf16), "se_gemm_res_ln_bf16: null argument");
+  if (gelu_no_residual) residual_f32 = ln_w;      // never dereferenced by the GELU instantiation; keeps the pointer checks below uniform
   if (N != se::k4N || K % se::k4BK != 0 || K < 4 * se::k4BK) {
     se::set_error("se_gemm_res_ln_bf16: the fused kernel is specialised for N = 768 and K a multiple of 32, K >= 128 (got N=%d K=%d)", N, K);
     return SE_ERR_UNSUPPORTED;
@@ -315,17 +330,24 @@ extern "C" int se_gemm_res_ln_bf16(const uint16_t* A, int lda, const uint16_t* W
   if (cfg < 0) {
     const char* e = getenv("SE_AMD_GEMM4_CFG");          // developer switch: bit 0 = DMA issue between the MFMAs, bit 1 = 7-piece ring
     cfg = e ? (atoi(e) & 3) : 1;        // default: 6 pieces, MFMA-phase issue -- equal to read-phase issue when A streams from the Infinity Cache (B = 32 bench), 17 % faster when it comes from HBM
-    SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::gemm4_res_ln_kernel<6, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, se::k4_lds(6)));
-    SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::gemm4_res_ln_kernel<6, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, se::k4_lds(6)));
-    SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::gemm4_res_ln_kernel<7, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, se::k4_lds(7)));
-    SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::gemm4_res_ln_kernel<7, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, se::k4_lds(7)));
+    SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::gemm4_res_ln_kernel<6, 0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, se::k4_lds(6)));
+    SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::gemm4_res_ln_kernel<6, 1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, se::k4_lds(6)));
+    SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::gemm4_res_ln_kernel<7, 0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, se::k4_lds(7)));
+    SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::gemm4_res_ln_kernel<7, 1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, se::k4_lds(7)));
+    SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::gemm4_res_ln_kernel<6, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, se::k4_lds(6)));
   }
   const int ntiles = (M + se::k4BM - 1) / se::k4BM;
   hipStream_t st = se::as_stream(stream);
   se::ProfScope prof(se::kProfGemm, 2.0 * M * (double)N * K, st);
 #define SE4_LAUNCH(SL, IM)                                                                                                              \
-  hipLaunchKernelGGL((se::gemm4_res_ln_kernel<SL, IM>), dim3(ntiles), dim3(se::k4Threads), se::k4_lds(SL), st, A, lda, W, ldw, bias, residual_f32, \
+  hipLaunchKernelGGL((se::gemm4_res_ln_kernel<SL, IM, 0>), dim3(ntiles), dim3(se::k4Threads), se::k4_lds(SL), st, A, lda, W, ldw, bias, residual_f32, \
                      ln_w, ln_b, eps, M, K, out_f32, out_bf16, ntiles)
+  if (gelu_no_residual) {
+    hipLaunchKernelGGL((se::gemm4_res_ln_kernel<6, 1, 1>), dim3(ntiles), dim3(se::k4Threads), se::k4_lds(6), st, A, lda, W, ldw, bias, residual_f32,
+                       ln_w, ln_b, eps, M, K, out_f32, out_bf16, ntiles);
+    SE_LAUNCH_CHECK();
+    return SE_OK;
+  }
   switch (cfg) {
     case 1: SE4_LAUNCH(6, 1); break;
     case 2: SE4_LAUNCH(7, 0); break;
@@ -336,3 +358,17 @@ extern "C" int se_gemm_res_ln_bf16(const uint16_t* A, int lda, const uint16_t* W
   SE_LAUNCH_CHECK();
   return SE_OK;
 }
+
+extern "C" int se_gemm_res_ln_bf16(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias, const float* residual_f32,
+                                   const float* ln_w, const float* ln_b, float eps, int M, int N, int K,
+                                   float* out_f32, uint16_t* out_bf16, void* stream) {
+  return gemm4_launch(A, lda, W, ldw, bias, residual_f32, ln_w, ln_b, eps, M, N, K, out_f32, out_bf16, false, stream);
+}
+
+// x = LayerNorm(gelu(A . W^T + bias)): internal helper of the spec head (se_spechead_fwd_bf16)
+namespace se {
+int launch_gemm_gelu_ln(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias, const float* ln_w, const float* ln_b, float eps,
+                        int M, int N, int K, float* out_f32, uint16_t* out_bf16, hipStream_t st) {
+  return gemm4_launch(A, lda, W, ldw, bias, nullptr, ln_w, ln_b, eps, M, N, K, out_f32, out_bf16, true, st);
+}
+}  // namespace se
