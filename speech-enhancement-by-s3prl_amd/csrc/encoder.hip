@@ -546,13 +546,19 @@ extern "C" int se_encoder_fwd_bf16(const se_encoder* enc, const float* feats, co
     hipLaunchKernelGGL(se::cast_pad_kernel, dim3(grid), dim3(256), 0, st, feats, Mz, D, se::kInPad, w.xin);
     SE_LAUNCH_CHECK();
   }
-  if ((rc = se_gemm_bf16(w.xin, se::kInPad, enc->in_w, se::kInPad, enc->in_b, nullptr, M, H, se::kInPad, SE_ACT_IDENTITY, nullptr, w.tmp, H, stream))) return rc;
-  if ((rc = se::launch_layernorm(w.tmp, enc->pe, T, enc->in_ln_w, enc->in_ln_b, M, H, enc->cfg.ln_eps, w.x_f32, w.x_bf, st))) return rc;
   const int L = enc->cfg.layers;
   static int fuse_env = -1;
   if (fuse_env < 0) {
     const char* e = getenv("SE_AMD_FUSED_LN");
     fuse_env = e ? atoi(e) : 1;
+  }
+  if (fuse_env && H == 768 && (fuse_env == 2 || M >= (enc->cfg.fused_ln_min_rows > 0 ? enc->cfg.fused_ln_min_rows : 24576))) {
+    // one row-complete kernel: the positional table rides the residual input (row index modulo T)
+    if ((rc = se::launch_gemm_pos_ln(w.xin, se::kInPad, enc->in_w, se::kInPad, enc->in_b, enc->pe, T, enc->in_ln_w, enc->in_ln_b, enc->cfg.ln_eps, M, H,
+                                     se::kInPad, w.x_f32, w.x_bf, st))) return rc;
+  } else {
+    if ((rc = se_gemm_bf16(w.xin, se::kInPad, enc->in_w, se::kInPad, enc->in_b, nullptr, M, H, se::kInPad, SE_ACT_IDENTITY, nullptr, w.tmp, H, stream))) return rc;
+    if ((rc = se::launch_layernorm(w.tmp, enc->pe, T, enc->in_ln_w, enc->in_ln_b, M, H, enc->cfg.ln_eps, w.x_f32, w.x_bf, st))) return rc;
   }
   // the row-complete GEMM + LayerNorm kernel owns 128 x 768 outputs per workgroup: M / 128 workgroups.  It needs ~a full round of the
   // 256 CUs to pay off (B = 32: 251 workgroups); below ~24 k rows the unfused GEMM + LayerNorm pair is faster (B = 16: 3.19 vs 3.31 ms,

@@ -9,6 +9,8 @@ constexpr int kInPad = 128;       // input feature dim padded to a multiple of t
 
 // host launchers of kernels that live in encoder.hip / bwd.hip
 // gemm4.hip: x = LayerNorm(gelu(A . W^T + bias)), N = 768 only
+int launch_gemm_pos_ln(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias, const float* table, int T, const float* ln_w,
+                       const float* ln_b, float eps, int M, int N, int K, float* out_f32, uint16_t* out_bf16, hipStream_t st);
 int launch_gemm_gelu_ln(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias, const float* ln_w, const float* ln_b, float eps,
                         int M, int N, int K, float* out_f32, uint16_t* out_bf16, hipStream_t st);
 int launch_layernorm(const float* x, const float* pe, int T, const float* w, const float* b, int M, int H, float eps,

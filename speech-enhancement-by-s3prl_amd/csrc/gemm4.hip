@@ -41,7 +41,7 @@ template <int SLOTS, int INM, int GELU>
 __global__ __launch_bounds__(k4Threads) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm4_res_ln_kernel(
     const uint16_t* __restrict__ A, int lda, const uint16_t* __restrict__ W, int ldw, const float* __restrict__ bias,
     const float* __restrict__ residual, const float* __restrict__ ln_w, const float* __restrict__ ln_b, float eps, int M, int K,
-    float* __restrict__ out_f32, uint16_t* __restrict__ out_bf16, int ntiles) {
+    float* __restrict__ out_f32, uint16_t* __restrict__ out_bf16, int ntiles, int res_mod) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int k4WSlots = SLOTS, k4WBytes = k4WPiece * SLOTS, k4RedOff = k4WBytes + k4ABytes;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(k4Threads) __attribute__((amdgpu_waves_per_eu(2, 2)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int gm = min(m0 + wr * 64 + i * 16 + mrow, M - 1);
-      const float* rp = residual + (size_t)gm * k4N + col0;
+      const float* rp = residual + (size_t)(res_mod > 0 ? gm % res_mod : gm) * k4N + col0;      // res_mod = T: a (T, 768) positional table as the residual
 #pragma unroll
       for (int t = 0; t < 12; ++t) {
         if (GELU) {
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(k4Threads) __attribute__((amdgpu_waves_per_eu(2, 2)
 
 static int gemm4_launch(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias, const float* residual_f32,
                         const float* ln_w, const float* ln_b, float eps, int M, int N, int K,
-                        float* out_f32, uint16_t* out_bf16, bool gelu_no_residual, void* stream) {
+                        float* out_f32, uint16_t* out_bf16, bool gelu_no_residual, int res_mod, void* stream) {
   SE_REQUIRE(A && W && (residual_f32 || gelu_no_residual) && ln_w && ln_b && (out_f32 || out_bf16), "se_gemm_res_ln_bf16: null argument");
   if (gelu_no_residual) residual_f32 = ln_w;      // never dereferenced by the GELU instantiation; keeps the pointer checks below uniform
   if (N != se::k4N || K % se::k4BK != 0 || K < 4 * se::k4BK) {
@@ -341,10 +341,10 @@ static int gemm4_launch(const uint16_t* A, int lda, const uint16_t* W, int ldw, 
   se::ProfScope prof(se::kProfGemm, 2.0 * M * (double)N * K, st);
 #define SE4_LAUNCH(SL, IM)                                                                                                              \
   hipLaunchKernelGGL((se::gemm4_res_ln_kernel<SL, IM, 0>), dim3(ntiles), dim3(se::k4Threads), se::k4_lds(SL), st, A, lda, W, ldw, bias, residual_f32, \
-                     ln_w, ln_b, eps, M, K, out_f32, out_bf16, ntiles)
+                     ln_w, ln_b, eps, M, K, out_f32, out_bf16, ntiles, res_mod)
   if (gelu_no_residual) {
     hipLaunchKernelGGL((se::gemm4_res_ln_kernel<6, 1, 1>), dim3(ntiles), dim3(se::k4Threads), se::k4_lds(6), st, A, lda, W, ldw, bias, residual_f32,
-                       ln_w, ln_b, eps, M, K, out_f32, out_bf16, ntiles);
+                       ln_w, ln_b, eps, M, K, out_f32, out_bf16, ntiles, res_mod);
     SE_LAUNCH_CHECK();
     return SE_OK;
   }
@@ -362,13 +362,18 @@ static int gemm4_launch(const uint16_t* A, int lda, const uint16_t* W, int ldw, 
 extern "C" int se_gemm_res_ln_bf16(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias, const float* residual_f32,
                                    const float* ln_w, const float* ln_b, float eps, int M, int N, int K,
                                    float* out_f32, uint16_t* out_bf16, void* stream) {
-  return gemm4_launch(A, lda, W, ldw, bias, residual_f32, ln_w, ln_b, eps, M, N, K, out_f32, out_bf16, false, stream);
+  return gemm4_launch(A, lda, W, ldw, bias, residual_f32, ln_w, ln_b, eps, M, N, K, out_f32, out_bf16, false, 0, stream);
 }
 
 // x = LayerNorm(gelu(A . W^T + bias)): internal helper of the spec head (se_spechead_fwd_bf16)
 namespace se {
 int launch_gemm_gelu_ln(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias, const float* ln_w, const float* ln_b, float eps,
                         int M, int N, int K, float* out_f32, uint16_t* out_bf16, hipStream_t st) {
-  return gemm4_launch(A, lda, W, ldw, bias, nullptr, ln_w, ln_b, eps, M, N, K, out_f32, out_bf16, true, st);
+  return gemm4_launch(A, lda, W, ldw, bias, nullptr, ln_w, ln_b, eps, M, N, K, out_f32, out_bf16, true, 0, st);
+}
+// x = LayerNorm(A . W^T + bias + table[row % T]): the encoder's input stage (projection + sinusoidal positions + LayerNorm)
+int launch_gemm_pos_ln(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias, const float* table, int T, const float* ln_w,
+                       const float* ln_b, float eps, int M, int N, int K, float* out_f32, uint16_t* out_bf16, hipStream_t st) {
+  return gemm4_launch(A, lda, W, ldw, bias, table, ln_w, ln_b, eps, M, N, K, out_f32, out_bf16, false, T, st);
 }
 }  // namespace se
