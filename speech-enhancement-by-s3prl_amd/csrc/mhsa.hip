@@ -144,7 +144,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
     }                                                                                                                      \
     float mx = fmaxf(s0[0], s1[0]);                                                                                        \
     _Pragma("unroll") for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, s0[r]), s1[r]);       /* v_max3_f32 */            \
-    mx = fmaxf(mx, __shfl_xor(mx, 32));                                                                                    \
+    {   /* the other 32 keys of this query row live in lane ^ 32: v_permlane32_swap (VALU) instead of ds_bpermute (an LDS round trip */ \
+        /* of ~100 cycles in the middle of the tile's dependency chain)                                                            */ \
+      const auto sw_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);           \
+      mx = fmaxf(__uint_as_float(sw_[0]), __uint_as_float(sw_[1]));                                                        \
+    }                                                                                                                      \
     /* deferred rescale: the reference maximum only moves when the tile maximum exceeds it by > 2^kDefer (log2 domain), */  \
     /* so P <= 2^kDefer instead of 1 (bf16 / fp32 keep their relative precision) and the O-wide multiply is rare        */  \
     const float m_new = ((mx - m_run) * c > kDefer) ? mx : m_run;                                                          \
