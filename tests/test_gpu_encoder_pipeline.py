@@ -71,6 +71,34 @@ def test_encoder_full_size_one_utterance(gpu):
     assert rel_l2(hidden, ref) < 2e-2
 
 
+def test_row_complete_kernels_at_full_width(gpu):
+    """The row-complete GEMM + LayerNorm kernel (encoder input stage with the positional table as residual, attention-output and
+    FFN-output projections, spec-head dense -> gelu -> LayerNorm) is only selected from ~24 k rows on; here it is forced at two
+    ragged utterances (fused_ln_min_rows = 1) and must agree with the GEMM + LayerNorm pair and with the oracle."""
+    from speech_enhancement_by_s3prl_amd import pipeline
+    cfg = pipeline.make_config(layers=2)                    # hidden 768: the width the kernel is built for
+    ckpt = pipeline.synthetic_checkpoint(cfg, seed=5)
+    torch.manual_seed(9)
+    B, T = 2, 301                                           # 602 rows: five 128-row tiles, the last one ragged; T does not divide 128
+    feats = torch.randn(B, T, 80)
+    feats[1, 250:] = 0.0
+    outs = {}
+    for name, rows in (('pair', 1 << 30), ('fused', 1)):
+        up = pipeline.build_upstream(ckpt, gpu)
+        up._engine.fused_ln_min_rows = rows
+        hidden = up(feats.to(gpu))
+        with torch.no_grad():
+            pred, res = up.SpecHead(hidden)
+        outs[name] = (hidden.cpu(), res['log_predicted'].cpu())
+    assert rel_l2(outs['fused'][0], outs['pair'][0]) < 3e-3         # same arithmetic, different kernels (bf16 operands in both)
+    assert rel_l2(outs['fused'][1], outs['pair'][1]) < 3e-3
+    ocfg = oenc.Config(cfg)
+    ref = oenc.encoder_forward(feats, ckpt['Transformer'], ocfg)
+    rpred, rres = oheads.spec_head(ref, ckpt['SpecHead'], ocfg, log=True)
+    assert rel_l2(outs['fused'][0], ref) < 2e-2
+    assert rel_l2(outs['fused'][1], rres['log_predicted']) < 3e-2
+
+
 def test_ckpt_file_route_and_waveform_input(gpu, small, tmp_path):
     """TRANSFORMER(options, inp_dim) loads its own weights from options['ckpt_file'] (model.py:132-149) and accepts a
     waveform (B, T, C) when the checkpoint has an 'online' config (runner.py:275: upstream(wavs.transpose(1, 2)))."""
