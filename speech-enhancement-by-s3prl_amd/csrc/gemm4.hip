@@ -41,7 +41,7 @@ template <int SLOTS, int INM, int GELU>
 __global__ __launch_bounds__(k4Threads) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm4_res_ln_kernel(
     const uint16_t* __restrict__ A, int lda, const uint16_t* __restrict__ W, int ldw, const float* __restrict__ bias,
     const float* __restrict__ residual, const float* __restrict__ ln_w, const float* __restrict__ ln_b, float eps, int M, int K,
-    float* __restrict__ out_f32, uint16_t* __restrict__ out_bf16, int ntiles, int res_mod) {
+    float* __restrict__ out_f32, uint16_t* __restrict__ out_bf16, int ntiles, int res_mod, int stagger) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int k4WSlots = SLOTS, k4WBytes = k4WPiece * SLOTS, k4RedOff = k4WBytes + k4ABytes;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -54,6 +54,10 @@ __global__ __launch_bounds__(k4Threads) __attribute__((amdgpu_waves_per_eu(2, 2)
     id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
   }
   const int m0 = id * k4BM;
+  // stagger: every second workgroup starts `stagger` x ~3.4 us late, so that the HBM-bound phases of the two halves (residual read at
+  // the start, output write at the end) fall into each other's compute phase instead of all 251 workgroups hitting HBM together
+  if (stagger > 0 && (blockIdx.x & 8))
+    for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(127);
 
   // ---- DMA sources.  Weight piece (g, j) = rows {wcc*192 + j*64 + 0..63 : wcc = 0..3} = 16 chunks of 16 rows x 64 B;
   //      wave w issues chunks w and w+8.  chunk c -> wcc = c >> 2, piece-local rows 16 c + (lane >> 2).
@@ -326,8 +330,10 @@ static int gemm4_launch(const uint16_t* A, int lda, const uint16_t* W, int ldw, 
   SE_REQUIRE(M > 0 && lda >= K && ldw >= K && lda % 8 == 0 && ldw % 8 == 0, "se_gemm_res_ln_bf16: bad leading dimensions");
   SE_REQUIRE((((uintptr_t)A | (uintptr_t)W | (uintptr_t)residual_f32 | (uintptr_t)out_f32 | (uintptr_t)out_bf16 | (uintptr_t)bias |
                (uintptr_t)ln_w | (uintptr_t)ln_b) % 16) == 0, "se_gemm_res_ln_bf16: pointers must be 16-B aligned");
-  static int cfg = -1;
+  static int cfg = -1, stagger = 0;
   if (cfg < 0) {
+    const char* es = getenv("SE_AMD_GEMM4_STAGGER");
+    stagger = es ? atoi(es) : 3;        // x ~3.4 us; 2-4 measured best (4.93 -> 4.89 ms per step), 6+ loses
     const char* e = getenv("SE_AMD_GEMM4_CFG");          // developer switch: bit 0 = DMA issue between the MFMAs, bit 1 = 7-piece ring
     cfg = e ? (atoi(e) & 3) : 1;        // default: 6 pieces, MFMA-phase issue -- equal to read-phase issue when A streams from the Infinity Cache (B = 32 bench), 17 % faster when it comes from HBM
     SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::gemm4_res_ln_kernel<6, 0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, se::k4_lds(6)));
@@ -339,12 +345,13 @@ static int gemm4_launch(const uint16_t* A, int lda, const uint16_t* W, int ldw, 
   const int ntiles = (M + se::k4BM - 1) / se::k4BM;
   hipStream_t st = se::as_stream(stream);
   se::ProfScope prof(se::kProfGemm, 2.0 * M * (double)N * K, st);
+  const int stg_ = (K >= 768) ? stagger : 0;       // the short K = 128 input stage has no compute phase to hide anything under
 #define SE4_LAUNCH(SL, IM)                                                                                                              \
   hipLaunchKernelGGL((se::gemm4_res_ln_kernel<SL, IM, 0>), dim3(ntiles), dim3(se::k4Threads), se::k4_lds(SL), st, A, lda, W, ldw, bias, residual_f32, \
-                     ln_w, ln_b, eps, M, K, out_f32, out_bf16, ntiles, res_mod)
+                     ln_w, ln_b, eps, M, K, out_f32, out_bf16, ntiles, res_mod, stg_)
   if (gelu_no_residual) {
     hipLaunchKernelGGL((se::gemm4_res_ln_kernel<6, 1, 1>), dim3(ntiles), dim3(se::k4Threads), se::k4_lds(6), st, A, lda, W, ldw, bias, residual_f32,
-                       ln_w, ln_b, eps, M, K, out_f32, out_bf16, ntiles, res_mod);
+                       ln_w, ln_b, eps, M, K, out_f32, out_bf16, ntiles, res_mod, stg_);
     SE_LAUNCH_CHECK();
     return SE_OK;
   }
