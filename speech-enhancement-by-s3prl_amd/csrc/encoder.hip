@@ -499,6 +499,7 @@ namespace {
 struct Ws {
   uint16_t *xin, *x_bf, *qkv, *ctx, *h;
   float *x_f32, *tmp, *slabs;
+  uint8_t* lo;           // low bytes of the 24-bit residual stream (row-complete path)
   size_t total;
 };
 constexpr size_t kSplitKRows = 3072;   // small-batch path: split-K FFN2 up to this many rows (B = 1: 0.73 vs 0.85 ms, B = 2: 0.84 vs 0.93; B = 4: no gain)
@@ -517,6 +518,7 @@ Ws carve(const se_encoder* e, size_t M, char* base) {
   w.ctx = (uint16_t*)take(M * H * 2);
   w.h = (uint16_t*)take(M * I * 2);
   w.slabs = (float*)take(M <= kSplitKRows ? (size_t)kSplitK * M * H * 4 : 0);
+  w.lo = (uint8_t*)take(H == 768 ? se::gemm4_lo_bytes((int)M) : 0);
   w.total = off;
   return w;
 }
@@ -552,18 +554,19 @@ extern "C" int se_encoder_fwd_bf16(const se_encoder* enc, const float* feats, co
     const char* e = getenv("SE_AMD_FUSED_LN");
     fuse_env = e ? atoi(e) : 1;
   }
-  if (fuse_env && H == 768 && (fuse_env == 2 || M >= (enc->cfg.fused_ln_min_rows > 0 ? enc->cfg.fused_ln_min_rows : 24576))) {
+  // the row-complete GEMM + LayerNorm kernel owns 128 x 768 outputs per workgroup: M / 128 workgroups.  It needs ~a full round of the
+  // 256 CUs to pay off (B = 32: 251 workgroups); below ~24 k rows the unfused GEMM + LayerNorm pair is faster (B = 16: 3.19 vs 3.31 ms,
+  // B = 1: 8 workgroups, 0.85 vs 1.70 ms).  SE_AMD_FUSED_LN = 2 forces it.  Between its launches the residual stream travels as
+  // bf16 + int8 (24 bits, gemm4.hip) instead of fp32 + bf16: 196 instead of 295 MB per K = 768 launch.
+  const bool fused = fuse_env && H == 768 && I % 32 == 0 && I >= 128 && (fuse_env == 2 || M >= (enc->cfg.fused_ln_min_rows > 0 ? enc->cfg.fused_ln_min_rows : 24576));
+  if (fused) {
     // one row-complete kernel: the positional table rides the residual input (row index modulo T)
     if ((rc = se::launch_gemm_pos_ln(w.xin, se::kInPad, enc->in_w, se::kInPad, enc->in_b, enc->pe, T, enc->in_ln_w, enc->in_ln_b, enc->cfg.ln_eps, M, H,
-                                     se::kInPad, w.x_f32, w.x_bf, st))) return rc;
+                                     se::kInPad, nullptr, w.x_bf, w.lo, st))) return rc;
   } else {
     if ((rc = se_gemm_bf16(w.xin, se::kInPad, enc->in_w, se::kInPad, enc->in_b, nullptr, M, H, se::kInPad, SE_ACT_IDENTITY, nullptr, w.tmp, H, stream))) return rc;
     if ((rc = se::launch_layernorm(w.tmp, enc->pe, T, enc->in_ln_w, enc->in_ln_b, M, H, enc->cfg.ln_eps, w.x_f32, w.x_bf, st))) return rc;
   }
-  // the row-complete GEMM + LayerNorm kernel owns 128 x 768 outputs per workgroup: M / 128 workgroups.  It needs ~a full round of the
-  // 256 CUs to pay off (B = 32: 251 workgroups); below ~24 k rows the unfused GEMM + LayerNorm pair is faster (B = 16: 3.19 vs 3.31 ms,
-  // B = 1: 8 workgroups, 0.85 vs 1.70 ms).  SE_AMD_FUSED_LN = 2 forces it.
-  const bool fused = fuse_env && H == 768 && I % 32 == 0 && I >= 128 && (fuse_env == 2 || M >= (enc->cfg.fused_ln_min_rows > 0 ? enc->cfg.fused_ln_min_rows : 24576));
   for (int i = 0; i < L; ++i) {
     const se_encoder::Layer& y = enc->layers[i];
     // B2
@@ -571,20 +574,18 @@ extern "C" int se_encoder_fwd_bf16(const se_encoder* enc, const float* feats, co
     if ((rc = se_mhsa_fwd_bf16(w.qkv, lengths, B, T, enc->cfg.heads, w.ctx, stream))) return rc;
     // attention output projection + residual + LayerNorm: one fused row-complete kernel when H == 768 (ping-pong x buffers:
     // the residual is read while the new stream is written), else GEMM + LayerNorm
-    if (fused) {
-      if ((rc = se_gemm_res_ln_bf16(w.ctx, H, y.ao_w, H, y.ao_b, w.x_f32, y.aln_w, y.aln_b, enc->cfg.ln_eps, M, H, H, w.tmp, w.x_bf, stream))) return rc;
-      std::swap(w.x_f32, w.tmp);
+    if (fused) {      // in place: a workgroup reads the residual rows of its own tile before it writes them
+      if ((rc = se::launch_gemm_res24_ln(w.ctx, H, y.ao_w, H, y.ao_b, w.x_bf, w.lo, y.aln_w, y.aln_b, enc->cfg.ln_eps, M, H, H, nullptr, w.x_bf, w.lo, st))) return rc;
     } else {
       if ((rc = se_gemm_bf16(w.ctx, H, y.ao_w, H, y.ao_b, w.x_f32, M, H, H, SE_ACT_IDENTITY, nullptr, w.tmp, H, stream))) return rc;
       if ((rc = se::launch_layernorm(w.tmp, nullptr, 1, y.aln_w, y.aln_b, M, H, enc->cfg.ln_eps, w.x_f32, w.x_bf, st))) return rc;
     }
     // B3
     if ((rc = se_gemm_bf16(w.x_bf, H, y.ff1_w, H, y.ff1_b, nullptr, M, I, H, SE_ACT_GELU, w.h, nullptr, I, stream))) return rc;
-    if (fused) {
-      float* xo = (i == L - 1) ? hidden : w.tmp;
-      if ((rc = se_gemm_res_ln_bf16(w.h, I, y.ff2_w, I, y.ff2_b, w.x_f32, y.oln_w, y.oln_b, enc->cfg.ln_eps, M, H, I, xo,
-                                    (i == L - 1) ? nullptr : w.x_bf, stream))) return rc;
-      if (i != L - 1) std::swap(w.x_f32, w.tmp);
+    if (fused) {      // the last layer leaves the stream as the fp32 `hidden` the caller asked for
+      if (i == L - 1) rc = se::launch_gemm_res24_ln(w.h, I, y.ff2_w, I, y.ff2_b, w.x_bf, w.lo, y.oln_w, y.oln_b, enc->cfg.ln_eps, M, H, I, hidden, nullptr, nullptr, st);
+      else rc = se::launch_gemm_res24_ln(w.h, I, y.ff2_w, I, y.ff2_b, w.x_bf, w.lo, y.oln_w, y.oln_b, enc->cfg.ln_eps, M, H, I, nullptr, w.x_bf, w.lo, st);
+      if (rc) return rc;
     } else {
       float* xo = (i == L - 1) ? hidden : w.x_f32;
       if (Mz <= kSplitKRows && H == 768 && I % (kSplitK * 64) == 0 && I / kSplitK >= 128) {

@@ -10,7 +10,12 @@ constexpr int kInPad = 128;       // input feature dim padded to a multiple of t
 // host launchers of kernels that live in encoder.hip / bwd.hip
 // gemm4.hip: x = LayerNorm(gelu(A . W^T + bias)), N = 768 only
 int launch_gemm_pos_ln(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias, const float* table, int T, const float* ln_w,
-                       const float* ln_b, float eps, int M, int N, int K, float* out_f32, uint16_t* out_bf16, hipStream_t st);
+                       const float* ln_b, float eps, int M, int N, int K, float* out_f32, uint16_t* out_bf16, uint8_t* out_lo, hipStream_t st);
+// the same kernel on the 24-bit residual stream (bf16 hi = the x_bf16 tensor + int8 lo, tile-major)
+int launch_gemm_res24_ln(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias, const uint16_t* res_hi, const uint8_t* res_lo,
+                         const float* ln_w, const float* ln_b, float eps, int M, int N, int K, float* out_f32, uint16_t* out_bf16, uint8_t* out_lo,
+                         hipStream_t st);
+size_t gemm4_lo_bytes(int M);
 int launch_gemm_gelu_ln(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias, const float* ln_w, const float* ln_b, float eps,
                         int M, int N, int K, float* out_f32, uint16_t* out_bf16, hipStream_t st);
 int launch_layernorm(const float* x, const float* pe, int T, const float* w, const float* b, int M, int H, float eps,

@@ -36,12 +36,30 @@ __device__ __forceinline__ int swz4_f(int row) { return (-(row >> 2)) & 3; }
 __device__ __forceinline__ int swz4(int row, int chunk) { return row * 64 + ((chunk ^ swz4_f(row)) << 4); }
 
 // SLOTS: weight-ring depth (pieces; SLOTS - 1 in flight).  INM: the ring-refill DMAs are issued between the MFMAs (1) or in the read phase (0)
+// ---- 24-bit residual stream between the row-complete launches of one encoder pass: value = bf16 hi (the x_bf16 tensor the next GEMM
+//      reads anyway, round-to-nearest) + int8 lo = round((y - hi) * 2^(15 - E)), E = exponent of hi: 16 mantissa bits (2^-17 relative; the
+//      encoder's error against fp32 is unchanged: 3.177e-3 vs 3.172e-3 relative L2) for 3 B per element instead of 4 + 2.  lo lives in the
+//      accumulator's own layout (one contiguous 256-B block per wave, row tile and column tile): written and read by the same lane.
+__device__ __forceinline__ float dec24(uint32_t hi16, int lo8) {
+  const uint32_t eb = (hi16 >> 7) & 0xffu;
+  const float sc = __uint_as_float(eb > 15u ? (eb - 15u) << 23 : 0u);           // 2^(E - 15); 0 below 2^-111
+  return fmaf((float)lo8, sc, __uint_as_float(hi16 << 16));
+}
+__device__ __forceinline__ uint32_t enc24_lo(float y, uint32_t hi16) {
+  const uint32_t eb = (hi16 >> 7) & 0xffu;
+  const float sc = __uint_as_float((eb >= 15u && eb <= 254u) ? (269u - eb) << 23 : 0u);      // 2^(15 - E)
+  const float q = rintf((y - __uint_as_float(hi16 << 16)) * sc);
+  return (uint32_t)(int)fminf(fmaxf(q, -128.f), 127.f) & 0xffu;
+}
+
 // GELU: x = LayerNorm(gelu(A . W^T + bias)) without a residual (the spec head's dense -> act -> LayerNorm, model.py:100-101)
-template <int SLOTS, int INM, int GELU>
+// RIN : the residual comes as (bf16 hi row-major, int8 lo tile-major) instead of fp32;  ROUT: the output goes out as (bf16, lo) instead of (fp32, bf16)
+template <int SLOTS, int INM, int GELU, int RIN, int ROUT>
 __global__ __launch_bounds__(k4Threads) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm4_res_ln_kernel(
     const uint16_t* __restrict__ A, int lda, const uint16_t* __restrict__ W, int ldw, const float* __restrict__ bias,
     const float* __restrict__ residual, const float* __restrict__ ln_w, const float* __restrict__ ln_b, float eps, int M, int K,
-    float* __restrict__ out_f32, uint16_t* __restrict__ out_bf16, int ntiles, int res_mod, int stagger) {
+    float* __restrict__ out_f32, uint16_t* __restrict__ out_bf16, int ntiles, int res_mod, int stagger,
+    const uint8_t* __restrict__ res_lo, uint8_t* __restrict__ out_lo) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int k4WSlots = SLOTS, k4WBytes = k4WPiece * SLOTS, k4RedOff = k4WBytes + k4ABytes;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -120,6 +138,11 @@ __global__ __launch_bounds__(k4Threads) __attribute__((amdgpu_waves_per_eu(2, 2)
       for (int t = 0; t < 12; ++t) {
         if (GELU) {
           acc[i][t] = (f32x4){bb[t].x, bb[t].y, bb[t].z, bb[t].w};
+        } else if (RIN) {
+          const uint2 h4 = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(residual) + (size_t)gm * k4N + col0 + 16 * t);
+          const uint32_t l4 = *reinterpret_cast<const uint32_t*>(res_lo + ((((size_t)id * 8 + wave) * 4 + i) * 12 + t) * 256 + lane * 4);
+          acc[i][t] = (f32x4){dec24(h4.x & 0xffffu, (int)(int8_t)(l4 & 0xffu)) + bb[t].x, dec24(h4.x >> 16, (int)(int8_t)((l4 >> 8) & 0xffu)) + bb[t].y,
+                              dec24(h4.y & 0xffffu, (int)(int8_t)((l4 >> 16) & 0xffu)) + bb[t].z, dec24(h4.y >> 16, (int)(int8_t)(l4 >> 24)) + bb[t].w};
         } else {
           const float4 rr = *reinterpret_cast<const float4*>(rp + 16 * t);
           acc[i][t] = (f32x4){rr.x + bb[t].x, rr.y + bb[t].y, rr.z + bb[t].z, rr.w + bb[t].w};
@@ -297,11 +320,14 @@ __global__ __launch_bounds__(k4Threads) __attribute__((amdgpu_waves_per_eu(2, 2)
       const float y1 = lw.y * ((acc[i][t][1] - mean[i]) * rstd[i]) + lb.y;
       const float y2 = lw.z * ((acc[i][t][2] - mean[i]) * rstd[i]) + lb.z;
       const float y3 = lw.w * ((acc[i][t][3] - mean[i]) * rstd[i]) + lb.w;
-      if (ok && out_f32) *reinterpret_cast<float4*>(out_f32 + o + 16 * t) = make_float4(y0, y1, y2, y3);
+      if (!ROUT && ok && out_f32) *reinterpret_cast<float4*>(out_f32 + o + 16 * t) = make_float4(y0, y1, y2, y3);
       if (out_bf16) {
         // 16-B bf16 stores (as gemm3.hip): lanes l, l ^ 16 trade 4-column pieces of the MFMA tile pair (t - 1, t), so a lane owns 8
         // consecutive columns and one wave instruction writes 16 rows x 64 contiguous bytes instead of 16 x 32
         const uint2 pk = make_uint2(pack_bf16x2(y0, y1), pack_bf16x2(y2, y3));
+        if (ROUT)      // tile-major lo bytes: rows past M are written too (the buffer covers whole tiles) and never read as real rows
+          *reinterpret_cast<uint32_t*>(out_lo + ((((size_t)id * 8 + wave) * 4 + i) * 12 + t) * 256 + lane * 4) =
+              enc24_lo(y0, pk.x & 0xffffu) | (enc24_lo(y1, pk.x >> 16) << 8) | (enc24_lo(y2, pk.y & 0xffffu) << 16) | (enc24_lo(y3, pk.y >> 16) << 24);
         if (t & 1) {
           const uint2 keep = godd ? pk : pk_prev, send = godd ? pk_prev : pk;
           uint2 recv;
@@ -320,46 +346,52 @@ __global__ __launch_bounds__(k4Threads) __attribute__((amdgpu_waves_per_eu(2, 2)
 
 static int gemm4_launch(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias, const float* residual_f32,
                         const float* ln_w, const float* ln_b, float eps, int M, int N, int K,
-                        float* out_f32, uint16_t* out_bf16, bool gelu_no_residual, int res_mod, void* stream) {
-  SE_REQUIRE(A && W && (residual_f32 || gelu_no_residual) && ln_w && ln_b && (out_f32 || out_bf16), "se_gemm_res_ln_bf16: null argument");
+                        float* out_f32, uint16_t* out_bf16, bool gelu_no_residual, int res_mod, void* stream,
+                        const uint16_t* res_hi = nullptr, const uint8_t* res_lo = nullptr, uint8_t* out_lo = nullptr) {
+  const bool rin = res_hi != nullptr, rout = out_lo != nullptr;
+  SE_REQUIRE(A && W && (residual_f32 || gelu_no_residual || rin) && ln_w && ln_b && (out_f32 || out_bf16), "se_gemm_res_ln_bf16: null argument");
+  SE_REQUIRE(!rin || res_lo, "se_gemm_res_ln_bf16: 24-bit residual without its low bytes");
+  SE_REQUIRE(!rout || out_bf16, "se_gemm_res_ln_bf16: 24-bit output needs the bf16 tensor");
   if (gelu_no_residual) residual_f32 = ln_w;      // never dereferenced by the GELU instantiation; keeps the pointer checks below uniform
+  if (rin) residual_f32 = reinterpret_cast<const float*>(res_hi);
   if (N != se::k4N || K % se::k4BK != 0 || K < 4 * se::k4BK) {
     se::set_error("se_gemm_res_ln_bf16: the fused kernel is specialised for N = 768 and K a multiple of 32, K >= 128 (got N=%d K=%d)", N, K);
     return SE_ERR_UNSUPPORTED;
   }
   SE_REQUIRE(M > 0 && lda >= K && ldw >= K && lda % 8 == 0 && ldw % 8 == 0, "se_gemm_res_ln_bf16: bad leading dimensions");
   SE_REQUIRE((((uintptr_t)A | (uintptr_t)W | (uintptr_t)residual_f32 | (uintptr_t)out_f32 | (uintptr_t)out_bf16 | (uintptr_t)bias |
-               (uintptr_t)ln_w | (uintptr_t)ln_b) % 16) == 0, "se_gemm_res_ln_bf16: pointers must be 16-B aligned");
+               (uintptr_t)ln_w | (uintptr_t)ln_b | (uintptr_t)res_lo | (uintptr_t)out_lo) % 16) == 0, "se_gemm_res_ln_bf16: pointers must be 16-B aligned");
   static int cfg = -1, stagger = 0;
   if (cfg < 0) {
     const char* es = getenv("SE_AMD_GEMM4_STAGGER");
     stagger = es ? atoi(es) : 3;        // x ~3.4 us; 2-4 measured best (4.93 -> 4.89 ms per step), 6+ loses
     const char* e = getenv("SE_AMD_GEMM4_CFG");          // developer switch: bit 0 = DMA issue between the MFMAs, bit 1 = 7-piece ring
     cfg = e ? (atoi(e) & 3) : 1;        // default: 6 pieces, MFMA-phase issue -- equal to read-phase issue when A streams from the Infinity Cache (B = 32 bench), 17 % faster when it comes from HBM
-    SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::gemm4_res_ln_kernel<6, 0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, se::k4_lds(6)));
-    SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::gemm4_res_ln_kernel<6, 1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, se::k4_lds(6)));
-    SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::gemm4_res_ln_kernel<7, 0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, se::k4_lds(7)));
-    SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::gemm4_res_ln_kernel<7, 1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, se::k4_lds(7)));
-    SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::gemm4_res_ln_kernel<6, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, se::k4_lds(6)));
+    SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::gemm4_res_ln_kernel<6, 0, 0, 0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, se::k4_lds(6)));
+    SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::gemm4_res_ln_kernel<6, 1, 0, 0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, se::k4_lds(6)));
+    SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::gemm4_res_ln_kernel<7, 0, 0, 0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, se::k4_lds(7)));
+    SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::gemm4_res_ln_kernel<7, 1, 0, 0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, se::k4_lds(7)));
+    SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::gemm4_res_ln_kernel<6, 1, 1, 0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, se::k4_lds(6)));
+    SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::gemm4_res_ln_kernel<6, 1, 0, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, se::k4_lds(6)));
+    SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::gemm4_res_ln_kernel<6, 1, 0, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, se::k4_lds(6)));
+    SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::gemm4_res_ln_kernel<6, 1, 0, 1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, se::k4_lds(6)));
   }
   const int ntiles = (M + se::k4BM - 1) / se::k4BM;
   hipStream_t st = se::as_stream(stream);
   se::ProfScope prof(se::kProfGemm, 2.0 * M * (double)N * K, st);
   const int stg_ = (K >= 768) ? stagger : 0;       // the short K = 128 input stage has no compute phase to hide anything under
-#define SE4_LAUNCH(SL, IM)                                                                                                              \
-  hipLaunchKernelGGL((se::gemm4_res_ln_kernel<SL, IM, 0>), dim3(ntiles), dim3(se::k4Threads), se::k4_lds(SL), st, A, lda, W, ldw, bias, residual_f32, \
-                     ln_w, ln_b, eps, M, K, out_f32, out_bf16, ntiles, res_mod, stg_)
-  if (gelu_no_residual) {
-    hipLaunchKernelGGL((se::gemm4_res_ln_kernel<6, 1, 1>), dim3(ntiles), dim3(se::k4Threads), se::k4_lds(6), st, A, lda, W, ldw, bias, residual_f32,
-                       ln_w, ln_b, eps, M, K, out_f32, out_bf16, ntiles, res_mod, stg_);
-    SE_LAUNCH_CHECK();
-    return SE_OK;
-  }
-  switch (cfg) {
-    case 1: SE4_LAUNCH(6, 1); break;
-    case 2: SE4_LAUNCH(7, 0); break;
-    case 3: SE4_LAUNCH(7, 1); break;
-    default: SE4_LAUNCH(6, 0); break;
+#define SE4_LAUNCH(SL, IM, GE, RI, RO)                                                                                                    \
+  hipLaunchKernelGGL((se::gemm4_res_ln_kernel<SL, IM, GE, RI, RO>), dim3(ntiles), dim3(se::k4Threads), se::k4_lds(SL), st, A, lda, W, ldw, bias, \
+                     residual_f32, ln_w, ln_b, eps, M, K, out_f32, out_bf16, ntiles, res_mod, stg_, res_lo, out_lo)
+  if (gelu_no_residual) SE4_LAUNCH(6, 1, 1, 0, 0);
+  else if (rin && rout) SE4_LAUNCH(6, 1, 0, 1, 1);
+  else if (rin) SE4_LAUNCH(6, 1, 0, 1, 0);
+  else if (rout) SE4_LAUNCH(6, 1, 0, 0, 1);
+  else switch (cfg) {
+    case 0: SE4_LAUNCH(6, 0, 0, 0, 0); break;
+    case 2: SE4_LAUNCH(7, 0, 0, 0, 0); break;
+    case 3: SE4_LAUNCH(7, 1, 0, 0, 0); break;
+    default: SE4_LAUNCH(6, 1, 0, 0, 0); break;
   }
 #undef SE4_LAUNCH
   SE_LAUNCH_CHECK();
@@ -372,15 +404,23 @@ extern "C" int se_gemm_res_ln_bf16(const uint16_t* A, int lda, const uint16_t* W
   return gemm4_launch(A, lda, W, ldw, bias, residual_f32, ln_w, ln_b, eps, M, N, K, out_f32, out_bf16, false, 0, stream);
 }
 
-// x = LayerNorm(gelu(A . W^T + bias)): internal helper of the spec head (se_spechead_fwd_bf16)
 namespace se {
+// x = LayerNorm(gelu(A . W^T + bias)): internal helper of the spec head (se_spechead_fwd_bf16)
 int launch_gemm_gelu_ln(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias, const float* ln_w, const float* ln_b, float eps,
                         int M, int N, int K, float* out_f32, uint16_t* out_bf16, hipStream_t st) {
   return gemm4_launch(A, lda, W, ldw, bias, nullptr, ln_w, ln_b, eps, M, N, K, out_f32, out_bf16, true, 0, st);
 }
-// x = LayerNorm(A . W^T + bias + table[row % T]): the encoder's input stage (projection + sinusoidal positions + LayerNorm)
+// x = LayerNorm(A . W^T + bias + table[row % T]): the encoder's input stage (projection + sinusoidal positions + LayerNorm); out_lo != nullptr:
+// the stream leaves as (bf16, lo) instead of (fp32, bf16)
 int launch_gemm_pos_ln(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias, const float* table, int T, const float* ln_w,
-                       const float* ln_b, float eps, int M, int N, int K, float* out_f32, uint16_t* out_bf16, hipStream_t st) {
-  return gemm4_launch(A, lda, W, ldw, bias, table, ln_w, ln_b, eps, M, N, K, out_f32, out_bf16, false, T, st);
+                       const float* ln_b, float eps, int M, int N, int K, float* out_f32, uint16_t* out_bf16, uint8_t* out_lo, hipStream_t st) {
+  return gemm4_launch(A, lda, W, ldw, bias, table, ln_w, ln_b, eps, M, N, K, out_f32, out_bf16, false, T, st, nullptr, nullptr, out_lo);
 }
+// the encoder's projections on the 24-bit stream: residual (res_hi, res_lo) in; (out_bf16, out_lo) or, for the last layer, fp32 out
+int launch_gemm_res24_ln(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias, const uint16_t* res_hi, const uint8_t* res_lo,
+                         const float* ln_w, const float* ln_b, float eps, int M, int N, int K, float* out_f32, uint16_t* out_bf16, uint8_t* out_lo,
+                         hipStream_t st) {
+  return gemm4_launch(A, lda, W, ldw, bias, nullptr, ln_w, ln_b, eps, M, N, K, out_f32, out_bf16, false, 0, st, res_hi, res_lo, out_lo);
+}
+size_t gemm4_lo_bytes(int M) { return (size_t)((M + k4BM - 1) / k4BM) * k4BM * k4N; }
 }  // namespace se
