@@ -85,7 +85,7 @@ def cpu_baseline(batch, layers, seconds_budget=25.0):
                       f'{dt:.2f} s per batch on {cpu_name}'}
 
 
-PMC_FILE = os.path.join(ROOT, 'profiles', 'r01_g_pmc_fetch_write.json')
+PMC_FILE = os.path.join(ROOT, 'profiles', 'r01_h_pmc_fetch_write.json')
 
 
 def pmc_traffic(substrings):
@@ -248,7 +248,7 @@ def main():
         traffic = pmc_traffic(('gemm2_bf16_kernel', 'gemm3_bf16_kernel', 'gemm4_res_ln_kernel')) if args.workload == 'enhance' else None
         out['roofline'] = {'bound': 'mfma', 'kernel': 'gemm_bf16_kernel', 'achieved': achieved, 'peak': MFMA_BF16_PEAK_TFLOPS,
                            'unit': 'TFLOP/s', 'frac': achieved / MFMA_BF16_PEAK_TFLOPS, 'traffic': traffic,
-                           'traffic_unit': 'HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, committed PMC passes: profiles/r01_g_pmc_fetch_write.json)',
+                           'traffic_unit': 'HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, committed PMC passes: profiles/r01_h_pmc_fetch_write.json)',
                            'launches': g_n, 'avg_launch_ms': g_ms / max(g_n, 1),
                            'algorithmic_flop_per_launch': g_flop / max(g_n, 1)}
         others = {}
