@@ -364,7 +364,7 @@ static int gemm4_launch(const uint16_t* A, int lda, const uint16_t* W, int ldw, 
   static int cfg = -1, stagger = 0;
   if (cfg < 0) {
     const char* es = getenv("SE_AMD_GEMM4_STAGGER");
-    stagger = es ? atoi(es) : 3;        // x ~3.4 us; 2-4 measured best (4.93 -> 4.89 ms per step), 6+ loses
+    stagger = es ? atoi(es) : 0;        // x ~3.4 us.  With the fp32 stream 2-4 was worth 0.7 % (4.93 -> 4.89 ms per step); with the 24-bit stream it is 0 +- 0.3 %: off
     const char* e = getenv("SE_AMD_GEMM4_CFG");          // developer switch: bit 0 = DMA issue between the MFMAs, bit 1 = 7-piece ring
     cfg = e ? (atoi(e) & 3) : 1;        // default: 6 pieces, MFMA-phase issue -- equal to read-phase issue when A streams from the Infinity Cache (B = 32 bench), 17 % faster when it comes from HBM
     SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::gemm4_res_ln_kernel<6, 0, 0, 0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, se::k4_lds(6)));
