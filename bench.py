@@ -13,8 +13,9 @@ Multi-GPU: utterances shard data-parallel with NO data-path collective (inferenc
 the same per-GPU batch ("weak" scaling); value = all utterances / max-over-ranks time.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus N ...            (no torchrun environment: starts the N ranks itself, see launch_ranks())
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line on rank 0 (`n_gpus` = the world size the ranks OBSERVED through the collective, checked against --gpus).
 """
 import argparse
 import ctypes
@@ -106,6 +107,59 @@ def pmc_traffic(substrings):
     return tot / n if n else None
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` outside torchrun: start N ranks as a CHILD `python -m torch.distributed.run` (this process has not
+    touched the GPU and never execs), relay rank 0's JSON line and the child's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + argv
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith('{') and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if proc.returncode != 0 or line is None:
+        print(f'bench.py: the {n}-rank child exited with code {proc.returncode}' + ('' if line else ' and printed no JSON line'), file=sys.stderr)
+        sys.exit(proc.returncode or 1)
+    got = json.loads(line).get('n_gpus')
+    if got != n:
+        print(f'bench.py: asked for {n} ranks, the job observed {got}', file=sys.stderr)
+        sys.exit(1)
+    print(line, flush=True)
+    sys.exit(0)
+
+
+def launch_check(args):
+    """--launch-check: the rank plumbing alone (process group, barrier, rank count by all-reduce, one JSON line), no kernels --
+    what the CPU test of the launcher runs over gloo."""
+    import torch.distributed as dist
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29500')
+    os.environ.setdefault('RANK', '0')
+    os.environ.setdefault('WORLD_SIZE', '1')
+    dist.init_process_group(args.backend)
+    dist.barrier()
+    ones = torch.ones(1, dtype=torch.float64)
+    dist.all_reduce(ones)
+    world = int(ones.item())
+    rank = dist.get_rank()
+    dist.barrier()
+    dist.destroy_process_group()
+    if world != args.gpus:
+        print(f'bench.py: --gpus {args.gpus} but {world} ranks joined', file=sys.stderr)
+        sys.exit(1)
+    if rank == 0:
+        print(json.dumps({'metric': 'launch-check', 'n_gpus': world, 'world_observed': world, 'backend': args.backend}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -121,12 +175,22 @@ def main():
     ap.add_argument('--graph', action='store_true', help='replay the enhance pass as one hipGraph launch (serving-size batches are launch-bound)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--backend', default='nccl', help="torch.distributed backend of the ranks ('nccl' = RCCL over xGMI)")
+    ap.add_argument('--launch-check', action='store_true', help='rank plumbing only (no kernels): used by the CPU test of the launcher')
     args = ap.parse_args()
+
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        launch_ranks(args.gpus, sys.argv[1:])            # never returns; nothing above touched the GPU
+    if args.launch_check:
+        return launch_check(args)
 
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     distributed = world > 1 or 'RANK' in os.environ      # under torchrun always go through RCCL (also at N = 1)
+    if world != args.gpus:
+        print(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}', file=sys.stderr)
+        sys.exit(2)
     if not torch.cuda.is_available():
         print('bench.py needs an MI355X: the hot path has no CPU fallback', file=sys.stderr)
         sys.exit(2)
@@ -141,8 +205,16 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
-        dist.init_process_group('nccl', device_id=dev)
+        dist.init_process_group(args.backend, device_id=dev)
         dist.barrier()                      # creates the communicator now (not inside the timed region)
+        ones = torch.ones(1, device=dev, dtype=torch.float64)
+        dist.all_reduce(ones)               # the world size the collective itself sees
+        world_observed = int(ones.item())
+        if world_observed != args.gpus:
+            print(f'bench.py: --gpus {args.gpus} but the all-reduce counted {world_observed} ranks', file=sys.stderr)
+            sys.exit(2)
+    else:
+        world_observed = 1
 
     from speech_enhancement_by_s3prl_amd import _lib, pipeline, synth
     lib = _lib.load()
@@ -207,14 +279,15 @@ def main():
     total_utts = args.batch * world * args.steps
     out = {
         'metric': {'enhance': 'enhanced 10s utts/sec', 'finetune': 'fine-tuned 10s utts/sec (Mockingjay training step)',
-                   'lstm': 'trained 10s utts/sec (LSTM head training step)'}[args.workload], 'value': total_utts / elapsed, 'unit': 'utt/s', 'n_gpus': world,
+                   'lstm': 'trained 10s utts/sec (LSTM head training step)'}[args.workload], 'value': total_utts / elapsed, 'unit': 'utt/s', 'n_gpus': world_observed,
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1000.0 * elapsed / args.steps,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
         'config': {'workload': 'configs[1]: TERA/Mockingjay upstream (6x768x12x3072, pretrain_sample.yaml) + '
                                'TransformerSpecPredictionHead, evaluate()-style pass, 10 s @ 16 kHz',
                    'batch_per_gpu': args.batch, 'global_batch': args.batch * world, 'layers': args.layers,
                    'frames': 1001, 'parallelism': f'dp{world} (utterance-sharded inference, no data-path collective)',
-                   'weights': 'seeded random, real sizes'},
+                   'weights': 'seeded random, real sizes',
+                   'ranks': f'{world_observed} ranks counted by all-reduce over {args.backend}' if distributed else 'single process, no process group'},
     }
     if args.graph and args.workload == 'enhance':
         out['config']['launch'] = 'one hipGraph replay per step'
@@ -245,7 +318,9 @@ def main():
             fam[name] = (ms.value, work.value, n.value)
         g_ms, g_flop, g_n = fam['gemm_bf16']
         achieved = g_flop / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
-        traffic = pmc_traffic(('gemm2_bf16_kernel', 'gemm3_bf16_kernel', 'gemm4_res_ln_kernel')) if args.workload == 'enhance' else None
+        # the committed PMC passes are of the default command: report them only when this run is that command
+        pmc_matches = (args.workload == 'enhance' and args.batch == 32 and args.layers == 6 and args.streams == 1 and not args.graph)
+        traffic = pmc_traffic(('gemm2_bf16_kernel', 'gemm3_bf16_kernel', 'gemm4_res_ln_kernel')) if pmc_matches else None
         out['roofline'] = {'bound': 'mfma', 'kernel': 'gemm_bf16_kernel', 'achieved': achieved, 'peak': MFMA_BF16_PEAK_TFLOPS,
                            'unit': 'TFLOP/s', 'frac': achieved / MFMA_BF16_PEAK_TFLOPS, 'traffic': traffic,
                            'traffic_unit': 'HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, committed PMC passes: profiles/r01_h_pmc_fetch_write.json)',

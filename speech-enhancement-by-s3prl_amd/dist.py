@@ -35,6 +35,27 @@ def all_reduce_sums(sums):
     return sums
 
 
+@torch.no_grad()
+def broadcast_parameters(module, src=0):
+    """Replicas must START equal: rank `src`'s parameters and buffers go to every rank through one flat buffer per dtype
+    (identical seeds make this a no-op in value, but nothing else guarantees it -- e.g. a checkpoint loaded on rank 0 only)."""
+    if not is_distributed():
+        return
+    tensors = [p.data for p in module.parameters()] + [b.data for b in module.buffers()]
+    by_type = {}
+    for t in tensors:
+        by_type.setdefault((t.dtype, t.device), []).append(t)
+    for group in by_type.values():
+        flat = torch.cat([t.reshape(-1) for t in group])
+        dist.broadcast(flat, src=src)
+        off = 0
+        for t in group:
+            t.copy_(flat[off:off + t.numel()].view_as(t))
+            off += t.numel()
+    for p in module.parameters():
+        torch.autograd.graph.increment_version(p)      # engines key their bf16 operand copies on the version counter
+
+
 class FlatGradAllReducer:
     """All-reduces (sum) the gradients of `params` through ONE flat fp32 buffer (allocated once)."""
 
@@ -104,6 +125,8 @@ class DataParallelTrainStep:
         self.model, self.criterion, self.optimizer, self.grad_clip = model, criterion, optimizer, grad_clip
         self.criterion.reduce_fn = all_reduce_sums
         self.reducer = FlatGradAllReducer(list(model.parameters()))
+        broadcast_parameters(model)
+
 
     def step(self, loss):
         """loss already computed with the global-mean criterion; backward, all-reduce, clip, (maybe) step."""

@@ -10,9 +10,13 @@ Surface kept (cited uses in the reference):
   _stft(wav2d, window=) / _magphase(complx)                        sampler.py:226-228
   .to() / .cpu() / deepcopy / pickle (spawned sampler child)       runner.py:65,70,232
 
-The compute path is HIP only: calling it with CPU tensors raises (no CPU fallback); construction and
-pickling work without a device, plans are created lazily on first use so a spawned child can pick its GPU
-first (sampler.py:145-153).
+The compute path is HIP only.  The reference calls the module while it (and its input) still live on the host --
+the zero-argument dimension probe (run_downstream.py:163,182-183; model.py:145-146), the `.cpu()` copy used for
+logging (runner.py:51,65) and the sampler child's default device (sampler.py:145-151).  Those calls are served by
+staging the host tensor on the current HIP device, running the SAME kernels there and handing the results back on the
+caller's device: still the HIP path, not a CPU implementation.  Without a gfx950 device every call raises (SEError).
+Construction and pickling work without a device; plans are created lazily on first use so a spawned child can pick
+its GPU first (sampler.py:145-153).
 """
 import torch
 import torch.nn as nn
@@ -91,10 +95,17 @@ class OnlinePreprocessor(nn.Module):
         assert type(feat_list) is list
         return feat_list
 
-    def _require_device(self, t):
-        if not t.is_cuda:
-            raise _lib.SEError('OnlinePreprocessor runs on MI355X only: move the module and its inputs to the GPU '
-                               '(.to("cuda")); the HIP path has no CPU fallback')
+    @staticmethod
+    def _stage(t):
+        """(tensor on a HIP device, device the caller expects results on).  A host tensor is copied to the current HIP
+        device (the reference's CPU-resident call sites, see the module docstring); there is no CPU implementation, so
+        without a device this raises."""
+        if t.is_cuda:
+            return t, t.device
+        if not torch.cuda.is_available():
+            raise _lib.SEError('OnlinePreprocessor runs on MI355X only: no HIP device is visible and the path has no CPU '
+                               'fallback (host inputs are staged on the current HIP device, they are never computed on the host)')
+        return t.to(torch.device('cuda', torch.cuda.current_device())), t.device
 
     def _stft_channel(self, wavs, channel, need):
         """One se_stft_f32 launch for `channel`; `need` is a set of {'linear','phase','complx','mel'}."""
@@ -139,7 +150,7 @@ class OnlinePreprocessor(nn.Module):
             max_channel_id = max(int(a['channel']) if 'channel' in a else 0 for a in feat_list)
             wavs = self._pseudo_wavs[0].view(1, 1, -1).repeat(1, max_channel_id + 1, 1)
         assert wavs.dim() >= 3
-        self._require_device(wavs)
+        wavs, home = self._stage(wavs)
         wavs = wavs.contiguous().float()
         lead = wavs.shape[:-2]
         wavs3 = wavs.reshape(-1, wavs.shape[-2], wavs.shape[-1])
@@ -165,7 +176,7 @@ class OnlinePreprocessor(nn.Module):
                 feat = self._select(raw, True, log, delta, cmvn)
             else:
                 feat = raw
-            feats.append(feat.reshape(*lead, *feat.shape[-2:]))
+            feats.append(feat.reshape(*lead, *feat.shape[-2:]).to(home))
         return feats
 
     def istft(self, linears=None, phases=None, linear_power=2, complxs=None):
@@ -178,7 +189,8 @@ class OnlinePreprocessor(nn.Module):
 
     def istft_with_sumsq(self, linears, phases, linear_power=2, lengths=None, out_len=None):
         """se_istft_f32; with `lengths` also returns the masked sum of squares (fused, for the dB normalisation)."""
-        self._require_device(linears)
+        linears, home = self._stage(linears)
+        phases = phases.to(linears.device)
         lib = _lib.load()
         lead = linears.shape[:-2]
         F, K = linears.shape[-2:]
@@ -194,15 +206,15 @@ class OnlinePreprocessor(nn.Module):
             sumsq = torch.empty(B, device=lin.device, dtype=torch.float32)
         _lib.check(lib.se_istft_f32(self._plan(lin.device), _lib.ptr(lin), _lib.ptr(ph), B, F, float(linear_power),
                                     _lib.ptr(wav), stride, _lib.ptr(lengths), _lib.ptr(sumsq), _lib.stream()), 'se_istft_f32')
-        return wav.reshape(*lead, stride), sumsq
+        return wav.reshape(*lead, stride).to(home), (None if sumsq is None else sumsq.to(home))
 
     # ---- attributes used by sampler.hist_scoring (sampler.py:226-228) -----------------------------------
     def _stft(self, wav2d, window=None):
         """(N, T) -> (N, K, F, 2) real view, the torch<=1.6 torch.stft layout S3PRL exposed."""
-        self._require_device(wav2d)
+        wav2d, home = self._stage(wav2d)
         out = self._stft_channel(wav2d.contiguous().float().unsqueeze(1), 0, {'complx'})['complx']   # (N, F, 2K)
         N, F, _ = out.shape
-        return out.view(N, F, self._n_freq, 2).permute(0, 2, 1, 3).contiguous()
+        return out.view(N, F, self._n_freq, 2).permute(0, 2, 1, 3).contiguous().to(home)
 
     @staticmethod
     def _magphase(complx, power=2.0):

@@ -56,8 +56,14 @@ def test_product_path_has_no_cpu_fallback():
     from speech_enhancement_by_s3prl_amd.preprocessor import OnlinePreprocessor
     from speech_enhancement_by_s3prl_amd.heads import LinearResidual
     P = OnlinePreprocessor(feat_list=[OnlinePreprocessor.get_feat_config('linear', 0)])
-    with pytest.raises(_lib.SEError):
-        P(torch.randn(1, 1, 1600))
+    if torch.cuda.is_available():
+        # host inputs are STAGED on the HIP device and computed there (the reference's host-resident call sites); never on the host
+        assert not P(torch.randn(1, 1, 1600))[0].is_cuda
+    else:
+        with pytest.raises(_lib.SEError):
+            P(torch.randn(1, 1, 1600))
+        with pytest.raises(_lib.SEError):
+            P()                                                     # the zero-arg dimension probe needs the device too
     with pytest.raises(_lib.SEError):
         LinearResidual(120, 201)(features=torch.randn(1, 10, 120), linears=torch.rand(1, 10, 201))
 

@@ -52,6 +52,13 @@ def _worker(rank, world, port, q):
     sums = sdist.all_reduce_sums(torch.stack([s.detach().double(), n.double()]))
     loss_global = (sums[0] / sums[1]).item()
     (s / sums[1].float()).backward()                  # local gradient already scaled by 1 / GLOBAL count
+    # replicas that start different are made equal (rank 0 wins), buffers included
+    m = torch.nn.BatchNorm1d(3)
+    with torch.no_grad():
+        m.weight.fill_(float(rank + 1))
+        m.running_mean.fill_(float(10 * rank + 5))
+    sdist.broadcast_parameters(m)
+    assert torch.equal(m.weight, torch.ones(3)) and torch.equal(m.running_mean, torch.full((3,), 5.0))
     red = sdist.FlatGradAllReducer([W, b])
     flat = red.reduce().clone()
     gn = torch.nn.utils.clip_grad_norm_([W, b], 1.0)
@@ -91,3 +98,20 @@ def test_dp2_matches_single_process():
                        _loss_terms(feats[i], lin[i], tar[i], lens[i], W.detach(), b.detach())[1]).item()
                       for i in ([0, 2], [1, 3]))
     assert abs(naive - loss.item()) > 1e-4
+
+
+def test_bench_launcher_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` outside torchrun must start 2 ranks (fresh child `python -m torch.distributed.run`, nothing
+    exec'd after a GPU call) and report the world size the ranks OBSERVED; the rank plumbing is exercised over gloo."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--launch-check', '--backend', 'gloo'],
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines                                           # ONE JSON line on stdout
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 2 and rec['world_observed'] == 2

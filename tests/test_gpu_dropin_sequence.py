@@ -1,0 +1,215 @@
+"""GPU: the reference's OWN call sequence, restated, through the S3PRL module paths of `s3prl_compat/`.
+
+What the reference's unchanged files do with the plugin surface, in order (no reference source is copied: the calls are restated):
+  run_downstream.get_preprocessor      run_downstream.py:123-164   ctor on the HOST, zero-argument call -> dims (80, 120, 201)
+  run_downstream.get_upstream_model    run_downstream.py:167-192   fresh host module called with feat_list=[input, target]; TRANSFORMER(options, inp_dim)
+  model.SpecHead / model.Mockingjay    model.py:94-126,129-161     reference-side wrappers around TransformerSpecPredictionHead (restated below)
+  Runner.__init__                      runner.py:59-74             deepcopy(preprocessor).cpu() for logging, .to(device) for the rest
+  logging(mode='audio')                runner.py:45-52             host waveform through the host copy -> log-linear spectrogram on the host
+  Runner._build_pseudo_wavs/_pseudo_clean   runner.py:273-277,287-300   upstream on waveforms (B, T, C) + SpecHead + _decode_wav
+  Runner.evaluate body                 runner.py:556-575
+Every call that the reference makes on host-resident modules / tensors must be served by the HIP kernels (staged on the current
+device) and come back on the host; the results must equal the all-on-device calls bit for bit."""
+import copy
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+COMPAT = os.path.join(ROOT, 'speech-enhancement-by-s3prl_amd', 's3prl_compat')
+
+
+@pytest.fixture(scope='module')
+def s3prl():
+    """The five S3PRL module paths the reference imports (run_downstream.py:18-20, runner.py:22-23, model.py:3-5, sampler.py:23-24)."""
+    sys.path.insert(0, COMPAT)
+    try:
+        from utility.preprocessor import OnlinePreprocessor
+        from transformer.nn_transformer import TRANSFORMER
+        from transformer.model import TransformerConfig, TransformerSpecPredictionHead
+        from downstream.model import dummy_upstream
+        from downstream.solver import get_optimizer
+    finally:
+        sys.path.remove(COMPAT)
+    return dict(OnlinePreprocessor=OnlinePreprocessor, TRANSFORMER=TRANSFORMER, TransformerConfig=TransformerConfig,
+                TransformerSpecPredictionHead=TransformerSpecPredictionHead, dummy_upstream=dummy_upstream, get_optimizer=get_optimizer)
+
+
+@pytest.fixture(scope='module')
+def ckpt_file(tmp_path_factory):
+    from speech_enhancement_by_s3prl_amd import pipeline
+    cfg = pipeline.make_config(layers=2, hidden=256, heads=4, intermediate=512)
+    cfg['online']['roots'] = ['unused']                      # extra keys of the real yaml must be tolerated (run_downstream.py:159)
+    ckpt = pipeline.synthetic_checkpoint(cfg, seed=3)
+    path = str(tmp_path_factory.mktemp('ckpt') / 'states-1000.ckpt')
+    torch.save(ckpt, path)
+    return path
+
+
+class RefSpecHead(torch.nn.Module):
+    """What the reference's unchanged model.SpecHead does with the plugin classes (model.py:94-126), restated."""
+
+    def __init__(self, s3prl, output_size, ckpt, eps=1e-6):
+        super().__init__()
+        ckpt = torch.load(ckpt, map_location='cpu')
+        head = s3prl['TransformerSpecPredictionHead'](s3prl['TransformerConfig'](ckpt['Settings']['Config']), output_size)
+        head.load_state_dict(ckpt['SpecHead'])
+        assert head.output.out_features == output_size
+        self.spechead, self.eps = head, eps
+        target = ckpt['Settings']['Config']['online']['target']
+        self.log = False if 'log' not in target else target['log']
+        self.act = torch.nn.ReLU()
+
+    def forward(self, features, **kwargs):
+        predicted, _ = self.spechead(features)
+        if self.log:
+            predicted, log_predicted = predicted.exp(), predicted
+        else:
+            log_predicted = (predicted + self.eps).log()
+        return self.act(predicted), {'log_predicted': log_predicted}
+
+
+def test_reference_call_sequence(gpu, s3prl, ckpt_file):
+    from speech_enhancement_by_s3prl_amd import decode, heads, synth
+    from speech_enhancement_by_s3prl_amd.objective import L1
+    P = s3prl['OnlinePreprocessor']
+
+    # ---- run_downstream.get_preprocessor (run_downstream.py:123-164): everything on the host ----------------------------------
+    pretrain_config = torch.load(ckpt_file, map_location='cpu')['Settings']['Config']
+    upstream_feat = pretrain_config['online']['input']
+    downstream_feat = {'feat_type': 'mel', 'log': True, 'delta': 2, 'cmvn': False}          # config/pseudo_noise.yaml preprocessor.baseline
+    channel_inp, channel_tar = 0, 1
+    upstream_feat['channel'] = channel_inp
+    downstream_feat['channel'] = channel_inp
+    feat_list = [upstream_feat, downstream_feat, P.get_feat_config('linear', channel_inp), P.get_feat_config('phase', channel_inp),
+                 P.get_feat_config('linear', channel_tar), P.get_feat_config('phase', channel_tar)]
+    preprocessor = P(**pretrain_config['online'], feat_list=feat_list)
+    setattr(preprocessor, 'channel_inp', channel_inp)
+    setattr(preprocessor, 'channel_tar', channel_tar)
+    assert not preprocessor._window.is_cuda
+    outs = preprocessor()                                                                   # run_downstream.py:163: zero-arg, host module
+    assert len(outs) == 6 and all(not t.is_cuda for t in outs)
+    up_feat, down_feat, inp_linear, inp_phase, tar_linear, tar_phase = outs
+    assert (up_feat.size(-1), down_feat.size(-1), tar_linear.size(-1)) == (80, 120, 201)
+    assert up_feat.shape[:2] == (1, 16000 // 160 + 1)
+    assert all(torch.isfinite(t).all() for t in outs)
+
+    # ---- run_downstream.get_upstream_model (run_downstream.py:167-192) ---------------------------------------------------------
+    options = {'ckpt_file': ckpt_file, 'load_pretrain': 'True', 'no_grad': 'False', 'dropout': 'default', 'spec_aug': 'False',
+               'spec_aug_prev': 'True', 'weighted_sum': 'False', 'select_layer': -1, 'permute_input': 'False'}
+    pre2 = P(**pretrain_config['online'])
+    inp_feat, tar_feat = pre2(feat_list=[pretrain_config['online']['input'], pretrain_config['online']['target']])   # :182-183
+    assert (inp_feat.size(-1), tar_feat.size(-1)) == (80, 201) and not inp_feat.is_cuda
+    upstream_model = s3prl['TRANSFORMER'](options, inp_feat.size(-1))
+    setattr(upstream_model, 'SpecHead', RefSpecHead(s3prl, tar_feat.size(-1), ckpt_file))
+    assert hasattr(upstream_model, 'forward') and hasattr(upstream_model, 'out_dim')
+    baseline = s3prl['dummy_upstream'](down_feat.size(-1))
+    assert baseline.out_dim == 120
+
+    # ---- Runner.__init__ (runner.py:59-74) -------------------------------------------------------------------------------------
+    log_pre = copy.deepcopy(preprocessor).cpu()                                             # runner.py:65
+    preprocessor = preprocessor.to(gpu)                                                     # runner.py:70
+    upstream_model = upstream_model.to(gpu)
+    downstream = heads.LinearResidual(input_size=down_feat.size(-1), output_size=tar_linear.size(-1), cmvn=True).to(gpu)
+    criterion = L1().to(gpu)
+    upstream_model.eval()
+
+    # the zero-arg probe equals the same call with the module on the device (same kernels, same pseudo wav)
+    dev_outs = preprocessor()
+    assert all(t.is_cuda for t in dev_outs)
+    for a, b in zip(outs, dev_outs):
+        assert torch.equal(a, b.cpu())
+
+    # ---- logging(mode='audio') (runner.py:45-52): host data through the host copy ----------------------------------------------
+    lengths, wavs = synth.synth_batch(3, 16000, first=5, ragged=True)
+    data = wavs[0, 0, :]
+    data = data / data.abs().max().item()
+    linear = log_pre(data.reshape(1, 1, -1), [P.get_feat_config(feat_type='linear', log=True)])[0]
+    assert not linear.is_cuda and linear.shape == (1, 101, 201) and torch.isfinite(linear).all()
+    dev_linear = preprocessor(data.reshape(1, 1, -1).to(gpu), [P.get_feat_config(feat_type='linear', log=True)])[0]
+    assert torch.equal(linear, dev_linear.cpu())
+    # sampler.hist_scoring's attribute use on a host copy (sampler.py:145-151,226-228)
+    spec = log_pre._stft(wavs[:, 0, :], window=log_pre._window)
+    mag, ph = log_pre._magphase(spec)
+    assert not spec.is_cuda and spec.shape == (3, 201, 101, 2) and mag.shape == (3, 201, 101)
+    # and the inverse on host tensors
+    host_wav = log_pre.istft(inp_linear, inp_phase)
+    assert not host_wav.is_cuda and host_wav.shape == (1, 16000)
+
+    # ---- _build_pseudo_wavs / _pseudo_clean (runner.py:273-277,287-300): upstream on WAVEFORMS (B, T, C) -----------------------
+    wavs, lengths = wavs.to(device=gpu), lengths.to(device=gpu)
+    feats_up, feats_down, linear_inp, phase_inp, linear_tar, phase_tar = preprocessor(wavs)
+    with torch.no_grad():
+        features = upstream_model(wavs.transpose(1, 2))
+        linear_predicted, _ = upstream_model.SpecHead(features)
+    pseudo_clean = decode.decode_wav(preprocessor, linear_predicted, phase_inp, lengths)    # target_level = -25 (runner.py:266)
+    assert pseudo_clean.shape == (3, int(lengths.max())) and torch.isfinite(pseudo_clean).all()
+    # the waveform entry extracts exactly the pre-training input feature
+    with torch.no_grad():
+        assert torch.equal(features, upstream_model(feats_up))
+    # the reference-side SpecHead wrapper (torch exp / ReLU around the plugin head) against the fused product head
+    fused = heads.SpecHead(tar_feat.size(-1), torch.load(ckpt_file, map_location='cpu')).to(gpu)
+    with torch.no_grad():
+        p2, r2 = fused(features)
+        _, r1 = upstream_model.SpecHead(features)
+    assert torch.allclose(linear_predicted, p2, rtol=2e-6, atol=1e-7)
+    assert torch.equal(r1['log_predicted'], r2['log_predicted'])
+
+    # ---- Runner.evaluate body (runner.py:556-575) with --downstream LinearResidual --from_rawfeature -----------------------------
+    with torch.no_grad():
+        wav_tar = wavs[:, preprocessor.channel_tar, :]
+        predicted, model_results = downstream(features=feats_down, linears=linear_inp)
+        wav_predicted = decode.decode_wav(preprocessor, predicted, phase_inp, lengths, wav_tar)
+        stft_lengths = lengths // preprocessor._win_args['hop_length'] + 1
+        stft_length_masks = decode.get_length_masks(stft_lengths)
+    assert wav_predicted.shape == (3, int(lengths.max())) and torch.isfinite(wav_predicted).all()
+    assert stft_length_masks.shape == (3, int(stft_lengths.max()))
+    # and with the upstream as the enhancer under the L1 criterion (model_results carries log_predicted)
+    with torch.no_grad():
+        predicted, model_results = upstream_model.SpecHead(upstream_model(feats_up))
+        loss, _ = criterion(predicted=predicted, linear_inp=linear_inp, linear_tar=linear_tar, stft_length_masks=stft_length_masks,
+                            stft_lengths=stft_lengths, lengths=lengths, **model_results)
+    assert torch.isfinite(loss)
+
+
+def test_mockingjay_constructor_sequence(gpu, s3prl, ckpt_file):
+    """model.Mockingjay.__init__ (model.py:129-161), restated: host preprocessor probed with feat_list, TRANSFORMER loads its own
+    weights from the path, the spec head is loaded from ckpt['SpecHead']; then one training step of it."""
+    P = s3prl['OnlinePreprocessor']
+    ckpt = torch.load(ckpt_file, map_location='cpu')
+    pretrain_config = ckpt['Settings']['Config']
+    pre = P(**pretrain_config['online'])
+    inp_feat, tar_feat = pre(feat_list=[pretrain_config['online']['input'], pretrain_config['online']['target']])
+    options = {'ckpt_file': ckpt_file, 'load_pretrain': 'True', 'no_grad': 'False', 'dropout': 'default', 'spec_aug': 'False',
+               'spec_aug_prev': 'True', 'weighted_sum': 'False', 'select_layer': -1, 'permute_input': 'False'}
+    mockingjay = s3prl['TRANSFORMER'](options, inp_feat.size(-1))
+    for k, v in ckpt['Transformer'].items():
+        assert torch.equal(mockingjay.model.state_dict()[k], v)                # "TRANSFORMER will automatically load parameters"
+    head = s3prl['TransformerSpecPredictionHead'](s3prl['TransformerConfig'](pretrain_config), tar_feat.size(-1))
+    head.load_state_dict(ckpt['SpecHead'])
+    assert head.output.out_features == tar_feat.size(-1)
+    # the product's own class does the same from the path
+    from speech_enhancement_by_s3prl_amd.heads import Mockingjay
+    m = Mockingjay(ckpt_file).to(gpu).train()
+    assert m.mockingjay.inp_dim == inp_feat.size(-1) and m.spechead.output.out_features == tar_feat.size(-1)
+    opt = s3prl['get_optimizer'](params=list(m.named_parameters()), lr=4e-5, warmup_proportion=0.07, training_steps=1000)   # runner.py:110-113
+    from speech_enhancement_by_s3prl_amd import synth
+    from speech_enhancement_by_s3prl_amd.objective import L1
+    lengths, wavs = synth.synth_batch(2, 16000, first=9)
+    wavs, lengths = wavs.to(gpu), lengths.to(gpu)
+    pre = pre.to(gpu)
+    pre.feat_list = [dict(pretrain_config['online']['input'], channel=0), P.get_feat_config('linear', 1)]
+    feats, linear_tar = pre(wavs)
+    predicted, res = m(features=feats, linears=None)
+    loss, _ = L1()(log_predicted=res['log_predicted'], linear_tar=linear_tar, stft_lengths=lengths // 160 + 1)
+    loss.backward()
+    gn = torch.nn.utils.clip_grad_norm_(list(m.parameters()), 1.0)
+    assert torch.isfinite(gn)
+    before = m.spechead.output.weight.detach().clone()
+    opt.step()
+    opt.zero_grad()
+    assert not torch.equal(before, m.spechead.output.weight)
