@@ -194,6 +194,8 @@ extern "C" int se_gemm2_launch(const uint16_t* A, int lda, const uint16_t* W, in
                                int M, int N, int K, int act, uint16_t* out_bf16, float* out_f32, int ldc, int vec_ok, int variant, void* stream);
 extern "C" int se_gemm3_launch(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias, const float* residual_f32,
                                int M, int N, int K, int act, uint16_t* out_bf16, float* out_f32, int ldc, int vec_ok, void* stream);
+extern "C" int se_gemm6_launch(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias, const float* residual_f32,
+                               int M, int N, int K, int act, uint16_t* out_bf16, float* out_f32, int ldc, int vec_ok, void* stream);
 extern "C" int se_gemm5_launch(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias, const float* residual_f32,
                                int M, int N, int K, int act, uint16_t* out_bf16, float* out_f32, int ldc, int vec_ok, void* stream);
 static int g_gemm_variant = -1;   // -1: read SE_AMD_GEMM once (1 = register-staged 128x128 kernel of this file, 2 = gemm2.hip lockstep, 3 = gemm2.hip ping-pong, 4 = gemm2.hip 128x128 x 2 workgroups / CU, 5 = gemm3.hip 256x256 [default])
@@ -216,11 +218,19 @@ extern "C" int se_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, int l
     // serving-size batches (M = B*T <= 8 utterances of 10 s): a 1 001-row GEMM makes 4 row tiles of 256 -- 36 workgroups for the QKV
     // projection on 256 CUs.  128 x 128 tiles at two workgroups per CU fill the chip 4x better: 0.85 vs 1.85 ms per utterance pass
     // at B = 1, 1.81 vs 2.61 ms at B = 8 (tools/small_batch_sweep.sh); from B = 16 on the large tiles win again.
-    if (M <= 8192) return se_gemm2_launch(A, lda, W, ldw, bias, residual_f32, M, N, K, act, out_bf16, out_f32, ldc, vec_ok, 4, stream);
-    static int use5 = -1;
+    static int use5 = -1, use6 = 0, small_m = 8192;
     if (use5 < 0) {
       const char* e5 = getenv("SE_AMD_GEMM5");       // developer switch: 1 = the one-wave-per-SIMD 256 x 256 kernel (gemm5.hip) for the bf16-output wide GEMMs
       use5 = e5 ? atoi(e5) : 0;
+      const char* e6 = getenv("SE_AMD_GEMM6");       // 1 = the 64-deep eight-phase 256 x 256 kernel (gemm6.hip) for the wide GEMMs
+      use6 = e6 ? atoi(e6) : 1;                      // default since round 2: +5-8 % over gemm3 on every wide shape (profiles/README.md)
+      const char* sm = getenv("SE_AMD_GEMM_SMALL_M");   // row count up to which the 128 x 128 kernel is used (kernel benchmarks set 0)
+      small_m = sm ? atoi(sm) : 8192;
+    }
+    if (M <= small_m) return se_gemm2_launch(A, lda, W, ldw, bias, residual_f32, M, N, K, act, out_bf16, out_f32, ldc, vec_ok, 4, stream);
+    if (use6 && N >= 1536) {
+      const int rc6 = se_gemm6_launch(A, lda, W, ldw, bias, residual_f32, M, N, K, act, out_bf16, out_f32, ldc, vec_ok, stream);
+      if (rc6 <= 0) return rc6;
     }
     if (use5 && N >= 1536) {
       const int rc5 = se_gemm5_launch(A, lda, W, ldw, bias, residual_f32, M, N, K, act, out_bf16, out_f32, ldc, vec_ok, stream);

@@ -1,0 +1,585 @@
+// gemm6.hip -- 256 x 256 bf16 GEMM, 64-deep K-tiles, eight phases per pair of K-tiles (C = epilogue(A . W^T + bias); contract: gemm.hip)
+//
+// Why another main loop: gemm3's 32-deep K-steps stage rows of 64 B, so every LDS-DMA wave instruction touches 16 cache lines and uses
+// half of each (the "fragment-shaped load" of the CDNA guide: twice the TA work per byte), and the whole family sat at ~0.9 PFLOP/s at
+// 4096^3 / 8192^3 where the guide's 256^2 eight-phase structure reaches 1.3-1.5 on the same chip.  This kernel is that structure:
+//
+//   tile     : 256 x 256 x 64; 512 threads = 8 waves as 2 (M) x 4 (N), wave tile 128 x 64 = 8 x 4 v_mfma_f32_16x16x32_bf16 tiles
+//   LDS      : 2 K-tile buffers x 4 half-tile slots x 16 KiB = 128 KiB.  A slot holds 128 rows x 128 B (one full cache line of k per
+//              row), 16-B chunk index XOR-ed with (row >> 1) & 7 (on the DMA source address and on the ds_read_b128 side): conflict-free.
+//              Half-tiles are cut so that each one is read in exactly ONE phase (B_0 in two):
+//                A_h = rows {wr * 128 + h * 64 + [0, 64)} of both wave rows, B_h = columns {wc * 64 + h * 32 + [0, 32)} of all four wave columns
+//   phases   : a wave's 128 x 64 output is four 64 x 32 quadrants; per K-tile the quadrants run (0,0) (0,1) (1,1) (1,0), so consecutive
+//              phases share one operand in registers: reads per phase = B_0 + A_0 | B_1 | A_1 | B_0 (12 | 4 | 8 | 4 ds_read_b128), 16 MFMAs each.
+//              phase = { fragment reads ; one half-tile of LDS-DMA (2 per wave) ; [counted vmcnt] | barrier | 16 MFMAs | barrier };
+//              waves 4-7 run one barrier behind waves 0-3, so on every SIMD one wave multiplies while its partner reads / issues DMA.
+//   staging  : a continuous stream of half-tiles, one per phase, each into the slot whose last reader finished one phase earlier:
+//                phase 1 of tile t : B_0 (t+1)     phase 2 : A_0 (t+2)     phase 3 : B_1 (t+2)     phase 4 : A_1 (t+2)
+//              The only wait of a K-tile is vmcnt(6) in phase 4 (three half-tiles stay in flight): in-order retirement then guarantees
+//              every half-tile of tile t+1; it is read from the next phase on (one barrier later for the lagging wave group).
+//   epilogue : gemm3's (swapped operands, C^T accumulators, 16-B stores, bias / GELU / fp32 residual fused, compile-time specialised)
+#include <stdlib.h>
+#include "common.h"
+#include "bf16.h"
+#include "prof.h"
+
+namespace se {
+
+constexpr int k6BM = 256, k6BN = 256, k6BK = 64, k6Threads = 512;
+constexpr int k6Slot = 128 * 128, k6Buf = 4 * k6Slot, k6Lds = 2 * k6Buf;       // 16 KiB, 64 KiB, 128 KiB
+constexpr int k6A0 = 0, k6A1 = k6Slot, k6B0 = 2 * k6Slot, k6B1 = 3 * k6Slot;  // slot offsets inside a buffer
+
+typedef __attribute__((address_space(3))) void* lds6_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb6_ptr_t;
+
+__device__ __forceinline__ float act6(float v, int act) {
+  if (act == SE_ACT_GELU) return gelu_erf(v);
+  if (act == SE_ACT_RELU) return fmaxf(v, 0.f);
+  return v;
+}
+
+// Epilogue of a 256 x 256 tile held as C^T accumulators acc[8][4] (col = lane & 15 -> output row, row = 4 (lane >> 4) + r -> 4 consecutive
+// columns); expects m0, n0, wr, wc, mrow, ncol, ncol8, godd, bb[4] (bias, zero when the accumulators already carry it) in scope.
+#define SE6_EPILOGUE_BODY(PRED)                                                                                            \
+  _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                                          \
+    const int gm = m0 + wr * 128 + i * 16 + mrow;                                                                          \
+    const bool mok = gm < M;                                                                                               \
+    const size_t orow = (size_t)min(gm, M - 1) * ldc;                                                                      \
+    float4 rr[4];                                                                                                          \
+    if constexpr (RES) {                                                                                                   \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                      \
+        const int gn = min(n0 + wc * 64 + j * 16 + ncol, N - 4);                                                           \
+        rr[j] = *reinterpret_cast<const float4*>(residual + orow + gn);                                                    \
+      }                                                                                                                    \
+    }                                                                                                                      \
+    uint2 pk[4];                                                                                                           \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                        \
+      const int gn = n0 + wc * 64 + j * 16 + ncol;                                                                         \
+      float v0 = acc[i][j][0] + bb[j].x, v1 = acc[i][j][1] + bb[j].y, v2 = acc[i][j][2] + bb[j].z, v3 = acc[i][j][3] + bb[j].w; \
+      if constexpr (ACT == SE_ACT_GELU) {                                                                                  \
+        const f32x2 ga = gelu_erf2((f32x2){v0, v1}), gb = gelu_erf2((f32x2){v2, v3});                                      \
+        v0 = ga.x; v1 = ga.y; v2 = gb.x; v3 = gb.y;                                                                        \
+      } else {                                                                                                             \
+        v0 = act6(v0, ACT); v1 = act6(v1, ACT); v2 = act6(v2, ACT); v3 = act6(v3, ACT);                                    \
+      }                                                                                                                    \
+      if constexpr (RES) { v0 += rr[j].x; v1 += rr[j].y; v2 += rr[j].z; v3 += rr[j].w; }                                   \
+      pk[j] = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));                                                        \
+      if (!(PRED) || (mok && gn < N)) {                                                                                    \
+        if constexpr (OF32) *reinterpret_cast<float4*>(out_f32 + orow + gn) = make_float4(v0, v1, v2, v3);                 \
+        if constexpr (OBF) {                                                                                               \
+          if (PRED) *reinterpret_cast<uint2*>(out_bf16 + orow + gn) = pk[j];                                               \
+        }                                                                                                                  \
+      }                                                                                                                    \
+    }                                                                                                                      \
+    if constexpr (OBF) {                                                                                                   \
+      if (!(PRED)) {                                                                                                       \
+        /* 16-B stores: lanes l, l ^ 16 trade 4-column pieces of two neighbouring MFMA tiles, so each lane owns 8 consecutive   \
+           bf16 columns and a wave instruction writes 16 rows x 64 contiguous bytes (gemm3.hip) */                          \
+        _Pragma("unroll") for (int p2 = 0; p2 < 2; ++p2) {                                                                 \
+          const uint2 keep = godd ? pk[2 * p2 + 1] : pk[2 * p2];                                                           \
+          const uint2 send = godd ? pk[2 * p2] : pk[2 * p2 + 1];                                                           \
+          uint2 recv;                                                                                                      \
+          recv.x = __shfl_xor(send.x, 16);                                                                                 \
+          recv.y = __shfl_xor(send.y, 16);                                                                                 \
+          const uint4 o16 = godd ? make_uint4(recv.x, recv.y, keep.x, keep.y) : make_uint4(keep.x, keep.y, recv.x, recv.y); \
+          *reinterpret_cast<uint4*>(out_bf16 + orow + n0 + wc * 64 + 16 * (2 * p2 + (godd ? 1 : 0)) + ncol8) = o16;        \
+        }                                                                                                                  \
+      }                                                                                                                    \
+    }                                                                                                                      \
+  }
+
+// ACT: compile-time activation; EF bit 0: fp32 residual, bit 1: bf16 output, bit 2: fp32 output (N % 4 == 0, 16-B rows)
+template <int ACT, int EF>
+__global__ __launch_bounds__(k6Threads) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm6_bf16_kernel(
+    const uint16_t* __restrict__ A, int lda, const uint16_t* __restrict__ W, int ldw, const float* __restrict__ bias,
+    const float* __restrict__ residual, int M, int N, int K, uint16_t* __restrict__ out_bf16, float* __restrict__ out_f32,
+    int ldc, int tiles_m, int tiles_n, int group_m) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+
+  // XCD-aware bijective remap + grouped order (as gemm3): each XCD walks a contiguous id range, GROUP_M tile rows swept n-major
+  const int nwg = tiles_m * tiles_n;
+  int id;
+  {
+    const int orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+  }
+  int tm, tn;
+  {
+    const int per_group = group_m * tiles_n, grp = id / per_group, first_m = grp * group_m;
+    const int gsz = min(tiles_m - first_m, group_m), in = id - grp * per_group;
+    tn = in / gsz;
+    tm = first_m + (in - tn * gsz);
+  }
+  const int m0 = tm * k6BM, n0 = tn * k6BN;
+
+  // ---- DMA sources.  A half-tile slot = 16 pieces of 1 KiB = 8 slot rows x 128 B each; wave w issues pieces w and w + 8.
+  //      lane -> slot row rho = 8 q + (lane >> 3); LDS position lane & 7 holds logical chunk (lane & 7) ^ ((rho >> 1) & 7).
+  //      A_h slot row rho <-> tile row (rho >> 6) * 128 + h * 64 + (rho & 63);  B_h slot row rho <-> tile column (rho >> 5) * 64 + h * 32 + (rho & 31)
+  const uint16_t* a_src[2][2];      // [h][piece]
+  const uint16_t* b_src[2][2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int rho = 8 * (wave + 8 * p) + (lane >> 3);
+    const int lc = ((lane & 7) ^ ((rho >> 1) & 7)) << 3;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int trow = (rho >> 6) * 128 + h * 64 + (rho & 63);
+      const int tcol = (rho >> 5) * 64 + h * 32 + (rho & 31);
+      a_src[h][p] = A + (size_t)min(m0 + trow, M - 1) * lda + lc;
+      b_src[h][p] = W + (size_t)min(n0 + tcol, N - 1) * ldw + lc;
+    }
+  }
+#define SE6_DMA(src, slot_off, buf, kt)                                                                                    \
+  do {                                                                                                                     \
+    _Pragma("unroll") for (int p_ = 0; p_ < 2; ++p_)                                                                       \
+      __builtin_amdgcn_global_load_lds((glb6_ptr_t)(src[p_] + (size_t)(kt) * k6BK),                                        \
+                                       (lds6_ptr_t)(smem + (buf) * k6Buf + (slot_off) + (wave + 8 * p_) * 1024), 16, 0, 0); \
+  } while (0)
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // ---- fragment addresses: lane -> row (lane & 15) of a 16-row MFMA tile, logical chunk 4 s + (lane >> 4) of k-slice s.
+  //      Tiles 16 rows apart share the swizzle term ((rho >> 1) & 7 only sees rho mod 16): tile i sits at base + 2 KiB * i.
+  const int frow = lane & 15, fch = lane >> 4;
+  int a_ad[2], b_ad[2];
+  {
+    const int ra = wr * 64 + frow, rb = wc * 32 + frow;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      a_ad[s] = ra * 128 + (((4 * s + fch) ^ ((ra >> 1) & 7)) << 4);
+      b_ad[s] = rb * 128 + (((4 * s + fch) ^ ((rb >> 1) & 7)) << 4);
+    }
+  }
+  bf16x8 af[4][2], bfr[2][2];          // [tile][k-slice]
+#define SE6_READ_A(buf, h)                                                                                                 \
+  _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                        \
+    af[i_][s_] = *reinterpret_cast<const bf16x8*>(smem + (buf) * k6Buf + ((h) ? k6A1 : k6A0) + a_ad[s_] + i_ * 2048);
+#define SE6_READ_B(buf, h)                                                                                                 \
+  _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                        \
+    bfr[j_][s_] = *reinterpret_cast<const bf16x8*>(smem + (buf) * k6Buf + ((h) ? k6B1 : k6B0) + b_ad[s_] + j_ * 2048);
+#define SE6_MMA(mq, nq)                                                                                                    \
+  _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                        \
+    _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                                                       \
+      acc[(mq) * 4 + i_][(nq) * 2 + j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j_][s_], af[i_][s_], acc[(mq) * 4 + i_][(nq) * 2 + j_], 0, 0, 0);
+  // reads retired BEFORE the barrier: the slot read in this phase is refilled by DMA one phase later (WAR), and the MFMAs start right
+  // after the barrier
+#define SE6_SYNC_A()                                                                                                       \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                       \
+  __builtin_amdgcn_sched_barrier(0);                                                                                       \
+  __builtin_amdgcn_s_barrier();                                                                                            \
+  __builtin_amdgcn_sched_barrier(0);                                                                                       \
+  __builtin_amdgcn_s_setprio(1);
+#define SE6_SYNC_B()                                                                                                       \
+  __builtin_amdgcn_s_setprio(0);                                                                                           \
+  __builtin_amdgcn_sched_barrier(0);                                                                                       \
+  __builtin_amdgcn_s_barrier();                                                                                            \
+  __builtin_amdgcn_sched_barrier(0);
+
+  const int nk = K / k6BK;                  // >= 2 (launcher)
+  // ---- prologue: all of tile 0, then tile 1's A_0, B_1, A_1 (what phases 2-4 of "tile -1" would have issued)
+  SE6_DMA(a_src[0], k6A0, 0, 0);
+  SE6_DMA(b_src[0], k6B0, 0, 0);
+  SE6_DMA(b_src[1], k6B1, 0, 0);
+  SE6_DMA(a_src[1], k6A1, 0, 0);
+  SE6_DMA(a_src[0], k6A0, 1, 1);
+  SE6_DMA(b_src[1], k6B1, 1, 1);
+  SE6_DMA(a_src[1], k6A1, 1, 1);
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");        // tile 0 landed (this wave's pieces)
+  __builtin_amdgcn_s_barrier();
+  const bool late = wave >= 4;
+  if (late) __builtin_amdgcn_s_barrier();                  // stagger: waves 4-7 run one barrier behind
+
+  // one K-tile from buffer BUF (compile-time); T = its index; STEADY: tile T + 2 exists (no run-time branches in the body)
+#define SE6_TILE(BUF, T, STEADY)                                                                                           \
+  {                                                                                                                        \
+    /* phase 1: quadrant (0,0) */                                                                                          \
+    SE6_READ_B(BUF, 0)                                                                                                     \
+    SE6_READ_A(BUF, 0)                                                                                                     \
+    if (STEADY || (T) + 1 < nk) SE6_DMA(b_src[0], k6B0, (BUF) ^ 1, (T) + 1);                                               \
+    SE6_SYNC_A()                                                                                                           \
+    SE6_MMA(0, 0)                                                                                                          \
+    SE6_SYNC_B()                                                                                                           \
+    /* phase 2: quadrant (0,1); A_0 of this buffer was read one phase ago -> refill it with tile T + 2 */                  \
+    SE6_READ_B(BUF, 1)                                                                                                     \
+    if (STEADY || (T) + 2 < nk) SE6_DMA(a_src[0], k6A0, BUF, (T) + 2);                                                     \
+    SE6_SYNC_A()                                                                                                           \
+    SE6_MMA(0, 1)                                                                                                          \
+    SE6_SYNC_B()                                                                                                           \
+    /* phase 3: quadrant (1,1) */                                                                                          \
+    SE6_READ_A(BUF, 1)                                                                                                     \
+    if (STEADY || (T) + 2 < nk) SE6_DMA(b_src[1], k6B1, BUF, (T) + 2);                                                     \
+    SE6_SYNC_A()                                                                                                           \
+    SE6_MMA(1, 1)                                                                                                          \
+    SE6_SYNC_B()                                                                                                           \
+    /* phase 4: quadrant (1,0); the K-tile's only DMA wait: everything up to B_0 (T + 1) has landed, 3 half-tiles of T + 2 stay in flight */ \
+    SE6_READ_B(BUF, 0)                                                                                                     \
+    if (STEADY || (T) + 2 < nk) {                                                                                          \
+      SE6_DMA(a_src[1], k6A1, BUF, (T) + 2);                                                                               \
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                                                     \
+    } else {                                                                                                               \
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                     \
+    }                                                                                                                      \
+    SE6_SYNC_A()                                                                                                           \
+    SE6_MMA(1, 0)                                                                                                          \
+    SE6_SYNC_B()                                                                                                           \
+  }
+  int t = 0;
+  for (; t + 3 < nk; t += 2) {              // steady state: tiles t and t + 1 both have a tile two ahead
+    SE6_TILE(0, t, true)
+    SE6_TILE(1, t + 1, true)
+  }
+  for (; t + 1 < nk; t += 2) {
+    SE6_TILE(0, t, false)
+    SE6_TILE(1, t + 1, false)
+  }
+  if (t < nk) SE6_TILE(0, t, false)
+#undef SE6_TILE
+  if (!late) __builtin_amdgcn_s_barrier();                 // re-align the two groups (barrier counts must match)
+
+  // ---- epilogue: C^T accumulators: col = lane & 15 -> output row, row = 4 (lane >> 4) + r -> 4 consecutive columns
+  constexpr bool RES = EF & 1, OBF = EF & 2, OF32 = EF & 4;
+  const int mrow = lane & 15, ncol = 4 * (lane >> 4);
+  float4 bb[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int gn = min(n0 + wc * 64 + j * 16 + ncol, N - 4);
+    bb[j] = bias ? *reinterpret_cast<const float4*>(bias + gn) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  // wave-uniform; the interior path's bf16 stores are 16 B wide
+  const bool interior = (m0 + k6BM <= M) && (n0 + k6BN <= N) && (!OBF || ((ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(out_bf16) & 15) == 0));
+  const bool godd = (lane >> 4) & 1;                      // odd lane group: keeps tile 2p+1, gets the left 4 columns from its partner
+  const int ncol8 = 4 * ((lane >> 4) & ~1);               // first of this lane's 8 consecutive columns inside the 16-column tile
+  if (interior) {
+    SE6_EPILOGUE_BODY(false)
+  } else {
+    SE6_EPILOGUE_BODY(true)
+  }
+#undef SE6_DMA
+#undef SE6_READ_A
+#undef SE6_READ_B
+#undef SE6_MMA
+#undef SE6_SYNC_A
+#undef SE6_SYNC_B
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// Persistent form (bf16 output, no residual: the QKV and FFN1 projections).  The K-sweep of the one-tile-per-workgroup kernel above
+// (tools/bench_kernels.py ksweep) shows a marginal rate of 1.4-1.5 PFLOP/s and a FIXED cost of 40 (QKV) / 72 (FFN1) us per launch at
+// K = 768: pipeline fill, epilogue and the 147 / 197 MB output write of every round, none of it overlapped with MFMAs because a
+// 128-KiB-LDS workgroup owns its CU.  Here gridDim.x workgroups (one per CU) walk lists of output tiles and
+//   * the half-tile stream runs CONTINUOUSLY across tile boundaries (the last two K-tiles of a tile already stage the first two of the next),
+//   * the epilogue's 16 store instructions per wave stay in flight under the next tile's first K-tiles (counted vmcnt includes them),
+//   * workgroups whose list is one tile shorter start `late_start` x ~4 us late, so the write bursts of the two populations fall into each
+//     other's main loops instead of all CUs writing at once.
+// Tile order: XCD x (= blockIdx & 7) owns a contiguous id range (gemm6's grouped order); its workgroups take ids start + slot + 32 i.
+// ------------------------------------------------------------------------------------------------------------------
+template <int ACT>
+__global__ __launch_bounds__(k6Threads) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm6p_bf16_kernel(
+    const uint16_t* __restrict__ A, int lda, const uint16_t* __restrict__ W, int ldw, const float* __restrict__ bias, int M, int N, int K,
+    uint16_t* __restrict__ out_bf16, int ldc, int tiles_m, int tiles_n, int group_m, int late_start) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr bool RES = false, OBF = true, OF32 = false;
+  const float* residual = nullptr;          // named by the shared epilogue body inside discarded branches only
+  float* out_f32 = nullptr;
+  (void)residual; (void)out_f32;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+
+  // ---- this workgroup's tile list
+  const int nwg = tiles_m * tiles_n;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, wpx = gridDim.x >> 3;
+  const int q = nwg >> 3, rem = nwg & 7;
+  const int range_start = (xcd < rem) ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q;
+  const int range_count = q + (xcd < rem ? 1 : 0);
+  const int my_tiles = (range_count > slot) ? (range_count - slot + wpx - 1) / wpx : 0;
+  if (my_tiles == 0) return;
+  if (late_start > 0 && my_tiles < (range_count + wpx - 1) / wpx)
+    for (int i = 0; i < late_start; ++i) __builtin_amdgcn_s_sleep(127);
+
+  // ---- DMA sources as 32-bit byte offsets from A / W (the launcher checks they fit): 8 registers per tile, rewritten in place when the
+  //      stream moves on to the next tile.  Mapping as in gemm6_bf16_kernel.
+  uint32_t a_of[2][2], b_of[2][2];
+#define SE6P_SET_SRC(id_, m0_, n0_)                                                                                        \
+  do {                                                                                                                     \
+    const int per_group_ = group_m * tiles_n, grp_ = (id_) / per_group_, first_m_ = grp_ * group_m;                        \
+    const int gsz_ = min(tiles_m - first_m_, group_m), in_ = (id_) - grp_ * per_group_;                                    \
+    const int tn_ = in_ / gsz_, tm_ = first_m_ + (in_ - tn_ * gsz_);                                                       \
+    m0_ = tm_ * k6BM;                                                                                                      \
+    n0_ = tn_ * k6BN;                                                                                                      \
+    int ln_ = lane;                                                                                                        \
+    asm volatile("" : "+v"(ln_));     /* opaque: keeps the lane-derived terms from being hoisted out of the tile loop and spilled */ \
+    _Pragma("unroll") for (int p_ = 0; p_ < 2; ++p_) {                                                                     \
+      const int rho_ = 8 * (wave + 8 * p_) + (ln_ >> 3);                                                                   \
+      const int lc_ = ((ln_ & 7) ^ ((rho_ >> 1) & 7)) << 3;                                                                \
+      _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_) {                                                                   \
+        const int trow_ = (rho_ >> 6) * 128 + h_ * 64 + (rho_ & 63);                                                       \
+        const int tcol_ = (rho_ >> 5) * 64 + h_ * 32 + (rho_ & 31);                                                        \
+        a_of[h_][p_] = (uint32_t)(min(m0_ + trow_, M - 1) * lda + lc_) * 2u;                                               \
+        b_of[h_][p_] = (uint32_t)(min(n0_ + tcol_, N - 1) * ldw + lc_) * 2u;                                               \
+      }                                                                                                                    \
+    }                                                                                                                      \
+  } while (0)
+  // one half-tile: `of` = a_of[h] / b_of[h], kt = K-tile index inside the tile the offsets belong to.  Hand-written issue: SGPR base +
+  // 32-bit per-lane offset (the builtin widened every offset to a 64-bit VGPR pair and spilled them); M0 = LDS destination, saved and
+  // restored around the instruction.  These loads are invisible to the compiler's vmcnt bookkeeping: every wait on them is counted
+  // by hand below (compiler-issued loads / stores in between only make ITS waits more conservative).
+  const uint32_t lds_wave = (uint32_t)(size_t)(lds6_ptr_t)smem + wave * 1024;
+#define SE6P_DMA(base, of, slot_off, buf, kt)                                                                              \
+  do {                                                                                                                     \
+    const char* sb_ = reinterpret_cast<const char*>(base) + (size_t)(kt) * (k6BK * 2);                                     \
+    _Pragma("unroll") for (int p_ = 0; p_ < 2; ++p_) {                                                                     \
+      uint32_t keep_;                                                                                                      \
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"      \
+                   : "=&s"(keep_)                                                                                          \
+                   : "v"(of[p_]), "s"(sb_), "s"(lds_wave + (uint32_t)((buf) * k6Buf + (slot_off) + p_ * 8192))             \
+                   : "memory");                                                                                            \
+    }                                                                                                                      \
+  } while (0)
+
+  const int frow = lane & 15, fch = lane >> 4;
+  int a_ad[2], b_ad[2];
+  {
+    const int ra = wr * 64 + frow, rb = wc * 32 + frow;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      a_ad[s] = ra * 128 + (((4 * s + fch) ^ ((ra >> 1) & 7)) << 4);
+      b_ad[s] = rb * 128 + (((4 * s + fch) ^ ((rb >> 1) & 7)) << 4);
+    }
+  }
+  bf16x8 af[4][2], bfr[2][2];
+#define SE6_READ_A(buf, h)                                                                                                 \
+  _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                        \
+    af[i_][s_] = *reinterpret_cast<const bf16x8*>(smem + (buf) * k6Buf + ((h) ? k6A1 : k6A0) + a_ad[s_] + i_ * 2048);
+#define SE6_READ_B(buf, h)                                                                                                 \
+  _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                        \
+    bfr[j_][s_] = *reinterpret_cast<const bf16x8*>(smem + (buf) * k6Buf + ((h) ? k6B1 : k6B0) + b_ad[s_] + j_ * 2048);
+#define SE6_MMA(mq, nq)                                                                                                    \
+  _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                        \
+    _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                                                       \
+      acc[(mq) * 4 + i_][(nq) * 2 + j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j_][s_], af[i_][s_], acc[(mq) * 4 + i_][(nq) * 2 + j_], 0, 0, 0);
+#define SE6_SYNC_A()                                                                                                       \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                       \
+  __builtin_amdgcn_sched_barrier(0);                                                                                       \
+  __builtin_amdgcn_s_barrier();                                                                                            \
+  __builtin_amdgcn_sched_barrier(0);                                                                                       \
+  __builtin_amdgcn_s_setprio(1);
+#define SE6_SYNC_B()                                                                                                       \
+  __builtin_amdgcn_s_setprio(0);                                                                                           \
+  __builtin_amdgcn_sched_barrier(0);                                                                                       \
+  __builtin_amdgcn_s_barrier();                                                                                            \
+  __builtin_amdgcn_sched_barrier(0);
+  // one K-tile from buffer BUF; I1..I4: what each phase issues (statements), WAIT: the phase-4 wait (statement)
+#define SE6P_TILE(BUF, I1, I2, I3, I4, WAIT)                                                                               \
+  {                                                                                                                        \
+    SE6_READ_B(BUF, 0)                                                                                                     \
+    SE6_READ_A(BUF, 0)                                                                                                     \
+    I1;                                                                                                                    \
+    SE6_SYNC_A()                                                                                                           \
+    SE6_MMA(0, 0)                                                                                                          \
+    SE6_SYNC_B()                                                                                                           \
+    SE6_READ_B(BUF, 1)                                                                                                     \
+    I2;                                                                                                                    \
+    SE6_SYNC_A()                                                                                                           \
+    SE6_MMA(0, 1)                                                                                                          \
+    SE6_SYNC_B()                                                                                                           \
+    SE6_READ_A(BUF, 1)                                                                                                     \
+    I3;                                                                                                                    \
+    SE6_SYNC_A()                                                                                                           \
+    SE6_MMA(1, 1)                                                                                                          \
+    SE6_SYNC_B()                                                                                                           \
+    SE6_READ_B(BUF, 0)                                                                                                     \
+    I4;                                                                                                                    \
+    WAIT;                                                                                                                  \
+    SE6_SYNC_A()                                                                                                           \
+    SE6_MMA(1, 0)                                                                                                          \
+    SE6_SYNC_B()                                                                                                           \
+  }
+#define SE6P_NOP ((void)0)
+#define SE6P_W6 asm volatile("s_waitcnt vmcnt(6)" ::: "memory")
+#define SE6P_W0 asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+
+  // bias of every output column, staged once in the LDS beside the ring: the tile loop then contains no compiler-visible VMEM load at all
+  // (a per-tile global load made hipcc put s_waitcnt vmcnt(0) at the loop header, which drained the stores this kernel leaves in flight)
+  float* bias_lds = reinterpret_cast<float*>(smem + k6Lds);
+  for (int c = tid; c < N; c += k6Threads) bias_lds[c] = bias ? bias[c] : 0.f;
+  __syncthreads();
+
+  const int nk = K / k6BK;                  // even, >= 4 (launcher)
+  int tile_id = range_start + slot;
+  int m0, n0;
+  SE6P_SET_SRC(tile_id, m0, n0);
+  // ---- prologue: K-tile 0 and all of K-tile 1 of the first tile (later tiles arrive with the same state: their K-tile 0 landed,
+  //      A_0 / B_1 / A_1 of K-tile 1 issued by the previous tile's last phases, B_0 of K-tile 1 issued just before the epilogue)
+  SE6P_DMA(A, a_of[0], k6A0, 0, 0);
+  SE6P_DMA(W, b_of[0], k6B0, 0, 0);
+  SE6P_DMA(W, b_of[1], k6B1, 0, 0);
+  SE6P_DMA(A, a_of[1], k6A1, 0, 0);
+  SE6P_DMA(A, a_of[0], k6A0, 1, 1);
+  SE6P_DMA(W, b_of[1], k6B1, 1, 1);
+  SE6P_DMA(A, a_of[1], k6A1, 1, 1);
+  SE6P_DMA(W, b_of[0], k6B0, 1, 1);
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  const bool late = wave >= 4;
+  if (late) __builtin_amdgcn_s_barrier();                  // stagger: waves 4-7 run one barrier behind
+
+  bool stores_pending = false;              // the previous tile's epilogue left exactly 16 store instructions per wave in flight
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int ti = 0; ti < my_tiles; ++ti) {
+    const bool has_next = ti + 1 < my_tiles;
+
+    // K-tile 0: B_0 (1) is already on its way.  Its wait must not cover the previous tile's stores (issued after B_0 (1)): 6 + 16.
+    SE6P_TILE(0, SE6P_NOP, SE6P_DMA(A, a_of[0], k6A0, 0, 2), SE6P_DMA(W, b_of[1], k6B1, 0, 2), SE6P_DMA(A, a_of[1], k6A1, 0, 2),
+              if (stores_pending) asm volatile("s_waitcnt vmcnt(22)" ::: "memory"); else SE6P_W6)
+    SE6P_TILE(1, SE6P_DMA(W, b_of[0], k6B0, 0, 2), SE6P_DMA(A, a_of[0], k6A0, 1, 3), SE6P_DMA(W, b_of[1], k6B1, 1, 3), SE6P_DMA(A, a_of[1], k6A1, 1, 3), SE6P_W6)
+    for (int t = 2; t + 2 < nk; t += 2) {
+      SE6P_TILE(0, SE6P_DMA(W, b_of[0], k6B0, 1, t + 1), SE6P_DMA(A, a_of[0], k6A0, 0, t + 2), SE6P_DMA(W, b_of[1], k6B1, 0, t + 2),
+                SE6P_DMA(A, a_of[1], k6A1, 0, t + 2), SE6P_W6)
+      SE6P_TILE(1, SE6P_DMA(W, b_of[0], k6B0, 0, t + 2), SE6P_DMA(A, a_of[0], k6A0, 1, t + 3), SE6P_DMA(W, b_of[1], k6B1, 1, t + 3),
+                SE6P_DMA(A, a_of[1], k6A1, 1, t + 3), SE6P_W6)
+    }
+    // last two K-tiles: after B_0 (nk - 1) every remaining issue belongs to the NEXT output tile (K-tiles 0 and 1), so the eight source
+    // offsets are rewritten in place; the epilogue keeps this tile's m0 / n0
+    const int m0c = m0, n0c = n0;
+    // (the last tile of the list "prefetches" itself: same instruction stream, no second copy of the 128-accumulator code path for the
+    //  register allocator to trip over; those bytes are never read and are drained before the kernel ends)
+    const int next_id = has_next ? tile_id + wpx : tile_id;
+    SE6P_TILE(0, SE6P_DMA(W, b_of[0], k6B0, 1, nk - 1); tile_id = next_id; SE6P_SET_SRC(tile_id, m0, n0),
+              SE6P_DMA(A, a_of[0], k6A0, 0, 0), SE6P_DMA(W, b_of[1], k6B1, 0, 0), SE6P_DMA(A, a_of[1], k6A1, 0, 0), SE6P_W6)
+    SE6P_TILE(1, SE6P_DMA(W, b_of[0], k6B0, 0, 0), SE6P_DMA(A, a_of[0], k6A0, 1, 1), SE6P_DMA(W, b_of[1], k6B1, 1, 1), SE6P_DMA(A, a_of[1], k6A1, 1, 1), SE6P_W6)
+    if (!late) __builtin_amdgcn_s_barrier();               // re-align the wave groups: both run the epilogue together
+    SE6P_DMA(W, b_of[0], k6B0, 1, 1);                      // B_0 of the next tile's K-tile 1 (its slot was last read in the phase just finished)
+
+    // ---- epilogue of tile (m0c, n0c); no LDS, no barrier
+    {
+      const int m0 = m0c, n0 = n0c;
+      int le_ = lane;
+      asm volatile("" : "+v"(le_));      // opaque (see SE6P_SET_SRC): the epilogue's lane constants are rebuilt per tile, not kept live
+      const int mrow = le_ & 15, ncol = 4 * (le_ >> 4);
+      const bool godd = (le_ >> 4) & 1;
+      const int ncol8 = 4 * ((le_ >> 4) & ~1);
+      float4 bb[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bb[j] = *reinterpret_cast<const float4*>(bias_lds + n0 + wc * 64 + j * 16 + ncol);
+      const bool interior = m0 + k6BM <= M;                // N is a multiple of 256 and the bf16 rows are 16-B aligned (launcher)
+      if (interior) {
+        SE6_EPILOGUE_BODY(false)
+        stores_pending = true;
+      } else {
+        SE6_EPILOGUE_BODY(true)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // exec-masked stores: their count is not fixed, so drain before the counted waits resume
+        stores_pending = false;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (late && has_next) __builtin_amdgcn_s_barrier();    // stagger again
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // no LDS-DMA may outlive the workgroup's LDS allocation
+#undef SE6P_TILE
+#undef SE6P_SET_SRC
+#undef SE6P_DMA
+#undef SE6_READ_A
+#undef SE6_READ_B
+#undef SE6_MMA
+#undef SE6_SYNC_A
+#undef SE6_SYNC_B
+}
+
+}  // namespace se
+
+namespace {
+struct G6Args {
+  const uint16_t* A; int lda; const uint16_t* W; int ldw; const float* bias; const float* residual; int M, N, K;
+  uint16_t* out_bf16; float* out_f32; int ldc; hipStream_t st;
+};
+
+template <int ACT, int EF>
+int launch6(const G6Args& g) {
+  const int tiles_m = (g.M + se::k6BM - 1) / se::k6BM, tiles_n = (g.N + se::k6BN - 1) / se::k6BN;
+  static int group_m = 0;
+  static bool attr_set = false;
+  if (!attr_set) {
+    const char* gm = getenv("SE_AMD_GEMM_GROUPM");
+    group_m = gm ? atoi(gm) : 4;
+    if (group_m < 1) group_m = 1;
+    SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::gemm6_bf16_kernel<ACT, EF>), hipFuncAttributeMaxDynamicSharedMemorySize, se::k6Lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((se::gemm6_bf16_kernel<ACT, EF>), dim3(tiles_m * tiles_n), dim3(se::k6Threads), se::k6Lds, g.st, g.A, g.lda, g.W, g.ldw,
+                     g.bias, g.residual, g.M, g.N, g.K, g.out_bf16, g.out_f32, g.ldc, tiles_m, tiles_n, group_m);
+  SE_LAUNCH_CHECK();
+  return SE_OK;
+}
+}  // namespace
+
+namespace {
+template <int ACT>
+int launch6p(const G6Args& g) {
+  const int tiles_m = (g.M + se::k6BM - 1) / se::k6BM, tiles_n = g.N / se::k6BN;
+  static int group_m = 0, n_cu = 0, late_start = 0;
+  static bool attr_set = false;
+  if (!attr_set) {
+    const char* gm = getenv("SE_AMD_GEMM_GROUPM");
+    group_m = gm ? atoi(gm) : 4;
+    if (group_m < 1) group_m = 1;
+    const char* ls = getenv("SE_AMD_GEMM6P_LATE");
+    late_start = ls ? atoi(ls) : 2;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    SE_HIP(hipGetDevice(&dev));
+    SE_HIP(hipGetDeviceProperties(&prop, dev));
+    n_cu = prop.multiProcessorCount & ~7;          // one workgroup per CU, a multiple of the 8 XCDs
+    if (n_cu < 8) n_cu = 8;
+    SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::gemm6p_bf16_kernel<ACT>), hipFuncAttributeMaxDynamicSharedMemorySize, se::k6Lds + 32768));
+    attr_set = true;
+  }
+  const int grid = std::min(n_cu, (tiles_m * tiles_n + 7) & ~7);
+  hipLaunchKernelGGL((se::gemm6p_bf16_kernel<ACT>), dim3(grid), dim3(se::k6Threads), se::k6Lds + g.N * 4, g.st, g.A, g.lda, g.W, g.ldw, g.bias, g.M, g.N, g.K,
+                     g.out_bf16, g.ldc, tiles_m, tiles_n, group_m, late_start);
+  SE_LAUNCH_CHECK();
+  return SE_OK;
+}
+}  // namespace
+
+// returns 1 if this kernel does not handle the call (caller falls back to gemm3 / gemm2), 0 on success, < 0 on error
+extern "C" int se_gemm6_launch(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias, const float* residual_f32,
+                               int M, int N, int K, int act, uint16_t* out_bf16, float* out_f32, int ldc, int vec_ok, void* stream) {
+  const bool vec = vec_ok && (N % 4 == 0) && (ldc % 4 == 0);
+  const bool one_out = (out_bf16 != nullptr) != (out_f32 != nullptr);
+  if (!vec || !one_out || K % se::k6BK != 0 || K < 2 * se::k6BK || (act != SE_ACT_IDENTITY && act != SE_ACT_GELU)) return 1;
+  G6Args g{A, lda, W, ldw, bias, residual_f32, M, N, K, out_bf16, out_f32, ldc, se::as_stream(stream)};
+  const bool gelu = act == SE_ACT_GELU, res = residual_f32 != nullptr, obf = out_bf16 != nullptr;
+  se::ProfScope prof(se::kProfGemm, 2.0 * M * (double)N * K, g.st);
+  static int persistent = -1;
+  if (persistent < 0) {
+    const char* e = getenv("SE_AMD_GEMM6P");          // 0: one workgroup per tile for every shape
+    persistent = e ? atoi(e) : 1;
+  }
+  // persistent form: bf16 output without residual, several tiles per CU, whole column tiles, an even number of K-tiles, 32-bit source offsets
+  if (persistent && obf && !res && N % se::k6BN == 0 && N <= 8192 && (K / se::k6BK) % 2 == 0 && K >= 4 * se::k6BK && (ldc % 8) == 0 &&
+      ((uintptr_t)out_bf16 % 16) == 0 && (size_t)M * lda < (1u << 31) && (size_t)N * ldw < (1u << 31) &&
+      (size_t)((M + se::k6BM - 1) / se::k6BM) * (N / se::k6BN) > 256)
+    return gelu ? launch6p<SE_ACT_GELU>(g) : launch6p<SE_ACT_IDENTITY>(g);
+  if (!gelu && !res && obf) return launch6<SE_ACT_IDENTITY, 2>(g);
+  if (gelu && !res && obf) return launch6<SE_ACT_GELU, 2>(g);
+  if (!gelu && res && !obf) return launch6<SE_ACT_IDENTITY, 4 | 1>(g);
+  if (!gelu && !res && !obf) return launch6<SE_ACT_IDENTITY, 4>(g);
+  if (gelu && !res && !obf) return launch6<SE_ACT_GELU, 4>(g);
+  return 1;
+}

@@ -54,6 +54,49 @@ def bench_gemm():
         print(f'gemm M={M} N={N} K={K} act={act} res={res}: {ms*1e3:8.1f} us  {2.0*M*N*K/ms/1e9:8.1f} TF/s  relerr {err:.1e}', flush=True)
 
 
+def bench_gemm_square():
+    """the guide's reference shapes (cdna_hip_programming.md section 5: 256^2 8-phase template, 1320-1340 TF at 4096^3 and ~1470 at 8192^3
+    on uniform random operands) through this library's kernel, to separate main-loop quality from the K = 768 fill / epilogue share"""
+    for n in (4096, 8192):
+        A = (torch.rand(n, n, device=dev) * 2 - 1).bfloat16()
+        W = (torch.rand(n, n, device=dev) * 2 - 1).bfloat16()
+        o16 = torch.empty(n, n, device=dev, dtype=torch.bfloat16)
+
+        def run():
+            L.check(lib.se_gemm_bf16(L.ptr(A), n, L.ptr(W), n, None, None, n, n, n, 0, L.ptr(o16), None, n, L.stream()), 'gemm')
+        ms = timeit(run)
+        print(f'gemm {n}^3 uniform[-1,1): {ms*1e3:8.1f} us  {2.0*n*n*n/ms/1e9:8.1f} TF/s', flush=True)
+
+
+def bench_gemm_qkv():
+    M, N, K = 32 * 1001, 2304, 768
+    A = torch.randn(M, K, device=dev).bfloat16()
+    W = (torch.randn(N, K, device=dev) * 0.05).bfloat16()
+    bias = torch.randn(N, device=dev)
+    o16 = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+
+    def run():
+        L.check(lib.se_gemm_bf16(L.ptr(A), K, L.ptr(W), K, L.ptr(bias), None, M, N, K, 0, L.ptr(o16), None, N, L.stream()), 'gemm')
+    ms = timeit(run)
+    print(f'gemm QKV M={M} N={N} K={K} [SE_AMD_GEMM3_SCHED={os.environ.get("SE_AMD_GEMM3_SCHED")}]: {ms*1e3:8.1f} us  {2.0*M*N*K/ms/1e9:8.1f} TF/s', flush=True)
+
+
+def bench_gemm_ksweep():
+    """time(K) at the QKV / FFN1 output shapes: the intercept is the launch's fixed cost (fill + epilogue + output write per tile x rounds)"""
+    M = 32 * 1001
+    for N, act in ((2304, 0), (3072, 3)):
+        for K in (128, 256, 384, 768, 1536, 3072):
+            A = torch.randn(M, K, device=dev).bfloat16()
+            W = (torch.randn(N, K, device=dev) * 0.05).bfloat16()
+            bias = torch.randn(N, device=dev)
+            o16 = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+
+            def run():
+                L.check(lib.se_gemm_bf16(L.ptr(A), K, L.ptr(W), K, L.ptr(bias), None, M, N, K, act, L.ptr(o16), None, N, L.stream()), 'gemm')
+            ms = timeit(run)
+            print(f'ksweep N={N} act={act} K={K}: {ms*1e3:8.1f} us  {2.0*M*N*K/ms/1e9:8.1f} TF/s', flush=True)
+
+
 def bench_wgrad():
     """weight gradient dW = dY^T X: transposes + split-K forward GEMM (old) vs the TN kernel on row-major operands."""
     M = 32 * 1001
@@ -148,6 +191,12 @@ if __name__ == '__main__':
     what = sys.argv[1] if len(sys.argv) > 1 else 'all'
     if what in ('gemm', 'all'):
         bench_gemm()
+    if what in ('ksweep',):
+        bench_gemm_ksweep()
+    if what in ('square',):
+        bench_gemm_square()
+    if what in ('qkv',):
+        bench_gemm_qkv()
     if what in ('gemmln', 'all'):
         bench_gemm_ln()
     if what in ('mhsa', 'all'):
