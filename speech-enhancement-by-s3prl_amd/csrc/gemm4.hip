@@ -52,6 +52,139 @@ __device__ __forceinline__ uint32_t enc24_lo(float y, uint32_t hi16) {
   return (uint32_t)(int)fminf(fmaxf(q, -128.f), 127.f) & 0xffu;
 }
 
+// acc[i][t] <- bias (+ residual): fp32 rows, or the 24-bit (bf16 hi row-major + int8 lo tile-major) stream, or a (T, 768) table indexed row % res_mod
+template <int GELU, int RIN>
+__device__ __forceinline__ void acc_init4(f32x4 (&acc)[4][12], const float* __restrict__ bias, const float* __restrict__ residual,
+                                          const uint8_t* __restrict__ res_lo, int M, int m0, int id, int wave, int wr, int lane, int col0, int res_mod) {
+  const int mrow = lane & 15;
+  float4 bb[12];
+#pragma unroll
+  for (int t = 0; t < 12; ++t) bb[t] = bias ? *reinterpret_cast<const float4*>(bias + col0 + 16 * t) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int gm = min(m0 + wr * 64 + i * 16 + mrow, M - 1);
+    const float* rp = residual + (size_t)(res_mod > 0 ? gm % res_mod : gm) * k4N + col0;      // res_mod = T: a (T, 768) positional table as the residual
+#pragma unroll
+    for (int t = 0; t < 12; ++t) {
+      if (GELU) {
+        acc[i][t] = (f32x4){bb[t].x, bb[t].y, bb[t].z, bb[t].w};
+      } else if (RIN) {
+        const uint2 h4 = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(residual) + (size_t)gm * k4N + col0 + 16 * t);
+        const uint32_t l4 = *reinterpret_cast<const uint32_t*>(res_lo + ((((size_t)id * 8 + wave) * 4 + i) * 12 + t) * 256 + lane * 4);
+        acc[i][t] = (f32x4){dec24(h4.x & 0xffffu, (int)(int8_t)(l4 & 0xffu)) + bb[t].x, dec24(h4.x >> 16, (int)(int8_t)((l4 >> 8) & 0xffu)) + bb[t].y,
+                            dec24(h4.y & 0xffffu, (int)(int8_t)((l4 >> 16) & 0xffu)) + bb[t].z, dec24(h4.y >> 16, (int)(int8_t)(l4 >> 24)) + bb[t].w};
+      } else {
+        const float4 rr = *reinterpret_cast<const float4*>(rp + 16 * t);
+        acc[i][t] = (f32x4){rr.x + bb[t].x, rr.y + bb[t].y, rr.z + bb[t].z, rr.w + bb[t].w};
+      }
+    }
+  }
+}
+
+// (optional gelu) + LayerNorm on the accumulators (which hold A.W^T + bias + residual) + the stores.  Called with every wave past its last
+// ring access (the caller's __syncthreads): the ring is dead, its first 6 KiB take ln_w / ln_b, `red_off` + 4 KiB the row partial sums.
+template <int GELU, int ROUT>
+__device__ __forceinline__ void ln_epilogue4(f32x4 (&acc)[4][12], char* smem, int red_off, const float* __restrict__ ln_w, const float* __restrict__ ln_b,
+                                             float eps, int M, int m0, int id, int wave, int wr, int wc, int lane, float* __restrict__ out_f32,
+                                             uint16_t* __restrict__ out_bf16, uint8_t* __restrict__ out_lo) {
+  const int tid = wave * 64 + lane;
+  const int mrow = lane & 15, cq = lane >> 4;
+  const int col0 = wc * 192 + 4 * cq;
+  if (GELU) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int t = 0; t < 12; ++t) {
+        const f32x2 ga = gelu_erf2((f32x2){acc[i][t][0], acc[i][t][1]}), gb = gelu_erf2((f32x2){acc[i][t][2], acc[i][t][3]});
+        acc[i][t] = (f32x4){ga.x, ga.y, gb.x, gb.y};
+      }
+  }
+  // ---- epilogue: LayerNorm on the accumulators (which already hold A.W^T + bias + residual)
+  float* colv = reinterpret_cast<float*>(smem);             // [2][768]: ln_w, ln_b staged in the dead ring
+  for (int c = tid; c < k4N; c += k4Threads) {
+    colv[c] = ln_w[c];
+    colv[k4N + c] = ln_b[c];
+  }
+  float* red = reinterpret_cast<float*>(smem + red_off);   // [pass][wr][wc][64]
+  // pass 1: row means
+  float mean[4], rstd[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < 12; ++t) s += (acc[i][t][0] + acc[i][t][1]) + (acc[i][t][2] + acc[i][t][3]);
+    s += __shfl_xor(s, 16);
+    s += __shfl_xor(s, 32);
+    if (cq == 0) red[(wr * 4 + wc) * 64 + i * 16 + mrow] = s;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float* rp = red + wr * 256 + i * 16 + mrow;
+    mean[i] = (rp[0] + rp[64] + rp[128] + rp[192]) * (1.0f / k4N);
+  }
+  // pass 2: variance around the mean (exact two-pass, as the stand-alone LayerNorm kernel)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float q = 0.f;
+#pragma unroll
+    for (int t = 0; t < 12; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float d = acc[i][t][r] - mean[i];
+        q = fmaf(d, d, q);
+      }
+    q += __shfl_xor(q, 16);
+    q += __shfl_xor(q, 32);
+    if (cq == 0) red[512 + (wr * 4 + wc) * 64 + i * 16 + mrow] = q;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float* rp = red + 512 + wr * 256 + i * 16 + mrow;
+    rstd[i] = 1.0f / sqrtf((rp[0] + rp[64] + rp[128] + rp[192]) * (1.0f / k4N) + eps);
+  }
+  // normalise + store (stores only in this loop; the per-column vectors come from LDS)
+  const bool interior = m0 + k4BM <= M;
+  const bool godd = cq & 1;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int gm = m0 + wr * 64 + i * 16 + mrow;
+    const bool ok = interior || gm < M;
+    const size_t o = (size_t)min(gm, M - 1) * k4N + col0;
+    const size_t orow8 = (size_t)min(gm, M - 1) * k4N + wc * 192 + 4 * (cq & ~1);      // first of this lane's 8 consecutive bf16 columns
+    uint2 pk_prev = make_uint2(0u, 0u);
+#pragma unroll
+    for (int t = 0; t < 12; ++t) {
+      if ((t & 3) == 0) __builtin_amdgcn_sched_barrier(0);
+      const float4 lw = *reinterpret_cast<const float4*>(colv + col0 + 16 * t);
+      const float4 lb = *reinterpret_cast<const float4*>(colv + k4N + col0 + 16 * t);
+      const float y0 = lw.x * ((acc[i][t][0] - mean[i]) * rstd[i]) + lb.x;
+      const float y1 = lw.y * ((acc[i][t][1] - mean[i]) * rstd[i]) + lb.y;
+      const float y2 = lw.z * ((acc[i][t][2] - mean[i]) * rstd[i]) + lb.z;
+      const float y3 = lw.w * ((acc[i][t][3] - mean[i]) * rstd[i]) + lb.w;
+      if (!ROUT && ok && out_f32) *reinterpret_cast<float4*>(out_f32 + o + 16 * t) = make_float4(y0, y1, y2, y3);
+      if (out_bf16) {
+        // 16-B bf16 stores (as gemm3.hip): lanes l, l ^ 16 trade 4-column pieces of the MFMA tile pair (t - 1, t), so a lane owns 8
+        // consecutive columns and one wave instruction writes 16 rows x 64 contiguous bytes instead of 16 x 32
+        const uint2 pk = make_uint2(pack_bf16x2(y0, y1), pack_bf16x2(y2, y3));
+        if (ROUT)      // tile-major lo bytes: rows past M are written too (the buffer covers whole tiles) and never read as real rows
+          *reinterpret_cast<uint32_t*>(out_lo + ((((size_t)id * 8 + wave) * 4 + i) * 12 + t) * 256 + lane * 4) =
+              enc24_lo(y0, pk.x & 0xffffu) | (enc24_lo(y1, pk.x >> 16) << 8) | (enc24_lo(y2, pk.y & 0xffffu) << 16) | (enc24_lo(y3, pk.y >> 16) << 24);
+        if (t & 1) {
+          const uint2 keep = godd ? pk : pk_prev, send = godd ? pk_prev : pk;
+          uint2 recv;
+          recv.x = __shfl_xor(send.x, 16);
+          recv.y = __shfl_xor(send.y, 16);
+          const uint4 o16 = godd ? make_uint4(recv.x, recv.y, keep.x, keep.y) : make_uint4(keep.x, keep.y, recv.x, recv.y);
+          if (ok) *reinterpret_cast<uint4*>(out_bf16 + orow8 + 16 * (godd ? t : t - 1)) = o16;
+        }
+        pk_prev = pk;
+      }
+    }
+  }
+}
+
 // GELU: x = LayerNorm(gelu(A . W^T + bias)) without a residual (the spec head's dense -> act -> LayerNorm, model.py:100-101)
 // RIN : the residual comes as (bf16 hi row-major, int8 lo tile-major) instead of fp32;  ROUT: the output goes out as (bf16, lo) instead of (fp32, bf16)
 template <int SLOTS, int INM, int GELU, int RIN, int ROUT>
@@ -126,30 +259,7 @@ __global__ __launch_bounds__(k4Threads) __attribute__((amdgpu_waves_per_eu(2, 2)
   const int mrow = lane & 15, cq = lane >> 4;
   const int col0 = wc * 192 + 4 * cq;
   f32x4 acc[4][12];
-  {
-    float4 bb[12];
-#pragma unroll
-    for (int t = 0; t < 12; ++t) bb[t] = bias ? *reinterpret_cast<const float4*>(bias + col0 + 16 * t) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int gm = min(m0 + wr * 64 + i * 16 + mrow, M - 1);
-      const float* rp = residual + (size_t)(res_mod > 0 ? gm % res_mod : gm) * k4N + col0;      // res_mod = T: a (T, 768) positional table as the residual
-#pragma unroll
-      for (int t = 0; t < 12; ++t) {
-        if (GELU) {
-          acc[i][t] = (f32x4){bb[t].x, bb[t].y, bb[t].z, bb[t].w};
-        } else if (RIN) {
-          const uint2 h4 = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(residual) + (size_t)gm * k4N + col0 + 16 * t);
-          const uint32_t l4 = *reinterpret_cast<const uint32_t*>(res_lo + ((((size_t)id * 8 + wave) * 4 + i) * 12 + t) * 256 + lane * 4);
-          acc[i][t] = (f32x4){dec24(h4.x & 0xffffu, (int)(int8_t)(l4 & 0xffu)) + bb[t].x, dec24(h4.x >> 16, (int)(int8_t)((l4 >> 8) & 0xffu)) + bb[t].y,
-                              dec24(h4.y & 0xffffu, (int)(int8_t)((l4 >> 16) & 0xffu)) + bb[t].z, dec24(h4.y >> 16, (int)(int8_t)(l4 >> 24)) + bb[t].w};
-        } else {
-          const float4 rr = *reinterpret_cast<const float4*>(rp + 16 * t);
-          acc[i][t] = (f32x4){rr.x + bb[t].x, rr.y + bb[t].y, rr.z + bb[t].z, rr.w + bb[t].w};
-        }
-      }
-    }
-  }
+  acc_init4<GELU, RIN>(acc, bias, residual, res_lo, M, m0, id, wave, wr, lane, col0, res_mod);
 
   const int frow = lane & 15, fch = lane >> 4;
   int a_off[4], b_off[4];
@@ -247,99 +357,161 @@ __global__ __launch_bounds__(k4Threads) __attribute__((amdgpu_waves_per_eu(2, 2)
   if (!late) __builtin_amdgcn_s_barrier();                  // re-align the two groups
   __syncthreads();                                          // ring is dead: reuse it for the per-column vectors
 
-  if (GELU) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int t = 0; t < 12; ++t) {
-        const f32x2 ga = gelu_erf2((f32x2){acc[i][t][0], acc[i][t][1]}), gb = gelu_erf2((f32x2){acc[i][t][2], acc[i][t][3]});
-        acc[i][t] = (f32x4){ga.x, ga.y, gb.x, gb.y};
-      }
+  ln_epilogue4<GELU, ROUT>(acc, smem, k4RedOff, ln_w, ln_b, eps, M, m0, id, wave, wr, wc, lane, out_f32, out_bf16, out_lo);
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// gemm7: the same row-complete tile (128 x 768, 8 waves as 2 x 4, wave tile 64 x 192) on 64-deep K-tiles with gemm6's staging rules.
+// The K-sweep of the kernel above gives a marginal rate of 0.82 PFLOP/s (matrix pipe busy 36 % of the cycles, PMC) where the 256 x 256
+// eight-phase loop runs at 1.4-1.5; here
+//   pieces   : a K-tile is THREE weight pieces of 256 rows x 128 B (rows {wc * 192 + p * 64 + [0, 64)} of all four wave columns: 32 KiB, one
+//              full cache line of k per row) + ONE activation piece (128 rows x 128 B, 16 KiB); 16-B chunk index ^ ((row >> 1) & 7)
+//   ring     : 4 weight slots + 2 activation slots = 160 KiB (all of the CU's LDS; the LayerNorm scratch reuses the dead ring)
+//   phases   : (piece p, k-slice s): 4 + 4 fragment reads, 16 MFMAs (4 row tiles x the piece's 4 column tiles x 32 k) -- six phases per
+//              K-tile; a weight piece is read in two CONSECUTIVE phases and is free after them
+//   staging  : during the two phases of piece q the wave issues its four 1-KiB parts of piece q + 3 (two per phase) into the slot piece
+//              q - 1 left one phase earlier; the first phase of a K-tile also issues the next K-tile's activation piece.  One counted wait
+//              per piece (second phase): piece q + 1 complete, 8-10 DMAs (two pieces) stay in flight across the barriers
+//   sync     : {reads ; DMA issue ; [vmcnt] ; lgkmcnt(0) | barrier | 16 MFMAs | barrier}, waves 4-7 one barrier behind waves 0-3
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int k7WSlot = 256 * 128, k7ASlot = 128 * 128, k7ABase = 4 * k7WSlot, k7Lds = 4 * k7WSlot + 2 * k7ASlot;     // 32 KiB, 16 KiB, 160 KiB
+
+template <int GELU, int RIN, int ROUT>
+__global__ __launch_bounds__(k4Threads) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm7_res_ln_kernel(
+    const uint16_t* __restrict__ A, int lda, const uint16_t* __restrict__ W, int ldw, const float* __restrict__ bias,
+    const float* __restrict__ residual, const float* __restrict__ ln_w, const float* __restrict__ ln_b, float eps, int M, int K,
+    float* __restrict__ out_f32, uint16_t* __restrict__ out_bf16, int ntiles, int res_mod,
+    const uint8_t* __restrict__ res_lo, uint8_t* __restrict__ out_lo) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  int id;
+  {
+    const int orig = blockIdx.x, xcd = orig & 7, q = ntiles >> 3, r = ntiles & 7;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
   }
-  // ---- epilogue: LayerNorm on the accumulators (which already hold A.W^T + bias + residual)
-  float* colv = reinterpret_cast<float*>(smem);             // [2][768]: ln_w, ln_b staged in the dead ring
-  for (int c = tid; c < k4N; c += k4Threads) {
-    colv[c] = ln_w[c];
-    colv[k4N + c] = ln_b[c];
-  }
-  float* red = reinterpret_cast<float*>(smem + k4RedOff);   // [pass][wr][wc][64]
-  // pass 1: row means
-  float mean[4], rstd[4];
+  const int m0 = id * k4BM;
+
+  // ---- DMA sources as 32-bit byte offsets (launcher: they fit).  A 1-KiB part = 8 slot rows x 128 B: lane -> slot row 8 c + (lane >> 3),
+  //      LDS position lane & 7 holds logical chunk (lane & 7) ^ ((row >> 1) & 7).  Weight slot row rho <-> W row (rho >> 6) * 192 + p * 64 + (rho & 63);
+  //      wave w issues parts w, w + 8, w + 16, w + 24 of a weight piece and parts w, w + 8 of an activation piece.
+  uint32_t w_of[4], a_of[2];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    float s = 0.f;
-#pragma unroll
-    for (int t = 0; t < 12; ++t) s += (acc[i][t][0] + acc[i][t][1]) + (acc[i][t][2] + acc[i][t][3]);
-    s += __shfl_xor(s, 16);
-    s += __shfl_xor(s, 32);
-    if (cq == 0) red[(wr * 4 + wc) * 64 + i * 16 + mrow] = s;
+    const int rho = 8 * (wave + 8 * i) + (lane >> 3);
+    const int lc = ((lane & 7) ^ ((rho >> 1) & 7)) << 3;
+    w_of[i] = (uint32_t)(((rho >> 6) * 192 + (rho & 63)) * ldw + lc) * 2u;
+    if (i < 2) a_of[i] = (uint32_t)(min(m0 + rho, M - 1) * lda + lc) * 2u;
   }
-  __syncthreads();
+  const uint32_t lds_wave = (uint32_t)(size_t)(lds4_ptr_t)smem + wave * 1024;
+  const size_t w_pstep = (size_t)64 * ldw * 2;            // bytes between the weight rows of consecutive pieces
+#define SE7_DMA1(base_bytes, off32, lds_dst)                                                                               \
+  do {                                                                                                                     \
+    uint32_t keep_;                                                                                                        \
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"           \
+                 : "=&s"(keep_) : "v"(off32), "s"(base_bytes), "s"(lds_dst) : "memory");                                   \
+  } while (0)
+  // half `s` (parts 2 s, 2 s + 1 of this wave's four) of weight piece q = 3 t + p into ring slot q & 3
+#define SE7_DMA_W(t, p, s)                                                                                                 \
+  do {                                                                                                                     \
+    const char* sb_ = reinterpret_cast<const char*>(W) + (size_t)(p) * w_pstep + (size_t)(t) * 128;                        \
+    const uint32_t d_ = lds_wave + (uint32_t)(((3 * (t) + (p)) & 3) * k7WSlot);                                            \
+    SE7_DMA1(sb_, w_of[2 * (s)], d_ + (uint32_t)((2 * (s)) * 8192));                                                       \
+    SE7_DMA1(sb_, w_of[2 * (s) + 1], d_ + (uint32_t)((2 * (s) + 1) * 8192));                                               \
+  } while (0)
+#define SE7_DMA_A(t)                                                                                                       \
+  do {                                                                                                                     \
+    const char* sb_ = reinterpret_cast<const char*>(A) + (size_t)(t) * 128;                                                \
+    const uint32_t d_ = lds_wave + (uint32_t)(k7ABase + ((t) & 1) * k7ASlot);                                              \
+    SE7_DMA1(sb_, a_of[0], d_);                                                                                            \
+    SE7_DMA1(sb_, a_of[1], d_ + 8192u);                                                                                    \
+  } while (0)
+
+  // ring prologue FIRST (the residual rows read for the accumulator initialisation then travel beside it): A (0), pieces 0, 1, 2
+  const int nk = K / 64;                    // >= 2 (launcher)
+  SE7_DMA_A(0);
+  SE7_DMA_W(0, 0, 0);
+  SE7_DMA_W(0, 0, 1);
+  SE7_DMA_W(0, 1, 0);
+  SE7_DMA_W(0, 1, 1);
+  SE7_DMA_W(0, 2, 0);
+  SE7_DMA_W(0, 2, 1);
+
+  const int cq = lane >> 4;
+  const int col0 = wc * 192 + 4 * cq;
+  f32x4 acc[4][12];
+  acc_init4<GELU, RIN>(acc, bias, residual, res_lo, M, m0, id, wave, wr, lane, col0, res_mod);
+
+  // fragment addresses: lane -> row (lane & 15) of a 16-row tile, logical chunk 4 s + (lane >> 4); tiles 16 rows apart share the swizzle term
+  const int frow = lane & 15, fch = lane >> 4;
+  int a_ad[2], b_ad[2];
+  {
+    const int ra = wr * 64 + frow, rb = wc * 64 + frow;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const float* rp = red + wr * 256 + i * 16 + mrow;
-    mean[i] = (rp[0] + rp[64] + rp[128] + rp[192]) * (1.0f / k4N);
+    for (int s2 = 0; s2 < 2; ++s2) {
+      a_ad[s2] = k7ABase + ra * 128 + (((4 * s2 + fch) ^ ((ra >> 1) & 7)) << 4);
+      b_ad[s2] = rb * 128 + (((4 * s2 + fch) ^ ((rb >> 1) & 7)) << 4);
+    }
   }
-  // pass 2: variance around the mean (exact two-pass, as the stand-alone LayerNorm kernel)
+  const bool late = wave >= 4;
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");         // A (0) and piece 0 landed (the residual loads above already drained more than that)
+  __builtin_amdgcn_s_barrier();
+  if (late) __builtin_amdgcn_s_barrier();                   // stagger: waves 4-7 one barrier behind
+
+  const int npieces = 3 * nk;
+  for (int t = 0; t < nk; ++t) {
+    const int a_sl = (t & 1) * k7ASlot;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    float q = 0.f;
+    for (int p = 0; p < 3; ++p) {
+      const int q = 3 * t + p;
+      const int w_sl = (q & 3) * k7WSlot;
 #pragma unroll
-    for (int t = 0; t < 12; ++t)
+      for (int s2 = 0; s2 < 2; ++s2) {
+        bf16x8 bfr[4], af[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float d = acc[i][t][r] - mean[i];
-        q = fmaf(d, d, q);
-      }
-    q += __shfl_xor(q, 16);
-    q += __shfl_xor(q, 32);
-    if (cq == 0) red[512 + (wr * 4 + wc) * 64 + i * 16 + mrow] = q;
-  }
-  __syncthreads();
+        for (int jj = 0; jj < 4; ++jj) bfr[jj] = *reinterpret_cast<const bf16x8*>(smem + w_sl + b_ad[s2] + jj * 2048);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const float* rp = red + 512 + wr * 256 + i * 16 + mrow;
-    rstd[i] = 1.0f / sqrtf((rp[0] + rp[64] + rp[128] + rp[192]) * (1.0f / k4N) + eps);
-  }
-  // normalise + store (stores only in this loop; the per-column vectors come from LDS)
-  const bool interior = m0 + k4BM <= M;
-  const bool godd = cq & 1;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int gm = m0 + wr * 64 + i * 16 + mrow;
-    const bool ok = interior || gm < M;
-    const size_t o = (size_t)min(gm, M - 1) * k4N + col0;
-    const size_t orow8 = (size_t)min(gm, M - 1) * k4N + wc * 192 + 4 * (cq & ~1);      // first of this lane's 8 consecutive bf16 columns
-    uint2 pk_prev = make_uint2(0u, 0u);
-#pragma unroll
-    for (int t = 0; t < 12; ++t) {
-      if ((t & 3) == 0) __builtin_amdgcn_sched_barrier(0);
-      const float4 lw = *reinterpret_cast<const float4*>(colv + col0 + 16 * t);
-      const float4 lb = *reinterpret_cast<const float4*>(colv + k4N + col0 + 16 * t);
-      const float y0 = lw.x * ((acc[i][t][0] - mean[i]) * rstd[i]) + lb.x;
-      const float y1 = lw.y * ((acc[i][t][1] - mean[i]) * rstd[i]) + lb.y;
-      const float y2 = lw.z * ((acc[i][t][2] - mean[i]) * rstd[i]) + lb.z;
-      const float y3 = lw.w * ((acc[i][t][3] - mean[i]) * rstd[i]) + lb.w;
-      if (!ROUT && ok && out_f32) *reinterpret_cast<float4*>(out_f32 + o + 16 * t) = make_float4(y0, y1, y2, y3);
-      if (out_bf16) {
-        // 16-B bf16 stores (as gemm3.hip): lanes l, l ^ 16 trade 4-column pieces of the MFMA tile pair (t - 1, t), so a lane owns 8
-        // consecutive columns and one wave instruction writes 16 rows x 64 contiguous bytes instead of 16 x 32
-        const uint2 pk = make_uint2(pack_bf16x2(y0, y1), pack_bf16x2(y2, y3));
-        if (ROUT)      // tile-major lo bytes: rows past M are written too (the buffer covers whole tiles) and never read as real rows
-          *reinterpret_cast<uint32_t*>(out_lo + ((((size_t)id * 8 + wave) * 4 + i) * 12 + t) * 256 + lane * 4) =
-              enc24_lo(y0, pk.x & 0xffffu) | (enc24_lo(y1, pk.x >> 16) << 8) | (enc24_lo(y2, pk.y & 0xffffu) << 16) | (enc24_lo(y3, pk.y >> 16) << 24);
-        if (t & 1) {
-          const uint2 keep = godd ? pk : pk_prev, send = godd ? pk_prev : pk;
-          uint2 recv;
-          recv.x = __shfl_xor(send.x, 16);
-          recv.y = __shfl_xor(send.y, 16);
-          const uint4 o16 = godd ? make_uint4(recv.x, recv.y, keep.x, keep.y) : make_uint4(keep.x, keep.y, recv.x, recv.y);
-          if (ok) *reinterpret_cast<uint4*>(out_bf16 + orow8 + 16 * (godd ? t : t - 1)) = o16;
+        for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(smem + a_sl + a_ad[s2] + i * 2048);
+        // staging (see the header): piece q + 3 -> the slot piece q - 1 left at the end of the previous phase; A (t + 1) -> the slot A (t - 1) left
+        if (p == 0 && s2 == 0 && t + 1 < nk) SE7_DMA_A(t + 1);
+        if (q + 3 < npieces) SE7_DMA_W(t + 1, p, s2);         // piece q + 3 = piece p of K-tile t + 1
+        if (s2 == 1) {
+          // piece q + 1 (and, before a new K-tile, its activation piece) complete: everything issued during pieces q - 1 and q may stay in flight
+          const int n = (q + 2 < npieces ? 4 : 0) + (q + 3 < npieces ? 4 : 0) + ((p == 0 || p == 1) && t + 1 < nk ? 2 : 0);
+          switch (n) {
+            case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+            case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+            case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+          }
         }
-        pk_prev = pk;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj)
+            acc[i][4 * p + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[jj], af[i], acc[i][4 * p + jj], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   }
+  if (!late) __builtin_amdgcn_s_barrier();                  // re-align the two groups
+  __syncthreads();                                          // ring is dead: reuse it for the per-column vectors
+  ln_epilogue4<GELU, ROUT>(acc, smem, 8192, ln_w, ln_b, eps, M, m0, id, wave, wr, wc, lane, out_f32, out_bf16, out_lo);
+#undef SE7_DMA1
+#undef SE7_DMA_W
+#undef SE7_DMA_A
 }
 
 }  // namespace se
@@ -379,6 +551,30 @@ static int gemm4_launch(const uint16_t* A, int lda, const uint16_t* W, int ldw, 
   const int ntiles = (M + se::k4BM - 1) / se::k4BM;
   hipStream_t st = se::as_stream(stream);
   se::ProfScope prof(se::kProfGemm, 2.0 * M * (double)N * K, st);
+  static int use7 = -1;
+  if (use7 < 0) {
+    const char* e7 = getenv("SE_AMD_GEMM7");           // 0: the 32-deep six-piece ring above for every call
+    use7 = e7 ? atoi(e7) : 1;
+    SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::gemm7_res_ln_kernel<1, 0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, se::k7Lds));
+    SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::gemm7_res_ln_kernel<0, 0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, se::k7Lds));
+    SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::gemm7_res_ln_kernel<0, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, se::k7Lds));
+    SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::gemm7_res_ln_kernel<0, 1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, se::k7Lds));
+    SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::gemm7_res_ln_kernel<0, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, se::k7Lds));
+  }
+  // 64-deep K-tiles (gemm7): whole K-tiles, at least two, 32-bit source offsets
+  if (use7 && K % 64 == 0 && K >= 128 && (size_t)M * lda < (1u << 31) && (size_t)se::k4N * ldw < (1u << 31)) {
+#define SE7_LAUNCH(GE, RI, RO)                                                                                                            \
+  hipLaunchKernelGGL((se::gemm7_res_ln_kernel<GE, RI, RO>), dim3(ntiles), dim3(se::k4Threads), se::k7Lds, st, A, lda, W, ldw, bias, residual_f32, \
+                     ln_w, ln_b, eps, M, K, out_f32, out_bf16, ntiles, res_mod, res_lo, out_lo)
+    if (gelu_no_residual) SE7_LAUNCH(1, 0, 0);
+    else if (rin && rout) SE7_LAUNCH(0, 1, 1);
+    else if (rin) SE7_LAUNCH(0, 1, 0);
+    else if (rout) SE7_LAUNCH(0, 0, 1);
+    else SE7_LAUNCH(0, 0, 0);
+#undef SE7_LAUNCH
+    SE_LAUNCH_CHECK();
+    return SE_OK;
+  }
   const int stg_ = (K >= 768) ? stagger : 0;       // the short K = 128 input stage has no compute phase to hide anything under
 #define SE4_LAUNCH(SL, IM, GE, RI, RO)                                                                                                    \
   hipLaunchKernelGGL((se::gemm4_res_ln_kernel<SL, IM, GE, RI, RO>), dim3(ntiles), dim3(se::k4Threads), se::k4_lds(SL), st, A, lda, W, ldw, bias, \
