@@ -247,6 +247,10 @@ int se_gemm_res_ln_bf16(const uint16_t* A, int lda, const uint16_t* W, int ldw, 
                         float* out_f32, uint16_t* out_bf16, void* stream);
 /* qkv (B*T, 3H) bf16 = [Q | K | V] per row, heads of 64 columns; ctx (B*T, H) bf16. */
 int se_mhsa_fwd_bf16(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, void* stream);
+/* The same attention on PRE-SCALED queries: the Q block of `qkv` already carries log2(e) / sqrt(64) (the encoder's inference copy of the
+   fused QKV weights folds it into the query rows before their bf16 rounding), i.e. ctx = softmax_base2(Q' K^T + pad-mask) V.  Inference
+   only; two-tile software pipeline with the running maximum carried as the MFMA C operand (csrc/mhsa.hip: mhsa_fwd2_kernel). */
+int se_mhsa_fwd_prescaled_bf16(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, void* stream);
 /* y = LN(x) * w + b over the last dim H (TF style, eps inside sqrt); x fp32 (M,H); outputs fp32 and/or bf16. */
 int se_layernorm_f32(const float* x, const float* w, const float* b, int M, int H, float eps,
                      float* out_f32, uint16_t* out_bf16, void* stream);

@@ -78,6 +78,7 @@ SIGNATURES = {
     'se_gemm_bf16': (c_int, [_P, c_int, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, _P, _P, c_int, _P]),
     'se_gemm_res_ln_bf16': (c_int, [_P, c_int, _P, c_int, _P, _P, _P, _P, c_float, c_int, c_int, c_int, _P, _P, _P]),
     'se_mhsa_fwd_bf16': (c_int, [_P, _P, c_int, c_int, c_int, _P, _P]),
+    'se_mhsa_fwd_prescaled_bf16': (c_int, [_P, _P, c_int, c_int, c_int, _P, _P]),
     'se_layernorm_f32': (c_int, [_P, _P, _P, c_int, c_int, c_float, _P, _P, _P]),
     'se_cast_f32_bf16': (c_int, [_P, c_size_t, _P, _P]),
     'se_transpose_bf16': (c_int, [_P, c_int, c_int, c_int, _P, c_int, _P]),

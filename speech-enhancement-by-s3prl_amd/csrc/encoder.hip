@@ -274,6 +274,22 @@ __global__ __launch_bounds__(256) void spec_epilogue_bwd_kernel(const float* __r
 
 }  // namespace se
 
+namespace se {
+// inference QKV copy of one layer: rows [0, H) = bf16(kQScale * W_q) from the fp32 master, rows [H, 3H) copied from the bf16 K / V rows
+__global__ __launch_bounds__(256) void qkv_inf_kernel(const float* __restrict__ q_w, const float* __restrict__ q_b, const uint16_t* __restrict__ qkv_w,
+                                                      const float* __restrict__ qkv_b, int H, uint16_t* __restrict__ w_inf, float* __restrict__ b_inf) {
+  const size_t hh = (size_t)H * H;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < 3 * hh; e += (size_t)gridDim.x * 256)
+    w_inf[e] = e < hh ? f2bf(q_w[e] * kQScale) : qkv_w[e];
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < 3 * H; e += gridDim.x * 256) b_inf[e] = e < H ? q_b[e] * kQScale : qkv_b[e];
+}
+int launch_qkv_inf(const float* q_w, const float* q_b, const uint16_t* qkv_w, const float* qkv_b, int H, uint16_t* qkv_w_inf, float* qkv_b_inf, hipStream_t st) {
+  hipLaunchKernelGGL(qkv_inf_kernel, dim3(512), dim3(256), 0, st, q_w, q_b, qkv_w, qkv_b, H, qkv_w_inf, qkv_b_inf);
+  SE_LAUNCH_CHECK();
+  return SE_OK;
+}
+}  // namespace se
+
 static inline uint16_t host_f2bf(float f) {   // round to nearest even, NaN kept quiet
   uint32_t u;
   memcpy(&u, &f, 4);
@@ -426,6 +442,19 @@ extern "C" int se_encoder_create(const se_encoder_config* cfg, const se_encoder_
       memcpy(bd + 2 * H, w->v_b[i], H * 4);
       lo.push_back(boff);
     }
+    size_t inf_w, inf_b;
+    {   // inference copy: query rows / bias scaled by log2(e) / sqrt(64) in fp32, rounded to bf16 once
+      inf_w = reserve((size_t)3 * H * H * 2);
+      uint16_t* d = reinterpret_cast<uint16_t*>(host.data() + inf_w);
+      for (size_t e = 0; e < (size_t)H * H; ++e) d[e] = host_f2bf(w->q_w[i][e] * se::kQScale);
+      for (size_t e = 0; e < (size_t)H * H; ++e) d[(size_t)H * H + e] = host_f2bf(w->k_w[i][e]);
+      for (size_t e = 0; e < (size_t)H * H; ++e) d[(size_t)2 * H * H + e] = host_f2bf(w->v_w[i][e]);
+      inf_b = reserve((size_t)3 * H * 4);
+      float* bd = reinterpret_cast<float*>(host.data() + inf_b);
+      for (int e = 0; e < H; ++e) bd[e] = w->q_b[i][e] * se::kQScale;
+      memcpy(bd + H, w->k_b[i], H * 4);
+      memcpy(bd + 2 * H, w->v_b[i], H * 4);
+    }
     lo.push_back(put_bf16(w->ao_w[i], H, H, H));
     lo.push_back(put_f32(w->ao_b[i], H));
     lo.push_back(put_f32(w->aln_w[i], H));
@@ -436,6 +465,8 @@ extern "C" int se_encoder_create(const se_encoder_config* cfg, const se_encoder_
     lo.push_back(put_f32(w->ff2_b[i], H));
     lo.push_back(put_f32(w->oln_w[i], H));
     lo.push_back(put_f32(w->oln_b[i], H));
+    lo.push_back(inf_w);
+    lo.push_back(inf_b);
     o.l.push_back(lo);
   }
   if (has_head) {
@@ -478,6 +509,7 @@ extern "C" int se_encoder_create(const se_encoder_config* cfg, const se_encoder_
     y.ff1_w = (uint16_t*)(base + lo[6]); y.ff1_b = (float*)(base + lo[7]);
     y.ff2_w = (uint16_t*)(base + lo[8]); y.ff2_b = (float*)(base + lo[9]);
     y.oln_w = (float*)(base + lo[10]); y.oln_b = (float*)(base + lo[11]);
+    y.qkv_w_inf = (uint16_t*)(base + lo[12]); y.qkv_b_inf = (float*)(base + lo[13]);
     e->layers.push_back(y);
   }
   if (has_head) {
@@ -570,8 +602,9 @@ extern "C" int se_encoder_fwd_bf16(const se_encoder* enc, const float* feats, co
   for (int i = 0; i < L; ++i) {
     const se_encoder::Layer& y = enc->layers[i];
     // B2
-    if ((rc = se_gemm_bf16(w.x_bf, H, y.qkv_w, H, y.qkv_b, nullptr, M, 3 * H, H, SE_ACT_IDENTITY, w.qkv, nullptr, 3 * H, stream))) return rc;
-    if ((rc = se_mhsa_fwd_bf16(w.qkv, lengths, B, T, enc->cfg.heads, w.ctx, stream))) return rc;
+    // (inference copy of the projection: the queries come out pre-scaled by log2(e) / sqrt(64), see mhsa.hip PRE)
+    if ((rc = se_gemm_bf16(w.x_bf, H, y.qkv_w_inf, H, y.qkv_b_inf, nullptr, M, 3 * H, H, SE_ACT_IDENTITY, w.qkv, nullptr, 3 * H, stream))) return rc;
+    if ((rc = se_mhsa_fwd_prescaled_bf16(w.qkv, lengths, B, T, enc->cfg.heads, w.ctx, stream))) return rc;
     // attention output projection + residual + LayerNorm: one fused row-complete kernel when H == 768 (ping-pong x buffers:
     // the residual is read while the new stream is written), else GEMM + LayerNorm
     if (fused) {      // in place: a workgroup reads the residual rows of its own tile before it writes them

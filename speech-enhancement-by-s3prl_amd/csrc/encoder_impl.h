@@ -27,6 +27,9 @@ int launch_layernorm_bwd(const float* x_in, const float* pe, int T, const float*
 int launch_gelu_bwd_colsum(const uint16_t* dy, const uint16_t* pre, uint16_t* dx, int rows, int cols, float* colsum, hipStream_t st);
 int launch_colsum_bf16(const uint16_t* x, int rows, int cols, int ld, float* out, hipStream_t st);
 inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+constexpr float kQScale = 0.125f * 1.44269504088896340736f;      // log2(e) / sqrt(64), folded into the inference copy of W_q, b_q
+// rebuilds a layer's inference QKV copy from device fp32 query masters + the layer's bf16 K / V rows (encoder.hip)
+int launch_qkv_inf(const float* q_w, const float* q_b, const uint16_t* qkv_w, const float* qkv_b, int H, uint16_t* qkv_w_inf, float* qkv_b_inf, hipStream_t st);
 }  // namespace se
 
 struct se_encoder {
@@ -38,6 +41,10 @@ struct se_encoder {
   float *in_b, *in_ln_w, *in_ln_b, *pe;
   struct Layer {
     uint16_t *qkv_w, *ao_w, *ff1_w, *ff2_w;
+    // inference copy of the fused QKV projection: query rows and query bias pre-multiplied by log2(e) / sqrt(64) BEFORE the bf16 rounding
+    // (se_mhsa_fwd_prescaled_bf16); the unscaled pair above stays what the training forward / backward use
+    uint16_t* qkv_w_inf;
+    float* qkv_b_inf;
     float *qkv_b, *ao_b, *aln_w, *aln_b, *ff1_b, *ff2_b, *oln_w, *oln_b;
   };
   std::vector<Layer> layers;

@@ -216,6 +216,10 @@ extern "C" int se_encoder_refresh_bf16(se_encoder* enc, const se_encoder_weights
   }
   SE_TRY(cast.flush());
   SE_TRY(copy.flush());
+  for (int i = 0; i < L; ++i) {          // the inference copies of the QKV projections (pre-scaled queries) follow their masters
+    se_encoder::Layer& y = enc->layers[i];
+    SE_TRY(se::launch_qkv_inf(w->q_w[i], w->q_b[i], y.qkv_w, y.qkv_b, H, y.qkv_w_inf, y.qkv_b_inf, st));
+  }
   return SE_OK;
 }
 

@@ -25,7 +25,13 @@ namespace se {
 
 // DROP = 1 (training): the attention probabilities are dropped (counter-based mask of dropout.h, site key `dkey`) AFTER the
 // row sum, i.e. O = (P . mask / (1 - p)) V with P normalised by the full sum -- torch's dropout(softmax(.)) V
-template <int OCC, int DROP>
+// PRE = 1 (inference): the queries arrive PRE-SCALED by log2(e) / sqrt(64) (the encoder's inference copy of the QKV weights folds it into the
+// query rows before their bf16 rounding), so K Q'^T is already the base-2 exponent, and the running reference starts at 0 instead of -inf:
+// while every row's reference is still 0 -- the normal case: it moves only when a score exceeds it by 2^kDefer, or the first tile sits
+// below 2^-64 -- the probabilities are exp2(S) with NO per-element VALU op in front of the exponential (was one v_fma each: 32 of the
+// ~190 vector instructions of a wave's key tile, in a loop whose vector issue is busy 64 % of the cycles against 36 % for the matrix pipe;
+// profiles/r02_pmc_*.json).  fp32 / bf16 keep their relative precision anywhere in |S| < 64 + kDefer.
+template <int OCC, int DROP, int PRE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void mhsa_fwd_kernel(
     const uint16_t* __restrict__ qkv, const int32_t* __restrict__ lengths, int T, int H, uint16_t* __restrict__ ctx,
     float* __restrict__ lse, uint32_t dkey, uint32_t thr16, float dscale) {
@@ -94,8 +100,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
   f32x16 o0, o1;                      // O^T d-blocks 0 / 1: col = query (lane & 31), row = d
 #pragma unroll
   for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
-  float m_run = -INFINITY, l_run = 0.f;
-  const float c = 0.125f * 1.44269504088896340736f;     // 1/sqrt(64) * log2(e)
+  float m_run = PRE ? 0.f : -INFINITY, l_run = 0.f;
+  const float c = PRE ? 1.0f : 0.125f * 1.44269504088896340736f;     // 1/sqrt(64) * log2(e), unless the queries carry it already
   constexpr float kDefer = 8.f;
   typedef float f2 __attribute__((ext_vector_type(2)));
 
@@ -151,18 +157,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
     }                                                                                                                      \
     /* deferred rescale: the reference maximum only moves when the tile maximum exceeds it by > 2^kDefer (log2 domain), */  \
     /* so P <= 2^kDefer instead of 1 (bf16 / fp32 keep their relative precision) and the O-wide multiply is rare        */  \
-    const float m_new = ((mx - m_run) * c > kDefer) ? mx : m_run;                                                          \
+    float m_new = ((mx - m_run) * c > kDefer) ? mx : m_run;                                                                \
+    if (PRE && kt == 0 && mx < -64.f) m_new = mx;        /* a first tile far below the initial reference 0 (later tiles cannot matter) */ \
     const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);                                                       \
     /* scalar fp32 ops on purpose (this file is built with -fno-slp-vectorize): v_pk_fma_f32 / v_pk_add_f32 cost more issue time than   */  \
     /* the two plain instructions they replace in this VALU-bound loop (148 -> 141 us per launch)                               */  \
     const float mc = -m_new * c;                                                                                           \
     float rs0 = 0.f, rs1 = 0.f;                                                                                            \
-    _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                                       \
-      const float a0 = __builtin_amdgcn_exp2f(fmaf(s0[r], c, mc));                                                         \
-      const float a1 = __builtin_amdgcn_exp2f(fmaf(s1[r], c, mc));                                                         \
-      rs0 += a0;                                                                                                           \
-      rs1 += a1;                                                                                                           \
-      s0[r] = a0; s1[r] = a1;                                                                                              \
+    if (PRE && __all(m_new == 0.f)) {                                                                                      \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                                     \
+        const float a0 = __builtin_amdgcn_exp2f(s0[r]);                                                                    \
+        const float a1 = __builtin_amdgcn_exp2f(s1[r]);                                                                    \
+        rs0 += a0;                                                                                                         \
+        rs1 += a1;                                                                                                         \
+        s0[r] = a0; s1[r] = a1;                                                                                            \
+      }                                                                                                                    \
+    } else {                                                                                                               \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                                     \
+        const float a0 = __builtin_amdgcn_exp2f(PRE ? s0[r] + mc : fmaf(s0[r], c, mc));                                    \
+        const float a1 = __builtin_amdgcn_exp2f(PRE ? s1[r] + mc : fmaf(s1[r], c, mc));                                    \
+        rs0 += a0;                                                                                                         \
+        rs1 += a1;                                                                                                         \
+        s0[r] = a0; s1[r] = a1;                                                                                            \
+      }                                                                                                                    \
     }                                                                                                                      \
     const f2 rs2 = {rs0, rs1};                                                                                             \
     l_run = fmaf(l_run, alpha, rs2.x + rs2.y);                                                                             \
@@ -230,6 +247,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
   }
 }
 
+
 }  // namespace se
 
 static int mhsa_fwd_launch(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, float* lse, float dropout_p,
@@ -247,12 +265,12 @@ static int mhsa_fwd_launch(const uint16_t* qkv, const int32_t* lengths, int B, i
   const se::DropoutCfg d = se::make_dropout(dropout_p, seed);
   if (d.thr16) {
     SE_REQUIRE((double)B * heads * T * ((T + 1) / 2) < 4294967296.0, "se_mhsa_fwd: dropout pair index exceeds 32 bits");
-    hipLaunchKernelGGL((se::mhsa_fwd_kernel<2, 1>), grid, dim3(256), 0, se::as_stream(stream), qkv, lengths, T, H, ctx, lse,
+    hipLaunchKernelGGL((se::mhsa_fwd_kernel<2, 1, 0>), grid, dim3(256), 0, se::as_stream(stream), qkv, lengths, T, H, ctx, lse,
                        se::dropout_key(seed, site), d.thr16, d.scale);
   } else if (occ == 2) {
-    hipLaunchKernelGGL((se::mhsa_fwd_kernel<2, 0>), grid, dim3(256), 0, se::as_stream(stream), qkv, lengths, T, H, ctx, lse, 0u, 0u, 1.f);
+    hipLaunchKernelGGL((se::mhsa_fwd_kernel<2, 0, 0>), grid, dim3(256), 0, se::as_stream(stream), qkv, lengths, T, H, ctx, lse, 0u, 0u, 1.f);
   } else {
-    hipLaunchKernelGGL((se::mhsa_fwd_kernel<3, 0>), grid, dim3(256), 0, se::as_stream(stream), qkv, lengths, T, H, ctx, lse, 0u, 0u, 1.f);
+    hipLaunchKernelGGL((se::mhsa_fwd_kernel<3, 0, 0>), grid, dim3(256), 0, se::as_stream(stream), qkv, lengths, T, H, ctx, lse, 0u, 0u, 1.f);
   }
   SE_LAUNCH_CHECK();
   return SE_OK;
@@ -260,6 +278,17 @@ static int mhsa_fwd_launch(const uint16_t* qkv, const int32_t* lengths, int B, i
 
 extern "C" int se_mhsa_fwd_bf16(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, void* stream) {
   return mhsa_fwd_launch(qkv, lengths, B, T, heads, ctx, nullptr, 0.f, 0, 0, stream);
+}
+
+extern "C" int se_mhsa_fwd_prescaled_bf16(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, void* stream) {
+  SE_REQUIRE(qkv && ctx, "se_mhsa_fwd_prescaled_bf16: null argument");
+  SE_REQUIRE(B > 0 && B <= 65535 && T > 0 && heads > 0 && heads <= 65535, "se_mhsa_fwd_prescaled_bf16: bad shape B=%d T=%d heads=%d", B, T, heads);
+  const int H = heads * se::kHD;
+  dim3 grid((T + se::kAQ - 1) / se::kAQ, heads, B);
+  se::ProfScope prof(se::kProfMhsa, 4.0 * B * (double)heads * T * (double)T * se::kHD, se::as_stream(stream));
+  hipLaunchKernelGGL((se::mhsa_fwd_kernel<3, 0, 1>), grid, dim3(256), 0, se::as_stream(stream), qkv, lengths, T, H, ctx, nullptr, 0u, 0u, 1.f);
+  SE_LAUNCH_CHECK();
+  return SE_OK;
 }
 
 extern "C" int se_mhsa_fwd_lse_bf16(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, float* lse,

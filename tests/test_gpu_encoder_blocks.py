@@ -83,6 +83,60 @@ def test_mhsa_vs_torch(gpu, B, T, heads, lens):
     assert err < 2e-2 * ref.abs().max().item(), err      # P and the output are rounded to bf16 (2^-9 relative)
 
 
+@pytest.mark.parametrize('B,T,heads,lens', [(2, 1001, 12, None), (3, 300, 4, [300, 17, 129]), (1, 64, 1, None), (2, 130, 2, [1, 65]), (8, 257, 1, [257, 200, 64, 63, 1, 128, 129, 256])])
+def test_mhsa_prescaled_vs_torch(gpu, B, T, heads, lens):
+    """the inference kernel on pre-scaled queries (two-tile pipeline, running maximum in the MFMA C operand) vs fp64 on the SAME bf16
+    operands: softmax_base2(Q' K^T) V with Q' = bf16(Q log2(e) / 8)"""
+    L = _lib()
+    lib = L.load()
+    torch.manual_seed(T + 1)
+    H = heads * 64
+    x = torch.randn(B * T, 3 * H, device=gpu) * 1.5
+    x[:, :H] *= 1.4426950408889634 / 8.0
+    qkv = x.bfloat16()
+    lengths = torch.tensor(lens if lens else [T] * B, device=gpu, dtype=torch.int32)
+    ctx = torch.empty(B * T, H, device=gpu, dtype=torch.bfloat16)
+    L.check(lib.se_mhsa_fwd_prescaled_bf16(L.ptr(qkv), L.ptr(lengths) if lens else None, B, T, heads, L.ptr(ctx), L.stream()), 'se_mhsa_fwd_prescaled_bf16')
+    # reference: undo the scale exactly in fp64 on the rounded operands (scores / 8 in nats == Q' K^T in bits)
+    q = qkv.double().reshape(B, T, 3, heads, 64)
+    Q, K, V = q[:, :, 0].transpose(1, 2), q[:, :, 1].transpose(1, 2), q[:, :, 2].transpose(1, 2)
+    S = (Q @ K.transpose(-1, -2)) * 0.6931471805599453                       # bits -> nats
+    mask = torch.arange(T, device=gpu)[None, :] >= lengths[:, None].long()
+    S = S.masked_fill(mask[:, None, None, :], float('-inf'))
+    ref = (torch.softmax(S, dim=-1) @ V).transpose(1, 2).reshape(B * T, H)
+    valid = (torch.arange(T, device=gpu)[None, :] < lengths[:, None].long()).reshape(-1) if lens else None
+    got = ctx.double()
+    err = (got - ref).abs()
+    assert torch.isfinite(got).all()
+    assert err.max().item() < 8e-3 * ref.abs().max().item(), err.max().item()      # P and the output are rounded to bf16 (2^-9 relative)
+
+
+def test_mhsa_prescaled_rising_maxima(gpu):
+    """rising row maxima across key tiles (both sides of the deferred-rescale branch, which here must also shift the S' tile computed ahead)"""
+    L = _lib()
+    lib = L.load()
+    B, T, heads = 1, 512, 2
+    torch.manual_seed(12)
+    u = torch.ones(64, device=gpu) / 8.0
+    a = torch.rand(T, device=gpu) * 8.0
+    bk = 8.0 * (torch.arange(T, device=gpu) // 64).float() + torch.rand(T, device=gpu)
+    q = a[:, None] * u[None, :] * 8.0 * (1.4426950408889634 / 8.0)
+    k = bk[:, None] * u[None, :]
+    v = torch.randn(T, 64, device=gpu)
+    one = torch.cat([q, k, v], dim=1)
+    qkv = torch.cat([one[:, 0:64], one[:, 0:64].flip(0), one[:, 64:128], one[:, 64:128], one[:, 128:], one[:, 128:]], dim=1).bfloat16()
+    ctx = torch.empty(T, 128, device=gpu, dtype=torch.bfloat16)
+    lengths = torch.tensor([T - 30], device=gpu, dtype=torch.int32)
+    L.check(lib.se_mhsa_fwd_prescaled_bf16(L.ptr(qkv), L.ptr(lengths), B, T, heads, L.ptr(ctx), L.stream()), 'se_mhsa_fwd_prescaled_bf16')
+    x = qkv.double().reshape(1, T, 3, heads, 64)
+    Q, K, V = x[:, :, 0].transpose(1, 2), x[:, :, 1].transpose(1, 2), x[:, :, 2].transpose(1, 2)
+    S = (Q @ K.transpose(-1, -2)) * 0.6931471805599453
+    S[..., T - 30:] = float('-inf')
+    ref = (torch.softmax(S, dim=-1) @ V).transpose(1, 2).reshape(T, 128)
+    err = (ctx.double() - ref).abs().max().item()
+    assert err < 2e-2 * ref.abs().max().item(), err
+
+
 def test_mhsa_rising_maxima(gpu):
     """Row maxima that climb tile after tile, by less than the deferred-rescale threshold for some query rows and by more for
     others in the same wave: exercises both sides of the (rare, data-dependent) rescale branch of the online softmax."""

@@ -171,6 +171,17 @@ def bench_mhsa():
         L.check(lib.se_mhsa_fwd_bf16(L.ptr(qkv), None, B, T, heads, L.ptr(ctx), L.stream()), 'mhsa')
     ms = timeit(run)
     print(f'mhsa B={B} T={T}: {ms*1e3:8.1f} us  {4.0*B*heads*T*T*64/ms/1e9:8.1f} TF/s', flush=True)
+    # the pre-scaled two-tile-pipeline kernel on the same scores (Q block multiplied by log2(e) / 8 before its bf16 rounding)
+    q2 = qkv.float()
+    q2[:, :768] *= 1.4426950408889634 / 8.0
+    q2 = q2.bfloat16()
+    ctx2 = torch.empty_like(ctx)
+
+    def run2():
+        L.check(lib.se_mhsa_fwd_prescaled_bf16(L.ptr(q2), None, B, T, heads, L.ptr(ctx2), L.stream()), 'mhsa2')
+    ms = timeit(run2)
+    d = (ctx2.float() - ctx.float()).abs().max().item() / ctx.float().abs().max().item()
+    print(f'mhsa prescaled B={B} T={T}: {ms*1e3:8.1f} us  {4.0*B*heads*T*T*64/ms/1e9:8.1f} TF/s   max diff vs the unscaled kernel {d:.2e}', flush=True)
 
 
 def bench_stft():
