@@ -1,9 +1,10 @@
 """GPU parity of rows B1-B4, C3, C4 and the whole evaluate()-style pass against the fp32 CPU oracle.
 
 The encoder computes its GEMMs on bf16 operands (north_star: 'bf16'); the oracle is fp32.  bf16 has 8 mantissa
-bits, so the bound here is the one SURVEY.md section 7 (hard part 6) states: relative L2 error of hidden states /
-predicted spectra <= 2e-2 and max-norm error <= 5e-2 of the output range; the 1e-4 bound applies to the fp32
-STFT -> head -> iSTFT path (tests/test_gpu_preprocessor.py, test_gpu_heads_decode.py).  PARITY UNPINNED vs the
+bits (hard part 6); the bounds below are ~2x what this build measures (gpurun_out/parity_measured.txt logs
+every value next to its bound: hidden states 0.7-3.1e-3 relative L2, log spectra 3.3-4.1e-3, spectra 1.1e-3, waveforms 4e-4), so that a
+precision regression such as a bf16 residual stream (measured: x2) fails.  The 1e-4 bound applies to the fp32 paths: STFT -> head -> iSTFT
+(tests/test_gpu_preprocessor.py, test_gpu_heads_decode.py) and the exact-fp32 encoder mode (tests/test_gpu_encoder_fp32.py).  PARITY UNPINNED vs the
 original S3PRL for these rows (restatement-defined oracle)."""
 import pytest
 import torch
@@ -15,6 +16,8 @@ from oracle import objective as oobj
 from oracle import preprocessor as opre
 
 pytestmark = pytest.mark.gpu
+
+from conftest import bounded  # noqa: E402
 
 
 def rel_l2(a, b):
@@ -43,16 +46,17 @@ def test_encoder_small_vs_oracle(gpu, small, B, T, lens):
     ocfg = oenc.Config(cfg)
     ref = oenc.encoder_forward(feats, ckpt['Transformer'], ocfg)
     assert hidden.shape == ref.shape == (B, T, 256)
-    assert rel_l2(hidden, ref) < 2e-2
-    assert (hidden.cpu() - ref).abs().max().item() < 5e-2 * ref.abs().max().item()
+    bounded(f'encoder_small[{B},{T}] hidden rel-L2', rel_l2(hidden, ref), 6e-3)
+    bounded(f'encoder_small[{B},{T}] hidden max-norm', (hidden.cpu() - ref).abs().max().item() / ref.abs().max().item(), 2e-2)
     with torch.no_grad():                          # inference path (with gradients enabled the head takes its training path)
         pred, res = up.SpecHead(hidden)
     rpred, rres = oheads.spec_head(ref, ckpt['SpecHead'], ocfg, log=True)
-    assert rel_l2(res['log_predicted'], rres['log_predicted']) < 3e-2
-    assert rel_l2(pred, rpred) < 3e-2
+    bounded(f'encoder_small[{B},{T}] log_predicted', rel_l2(res['log_predicted'], rres['log_predicted']), 8e-3)
+    bounded(f'encoder_small[{B},{T}] predicted', rel_l2(pred, rpred), 3e-3)
     with torch.no_grad():
         raw, none = up.SpecHead.spechead(hidden)       # TransformerSpecPredictionHead returns a 2-tuple (model.py:120)
-    assert none is None and rel_l2(raw, rres['log_predicted']) < 3e-2
+    assert none is None
+    bounded(f'encoder_small[{B},{T}] raw head', rel_l2(raw, rres['log_predicted']), 8e-3)
 
 
 def test_encoder_full_size_one_utterance(gpu):
@@ -68,7 +72,7 @@ def test_encoder_full_size_one_utterance(gpu):
     ref_feats = opre.forward(wavs, pre.feat_list, opre.Geometry())
     ref = oenc.encoder_forward(ref_feats[0], ckpt['Transformer'], oenc.Config(cfg))
     assert hidden.shape == (1, 1001, 768)
-    assert rel_l2(hidden, ref) < 2e-2
+    bounded('encoder_full_size_one_utterance hidden', rel_l2(hidden, ref), 6e-3)
 
 
 def test_row_complete_kernels_at_full_width(gpu):
@@ -95,8 +99,8 @@ def test_row_complete_kernels_at_full_width(gpu):
     ocfg = oenc.Config(cfg)
     ref = oenc.encoder_forward(feats, ckpt['Transformer'], ocfg)
     rpred, rres = oheads.spec_head(ref, ckpt['SpecHead'], ocfg, log=True)
-    assert rel_l2(outs['fused'][0], ref) < 2e-2
-    assert rel_l2(outs['fused'][1], rres['log_predicted']) < 3e-2
+    bounded('row_complete hidden vs oracle', rel_l2(outs['fused'][0], ref), 6e-3)
+    bounded('row_complete log_predicted vs oracle', rel_l2(outs['fused'][1], rres['log_predicted']), 8e-3)
 
 
 def test_ckpt_file_route_and_waveform_input(gpu, small, tmp_path):
@@ -136,9 +140,9 @@ def test_upstream_enhance_step_vs_oracle(gpu, small):
     rpred, rres = oheads.spec_head(hid, ckpt['SpecHead'], ocfg, log=True)
     rwav = odec.decode_wav(rpred, f[3], lengths, geom, wavs[:, 1])
     rloss = oobj.l1(rres['log_predicted'], f[4], odec.get_length_masks(lengths // 160 + 1))
-    assert rel_l2(predicted, rpred) < 3e-2
-    assert rel_l2(wav_pred, rwav) < 3e-2
-    assert abs(loss.item() - rloss.item()) < 2e-2 * abs(rloss.item())
+    bounded('upstream_enhance_step predicted', rel_l2(predicted, rpred), 3e-3)
+    bounded('upstream_enhance_step wav', rel_l2(wav_pred, rwav), 1.5e-3)
+    bounded('upstream_enhance_step loss', abs(loss.item() - rloss.item()) / abs(rloss.item()), 3e-3)
 
 
 def test_head_enhance_step_fp32_1e4(gpu):
@@ -187,5 +191,32 @@ def test_enhance_step_odd_shapes(gpu, small, n_samples, B):
     rpred, rres = oheads.spec_head(hid, ckpt['SpecHead'], ocfg, log=True)
     rwav = odec.decode_wav(rpred, f[3], lengths, geom, wavs[:, 1])
     assert predicted.shape == rpred.shape and wav_pred.shape == rwav.shape
-    assert rel_l2(predicted, rpred) < 4e-2
-    assert rel_l2(wav_pred, rwav) < 4e-2
+    bounded(f'odd_shapes[{n_samples},{B}] predicted', rel_l2(predicted, rpred), 3e-3)
+    bounded(f'odd_shapes[{n_samples},{B}] wav', rel_l2(wav_pred, rwav), 1.5e-3)
+
+
+def test_bench_shape_default_dispatch_vs_oracle(gpu):
+    """The shape and dispatch the headline bench times (runner.py:556-575 at B = 32, T' = 1001: 32 032 rows -> persistent 256 x 256 GEMMs for
+    QKV / FFN1, the row-complete GEMM + LayerNorm kernels on the 24-bit residual stream, the pre-scaled attention kernel), one encoder layer
+    + the spec head to bound the oracle's time, against the fp32 CPU oracle."""
+    from speech_enhancement_by_s3prl_amd import pipeline, synth
+    cfg = pipeline.make_config(layers=1)
+    ckpt = pipeline.synthetic_checkpoint(cfg, seed=7)
+    up = pipeline.build_upstream(ckpt, gpu)
+    pre = pipeline.build_preprocessor(cfg, gpu)
+    lengths, wavs = synth.fast_batch(32, 160000, seed=3)
+    feats = pre(wavs.to(gpu))
+    assert feats[0].shape == (32, 1001, 80)
+    with torch.no_grad():
+        hidden = up(feats[0])
+        pred, res = up.SpecHead(hidden)
+    torch.set_num_threads(max(1, min(16, len(__import__('os').sched_getaffinity(0)))))
+    ocfg = oenc.Config(cfg)
+    ref_feats = opre.forward(wavs, pre.feat_list, opre.Geometry())
+    bounded('bench_shape feats', rel_l2(feats[0], ref_feats[0]), 1e-4)
+    ref = oenc.encoder_forward(ref_feats[0], ckpt['Transformer'], ocfg)
+    rpred, rres = oheads.spec_head(ref, ckpt['SpecHead'], ocfg, log=True)
+    bounded('bench_shape hidden (B=32, T=1001, default dispatch)', rel_l2(hidden, ref), 6e-3)
+    bounded('bench_shape log_predicted', rel_l2(res['log_predicted'], rres['log_predicted']), 8e-3)
+    per_utt = ((hidden.cpu() - ref).flatten(1).norm(dim=1) / ref.flatten(1).norm(dim=1)).max().item()
+    bounded('bench_shape hidden worst utterance', per_utt, 6e-3)

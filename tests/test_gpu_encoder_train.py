@@ -13,6 +13,8 @@ from oracle import objective as oobj
 
 pytestmark = pytest.mark.gpu
 
+from conftest import bounded  # noqa: E402
+
 
 def _L():
     from speech_enhancement_by_s3prl_amd import _lib
@@ -25,7 +27,8 @@ def rel_l2(a, b):
 
 
 @pytest.mark.parametrize('B,T,heads,lens,drop', [(2, 300, 12, [300, 177], 0.0), (1, 129, 4, None, 0.0), (3, 64, 2, [64, 1, 33], 0.0),
-                                                  (2, 301, 12, [301, 190], 0.1), (1, 130, 4, None, 0.25)])
+                                                  (2, 301, 12, [301, 190], 0.1), (1, 130, 4, None, 0.25),
+                                                  (1, 1001, 12, None, 0.0)])       # the fine-tune bench's T' = 1001
 def test_mhsa_backward_vs_autograd(gpu, B, T, heads, lens, drop):
     L = _L()
     lib = L.load()
@@ -57,14 +60,14 @@ def test_mhsa_backward_vs_autograd(gpu, B, T, heads, lens, drop):
     o = (p @ v).permute(0, 2, 1, 3).reshape(B * T, H)
     (o * d_o.double()).sum().backward()
     # forward pieces
-    assert rel_l2(ctx, o.detach()) < 1e-2
+    bounded(f'mhsa_fwd_lse[{B},{T},{heads},drop={drop}] ctx', rel_l2(ctx, o.detach()), 5e-3)
     ref_lse = torch.logsumexp(s.detach(), dim=-1) / math.log(2.0)            # the kernel keeps it in the log2 domain
     assert (lse.double().cpu() - ref_lse).abs().max().item() < 1e-3
     assert torch.isfinite(dqkv.float()).all()
     got = dqkv.double().cpu()
     for name, lo in (('dQ', 0), ('dK', H), ('dV', 2 * H)):
         r = rel_l2(got[:, lo:lo + H], x.grad[:, lo:lo + H])
-        assert r < 1.5e-2, (name, r)          # P, dS and the outputs are rounded to bf16 (2^-9 relative each)
+        bounded(f'mhsa_bwd[{B},{T},{heads},drop={drop}] {name}', r, 6.5e-3)          # P, dS and the outputs are rounded to bf16 (2^-9 relative each)
     # padded keys: exact zeros
     for b in range(B):
         n = int(lengths[b])
@@ -113,7 +116,7 @@ def _encoder_grads_vs_oracle(gpu, cfg, ckpt, B, T, lens, tol, train_mode=False):
     p_drop, seed = up.last_dropout if train_mode else (0.0, 0)
     assert (p_drop > 0) == train_mode
     ref = oenc.encoder_forward(feats.double(), sd, ocfg, dropout_p=p_drop, seed=seed)     # same counter-based masks
-    assert rel_l2(hidden.detach(), ref.detach()) < 2e-2
+    bounded(f'encoder_train[{B},{T}] hidden', rel_l2(hidden.detach(), ref.detach()), 5e-3)
     (ref * G.double()).sum().backward()
     worst = 0.0
     for name, p in up.model.named_parameters():
@@ -128,6 +131,7 @@ def _encoder_grads_vs_oracle(gpu, cfg, ckpt, B, T, lens, tol, train_mode=False):
         r = rel_l2(p.grad, sd[name].grad)
         worst = max(worst, r)
         assert r < tol, (name, r)
+    bounded(f'encoder_train[{B},{T},H{H},train={train_mode}] worst parameter-gradient rel-L2', worst, tol)
     return worst
 
 
@@ -136,7 +140,7 @@ def test_encoder_gradients_small_config(gpu):
     from speech_enhancement_by_s3prl_amd import pipeline
     cfg = pipeline.make_config(layers=2, hidden=256, heads=4, intermediate=512)
     ckpt = pipeline.synthetic_checkpoint(cfg, seed=3)
-    _encoder_grads_vs_oracle(gpu, cfg, ckpt, 3, 257, [257, 100, 64], tol=4e-2)
+    _encoder_grads_vs_oracle(gpu, cfg, ckpt, 3, 257, [257, 100, 64], tol=2.5e-2)
 
 
 @pytest.mark.parametrize('B,T,lens', [(1, 17, None), (5, 65, [65, 64, 3, 33, 2]), (2, 130, [130, 129])])
@@ -146,7 +150,7 @@ def test_encoder_gradients_edge_shapes(gpu, B, T, lens):
     from speech_enhancement_by_s3prl_amd import pipeline
     cfg = pipeline.make_config(layers=1, hidden=256, heads=4, intermediate=512)
     ckpt = pipeline.synthetic_checkpoint(cfg, seed=6)
-    _encoder_grads_vs_oracle(gpu, cfg, ckpt, B, T, lens, tol=4e-2)
+    _encoder_grads_vs_oracle(gpu, cfg, ckpt, B, T, lens, tol=2.5e-2)
 
 
 def test_encoder_gradients_full_width(gpu):
@@ -154,7 +158,17 @@ def test_encoder_gradients_full_width(gpu):
     from speech_enhancement_by_s3prl_amd import pipeline
     cfg = pipeline.make_config(layers=2)
     ckpt = pipeline.synthetic_checkpoint(cfg, seed=4)
-    _encoder_grads_vs_oracle(gpu, cfg, ckpt, 2, 200, [200, 150], tol=4e-2)
+    _encoder_grads_vs_oracle(gpu, cfg, ckpt, 2, 200, [200, 150], tol=2.5e-2)
+
+
+def test_encoder_gradients_at_bench_length(gpu):
+    """T' = 1001 (the 10 s utterances the fine-tune bench runs, runner.py:431-471), full width, one layer, one utterance: hidden states and
+    every parameter gradient vs fp64 autograd through the oracle -- the 16-tile flash backward, the TN weight-gradient kernel at M = 1001."""
+    from speech_enhancement_by_s3prl_amd import pipeline
+    torch.set_num_threads(max(1, min(16, len(__import__('os').sched_getaffinity(0)))))
+    cfg = pipeline.make_config(layers=1)
+    ckpt = pipeline.synthetic_checkpoint(cfg, seed=8)
+    _encoder_grads_vs_oracle(gpu, cfg, ckpt, 1, 1001, None, tol=2.5e-2)
 
 
 def test_encoder_gradients_with_dropout(gpu):
@@ -162,9 +176,9 @@ def test_encoder_gradients_with_dropout(gpu):
     oracle regenerates them from the seed: oracle/encoder.py keep_mask == csrc/dropout.h), small and full width."""
     from speech_enhancement_by_s3prl_amd import pipeline
     cfg = pipeline.make_config(layers=2, hidden=256, heads=4, intermediate=512)
-    _encoder_grads_vs_oracle(gpu, cfg, pipeline.synthetic_checkpoint(cfg, seed=3), 3, 131, [131, 100, 64], tol=4e-2, train_mode=True)
+    _encoder_grads_vs_oracle(gpu, cfg, pipeline.synthetic_checkpoint(cfg, seed=3), 3, 131, [131, 100, 64], tol=2.5e-2, train_mode=True)
     cfg = pipeline.make_config(layers=2)
-    _encoder_grads_vs_oracle(gpu, cfg, pipeline.synthetic_checkpoint(cfg, seed=4), 2, 150, [150, 99], tol=4e-2, train_mode=True)
+    _encoder_grads_vs_oracle(gpu, cfg, pipeline.synthetic_checkpoint(cfg, seed=4), 2, 150, [150, 99], tol=2.5e-2, train_mode=True)
 
 
 def test_dropout_is_resampled_and_off_in_eval(gpu):
