@@ -175,6 +175,7 @@ def main():
     ap.add_argument('--graph', action='store_true', help='replay the enhance pass as one hipGraph launch (serving-size batches are launch-bound)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-host-fed', action='store_true', help='skip the PCIe-inclusive side measurement')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend of the ranks ('nccl' = RCCL over xGMI)")
     ap.add_argument('--launch-check', action='store_true', help='rank plumbing only (no kernels): used by the CPU test of the launcher')
     args = ap.parse_args()
@@ -345,6 +346,23 @@ def main():
                                             'avg_launch_ms': ms / n, 'share_of_step_ms': ms / args.steps}
         others['gemm_share_of_step_ms'] = g_ms / args.steps
         out['roofline_other_kernels'] = others
+
+    if rank == 0 and args.workload == 'enhance' and not args.graph and not args.no_host_fed:
+        # PCIe-inclusive side measurement (never `value`): the same K steps with every batch arriving from pinned HOST memory through the
+        # double-buffered feeder (feeder.py; the reference copies synchronously on the compute stream, runner.py:431-432, 556-557)
+        from speech_enhancement_by_s3prl_amd.feeder import HostBatchFeeder
+        host_l, host_w = lengths.cpu().pin_memory(), wavs.cpu().pin_memory()
+        for dl, dw in HostBatchFeeder([(host_l, host_w)] * args.warmup, dev):
+            step(dw, dl, max_len)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for dl, dw in HostBatchFeeder([(host_l, host_w)] * args.steps, dev):
+            step(dw, dl, max_len)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        out['host_fed'] = {'value': args.batch * args.steps / el, 'unit': 'utt/s', 'ms_per_step': 1000.0 * el / args.steps,
+                           'bytes_per_step': host_w.numel() * 4 + host_l.numel() * 8,
+                           'note': 'rank 0 only; batches DMA-ed from pinned host memory on a copy stream, double buffered (PCIe-inclusive; not the headline value)'}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == 'enhance':
         try:
