@@ -257,6 +257,18 @@ int se_layernorm_f32(const float* x, const float* w, const float* b, int M, int 
 int se_cast_f32_bf16(const float* x, size_t n, uint16_t* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Exact-fp32 building blocks of the encoder's parity mode (TRANSFORMER / TransformerSpecPredictionHead with precision = 'fp32':
+ * rows B1-B4 at north_star's 1e-4 tolerance against the reference's fp32 PyTorch path; the bf16 kernels above stay the bench default).
+ * se_gemm_f32: C = act(alpha * A . W^T + bias) [+ residual[row % res_mod]] with fp32 operands on the fp32 matrix instruction (a k-ordered
+ *   fmaf chain), batched over batch_outer x batch_inner problems with free element strides; W is (N, K) row-major (nn.Linear weight, the
+ *   K operand of Q K^T) or, with w_kmajor = 1, (K, N) row-major (the V operand of P V).  lda / ldw / ldc in elements.
+ * se_softmax_rows_f32: in-place row softmax of scores (B, heads, T, T) with the reference's additive -10000 on keys >= lengths[b]. */
+int se_gemm_f32(const float* A, long lda, const float* W, long ldw, int w_kmajor, const float* bias, const float* residual, int res_mod,
+                int M, int N, int K, int act, float alpha, float* C, long ldc, int batch_outer, int batch_inner, long strideA_outer,
+                long strideA_inner, long strideW_outer, long strideW_inner, long strideC_outer, long strideC_inner, void* stream);
+int se_softmax_rows_f32(float* scores, const int32_t* lengths, int B, int heads, int T, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Backward building blocks (row E2 beyond the linear heads: autograd through TransformerSpecPredictionHead /
  * SpecHead, model.py:94-126, runner.py:459).  Mixed precision as the forward: bf16 GEMM operands, fp32 sums.
  * The input gradient dX = dY . W is se_gemm_bf16 on a transposed bf16 weight copy (se_transpose_*).

@@ -1,0 +1,138 @@
+// fp32path.hip -- the EXACT-fp32 building blocks of the encoder's parity mode (rows B1-B4 at the tolerance north_star states for enhanced
+// magnitudes, 1e-4 relative; BASELINE.json's bench configuration is bf16 and stays the default).
+//
+// The bf16 kernels round every GEMM operand to 8 mantissa bits; no amount of care in them reaches 1e-4 against the reference's fp32
+// PyTorch path.  This file is the other end of the trade: fp32 operands, fp32 products, fp32 sums, libm-grade erf / exp, the score matrix
+// materialised as the reference does (runner.py:273-284 -> S3PRL's BERT attention: scores + additive -10000 mask -> softmax -> P V).
+//   se_gemm_f32        C = epilogue(A . W^T + bias [+ residual]) on v_mfma_f32_32x32x2_f32 (fp32 in / fp32 accumulate: bit for bit a k-ordered
+//                      fmaf chain, 1/16 of the bf16 matrix rate -- gfx950 has no TF32), batched over two levels (utterance, head) with free
+//                      strides, W either (N, K) row-major (nn.Linear, K^T of attention) or (K, N) row-major (the V operand of P . V)
+//   se_softmax_rows_f32  in-place masked row softmax of the score tensor (exact expf, fp32 sums; keys >= length get the reference's
+//                      additive -10000 before the maximum, i.e. exp() == 0 in fp32)
+// Throughput is not the point (a 10 s utterance through the 6-layer encoder takes tens of ms); the tile is a plain 64 x 64 x 16 LDS-staged loop.
+#include "common.h"
+
+namespace se {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16_;
+
+constexpr int kFT = 64, kFK = 16;       // output tile 64 x 64, K-tile 16; 256 threads = 4 waves as 2 x 2, wave tile 32 x 32 (one MFMA accumulator)
+
+__device__ __forceinline__ float gelu_exact(float v) { return v * 0.5f * (1.0f + erff(v * 0.70710678118654752440f)); }
+
+// element (m, k) of A at A[m * lda + k]; element (n, k) of W at W[n * ldw + k] (WK = 0) or W[k * ldw + n] (WK = 1)
+template <int WK>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, long lda, const float* __restrict__ W, long ldw,
+                                                       const float* __restrict__ bias, const float* __restrict__ residual, int res_mod, int M, int N,
+                                                       int K, int act, float alpha, float* __restrict__ C, long ldc, int inner, long sA0, long sA1,
+                                                       long sW0, long sW1, long sC0, long sC1) {
+  __shared__ float As[kFK][kFT + 1];      // [k][m]
+  __shared__ float Ws[kFK][kFT + 1];      // [k][n]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int z = blockIdx.z, z0 = z / inner, z1 = z - z0 * inner;
+  A += z0 * sA0 + z1 * sA1;
+  W += z0 * sW0 + z1 * sW1;
+  C += z0 * sC0 + z1 * sC1;
+  const int m0 = blockIdx.y * kFT, n0 = blockIdx.x * kFT;
+  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+  f32x16_ acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  // v_mfma_f32_32x32x2_f32: A operand lane l -> row (l & 31), k = l >> 5; B operand lane l -> column (l & 31), k = l >> 5;
+  // D: lane l -> column (l & 31), rows (r & 3) + 8 (r >> 2) + 4 (l >> 5)
+  const int lr = lane & 31, lk = lane >> 5;
+  for (int k0 = 0; k0 < K; k0 += kFK) {
+    // stage: 64 x 16 elements of each operand, 4 per thread; out-of-range -> 0
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + 256 * i;
+      const int kk = e & 15, mm = e >> 4;             // k fastest: contiguous for row-major A / (N, K) W
+      const int gm = m0 + mm, gk = k0 + kk;
+      As[kk][mm] = (gm < M && gk < K) ? A[(long)gm * lda + gk] : 0.f;
+      if (WK == 0) {
+        const int gn = n0 + mm;
+        Ws[kk][mm] = (gn < N && gk < K) ? W[(long)gn * ldw + gk] : 0.f;
+      } else {
+        const int nn = e & 63, k2 = e >> 6;           // n fastest: contiguous for (K, N) W
+        const int gn = n0 + nn, gk2 = k0 + k2;
+        Ws[k2][nn] = (gn < N && gk2 < K) ? W[(long)gk2 * ldw + gn] : 0.f;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < kFK; ks += 2) {
+      const float a = As[ks + lk][wm + lr];
+      const float b = Ws[ks + lk][wn + lr];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  const int gn = n0 + wn + lr;
+  if (gn >= N) return;
+  const float bv = bias ? bias[gn] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int gm = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * lk;
+    if (gm >= M) continue;
+    float v = fmaf(acc[r], alpha, bv);
+    if (act == SE_ACT_GELU) v = gelu_exact(v);
+    if (residual) v += residual[(long)(res_mod > 0 ? gm % res_mod : gm) * N + gn];
+    C[(long)gm * ldc + gn] = v;
+  }
+}
+
+// S: (B, heads, T, T) scores; row (b, h, i): p_j = softmax_j(S_ij + (j >= len[b] ? -10000 : 0)).  One wave per row.
+__global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ S, const int32_t* __restrict__ lengths, int heads, int T, long rows) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const int b = (int)(row / ((long)heads * T));
+  const int len = lengths ? min(max(lengths[b], 0), T) : T;
+  float* s = S + row * T;
+  float mx = -INFINITY;
+  for (int j = lane; j < T; j += 64) mx = fmaxf(mx, s[j] + (j >= len ? -10000.0f : 0.f));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  float sum = 0.f;
+  for (int j = lane; j < T; j += 64) {
+    const float e = expf(s[j] + (j >= len ? -10000.0f : 0.f) - mx);
+    s[j] = e;
+    sum += e;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+  const float inv = 1.0f / sum;
+  for (int j = lane; j < T; j += 64) s[j] *= inv;
+}
+
+}  // namespace se
+
+extern "C" int se_gemm_f32(const float* A, long lda, const float* W, long ldw, int w_kmajor, const float* bias, const float* residual, int res_mod,
+                           int M, int N, int K, int act, float alpha, float* C, long ldc, int batch_outer, int batch_inner, long strideA_outer,
+                           long strideA_inner, long strideW_outer, long strideW_inner, long strideC_outer, long strideC_inner, void* stream) {
+  SE_REQUIRE(A && W && C, "se_gemm_f32: null argument");
+  SE_REQUIRE(M > 0 && N > 0 && K > 0 && batch_outer > 0 && batch_inner > 0, "se_gemm_f32: bad shape M=%d N=%d K=%d batch=%d x %d", M, N, K, batch_outer, batch_inner);
+  SE_REQUIRE((long)batch_outer * batch_inner <= 65535, "se_gemm_f32: batch %ld exceeds grid.z", (long)batch_outer * batch_inner);
+  SE_REQUIRE(act == SE_ACT_IDENTITY || act == SE_ACT_GELU, "se_gemm_f32: activation %d not supported (identity / gelu)", act);
+  SE_REQUIRE(!residual || ((long)batch_outer * batch_inner == 1), "se_gemm_f32: a residual is only defined for unbatched calls");
+  dim3 grid((N + se::kFT - 1) / se::kFT, (M + se::kFT - 1) / se::kFT, batch_outer * batch_inner);
+  SE_REQUIRE(grid.y <= 65535, "se_gemm_f32: M=%d too large", M);
+  hipStream_t st = se::as_stream(stream);
+  if (w_kmajor)
+    hipLaunchKernelGGL(se::gemm_f32_kernel<1>, grid, dim3(256), 0, st, A, lda, W, ldw, bias, residual, res_mod, M, N, K, act, alpha, C, ldc, batch_inner,
+                       strideA_outer, strideA_inner, strideW_outer, strideW_inner, strideC_outer, strideC_inner);
+  else
+    hipLaunchKernelGGL(se::gemm_f32_kernel<0>, grid, dim3(256), 0, st, A, lda, W, ldw, bias, residual, res_mod, M, N, K, act, alpha, C, ldc, batch_inner,
+                       strideA_outer, strideA_inner, strideW_outer, strideW_inner, strideC_outer, strideC_inner);
+  SE_LAUNCH_CHECK();
+  return SE_OK;
+}
+
+extern "C" int se_softmax_rows_f32(float* scores, const int32_t* lengths, int B, int heads, int T, void* stream) {
+  SE_REQUIRE(scores && B > 0 && heads > 0 && T > 0, "se_softmax_rows_f32: bad argument");
+  const long rows = (long)B * heads * T;
+  SE_REQUIRE((rows + 3) / 4 <= 0x7fffffffL, "se_softmax_rows_f32: too many rows");
+  hipLaunchKernelGGL(se::softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, se::as_stream(stream), scores, lengths, heads, T, rows);
+  SE_LAUNCH_CHECK();
+  return SE_OK;
+}

@@ -107,6 +107,12 @@ class TransformerSpecPredictionHead(nn.Module):
     def _needs_grad(self):
         return torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
 
+    def set_precision(self, precision):
+        """'bf16' (default: MFMA bf16 operands, fp32 sums) or 'fp32' (exact-fp32 parity mode, inference only)."""
+        assert precision in ('bf16', 'fp32')
+        self._engine.precision = precision
+        return self
+
     def forward(self, hidden_states):
         if self._needs_grad():
             # training path (kept intermediates + HIP backward); `raw` = log_predicted of a log-target, identity-activation epilogue
@@ -221,6 +227,7 @@ class _Engine:
         self.key = None
         self.ws = {}                  # one workspace per HIP stream: concurrent passes (pipeline.UpstreamEnhanceStep(streams=2)) must not share
         self.fused_ln_min_rows = 0    # 0 = the library's default threshold for the row-complete GEMM + LayerNorm kernel
+        self.precision = 'bf16'       # 'fp32': the exact-fp32 parity mode (inference only; csrc/fp32path.hip)
 
     def __del__(self):
         try:
@@ -234,6 +241,7 @@ class _Engine:
 
     def __setstate__(self, state):
         self.handle, self.key, self.ws, self.fused_ln_min_rows = None, None, {}, 0
+        self.precision = 'bf16'
 
     def __deepcopy__(self, memo):
         return _Engine()
@@ -339,7 +347,98 @@ class _Engine:
             ws = self.ws[sid] = torch.empty(n, device=device, dtype=torch.uint8)
         return ws, n
 
+    # ---- exact-fp32 parity mode (inference): fp32 operands / products / sums on se_gemm_f32, the score tensor materialised as the reference does
+    @staticmethod
+    def _gemm32(a, w, bias, M, N, K, act=0, residual=None, res_mod=0, alpha=1.0, out=None, lda=None, ldw=None, ldc=None, w_kmajor=0, batch=(1, 1),
+                strides=(0, 0, 0, 0, 0, 0)):
+        lib = _lib.load()
+        if out is None:
+            out = torch.empty(M, N, device=a.device, dtype=torch.float32)
+        _lib.check(lib.se_gemm_f32(a.data_ptr(), K if lda is None else lda, w.data_ptr(), K if ldw is None else ldw, int(w_kmajor), _lib.ptr(bias), _lib.ptr(residual),
+                                   int(res_mod), M, N, K, int(act), float(alpha), out.data_ptr(), N if ldc is None else ldc, batch[0], batch[1], *strides,
+                                   _lib.stream()), 'se_gemm_f32')
+        return out
+
+    @staticmethod
+    def _ln32(x, ln, M, H):
+        lib = _lib.load()
+        out = torch.empty(M, H, device=x.device, dtype=torch.float32)
+        _lib.check(lib.se_layernorm_f32(_lib.ptr(x), _lib.ptr(ln.weight.detach()), _lib.ptr(ln.bias.detach()), M, H, float(ln.variance_epsilon), _lib.ptr(out), None,
+                                        _lib.stream()), 'se_layernorm_f32')
+        return out
+
+    def encode_fp32(self, model, feats, lengths=None):
+        """rows B1-B3 in exact fp32 (oracle/encoder.py: encoder_forward is the same chain on the CPU): input projection + sinusoid table +
+        LayerNorm, then per layer Q / K / V projections, scores = Q K^T / 8 (+ -10000 on padded keys) -> softmax -> P V, output projection
+        + residual + LayerNorm, FFN with erf-GELU + residual + LayerNorm."""
+        if not feats.is_cuda:
+            raise _lib.SEError('TRANSFORMER runs on MI355X only (no CPU fallback): move the module and inputs to the GPU')
+        lib = _lib.load()
+        cfg = model.config
+        feats = feats.contiguous().float()
+        B, T, D = feats.shape
+        H, heads, I = cfg.hidden_size, cfg.num_attention_heads, cfg.intermediate_size
+        dev = feats.device
+        if H != heads * 64:
+            raise NotImplementedError('head dim must be 64')
+        if lengths is None:
+            lengths = torch.empty(B, device=dev, dtype=torch.int32)
+            _lib.check(lib.se_valid_lengths_i32(_lib.ptr(feats), B, T, D, _lib.ptr(lengths), _lib.stream()), 'se_valid_lengths_i32')
+        M = B * T
+        pe = getattr(self, '_pe32', None)
+        if pe is None or pe.shape != (T, H) or pe.device != dev:
+            pos = torch.arange(T, dtype=torch.float64)[:, None]
+            j = torch.arange(H, dtype=torch.float64)[None, :]
+            ang = pos / torch.pow(torch.tensor(10000.0, dtype=torch.float64), 2.0 * torch.floor(j / 2.0) / H)
+            tab = torch.where((torch.arange(H) % 2 == 0)[None, :], torch.sin(ang), torch.cos(ang))
+            pe = self._pe32 = tab.float().to(dev).contiguous()      # the constant table of S3PRL's position_encoding, built in float64
+        ir = model.input_representations
+        w = lambda p: p.detach().contiguous()       # noqa: E731
+        x = self._gemm32(feats.view(M, D), w(ir.spec_transform.weight), w(ir.spec_transform.bias), M, H, D, residual=pe, res_mod=T)
+        x = self._ln32(x, ir.LayerNorm, M, H)
+        scores = torch.empty(B, heads, T, T, device=dev, dtype=torch.float32)
+        qkv = torch.empty(3, M, H, device=dev, dtype=torch.float32)
+        ctx = torch.empty(M, H, device=dev, dtype=torch.float32)
+        for layer in model.encoder.layer:
+            att = layer.attention
+            for i, lin in enumerate((att.self.query, att.self.key, att.self.value)):
+                self._gemm32(x, w(lin.weight), w(lin.bias), M, H, H, out=qkv[i])
+            # scores[b, h] = Q_bh K_bh^T / sqrt(64): batched over (utterance, head): row stride H, utterance stride T H, head stride 64
+            self._gemm32(qkv[0], qkv[1], None, T, T, 64, alpha=0.125, out=scores, lda=H, ldw=H, ldc=T, batch=(B, heads),
+                         strides=(T * H, 64, T * H, 64, heads * T * T, T * T))
+            _lib.check(lib.se_softmax_rows_f32(_lib.ptr(scores), _lib.ptr(lengths), B, heads, T, _lib.stream()), 'se_softmax_rows_f32')
+            # ctx[b, :, h] = P_bh V_bh: V_bh is (K = T, N = 64) row-major inside the (M, H) value tensor
+            self._gemm32(scores, qkv[2], None, T, 64, T, out=ctx, lda=T, ldw=H, ldc=H, w_kmajor=1, batch=(B, heads),
+                         strides=(heads * T * T, T * T, T * H, 64, T * H, 64))
+            a = self._gemm32(ctx, w(att.output.dense.weight), w(att.output.dense.bias), M, H, H, residual=x)
+            x = self._ln32(a, att.output.LayerNorm, M, H)
+            h = self._gemm32(x, w(layer.intermediate.dense.weight), w(layer.intermediate.dense.bias), M, I, H, act=_lib.SE_ACT['GELU'])
+            o = self._gemm32(h, w(layer.output.dense.weight), w(layer.output.dense.bias), M, H, I, residual=x)
+            x = self._ln32(o, layer.output.LayerNorm, M, H)
+        return x.view(B, T, H)
+
+    def spechead_fp32(self, head, hidden, mode='raw', log_target=False, act='ReLU', eps=1e-6):
+        """row B4 in exact fp32: dense -> erf-GELU -> LayerNorm -> output linear (-> exp / log / activation epilogue)."""
+        if not hidden.is_cuda:
+            raise _lib.SEError('TransformerSpecPredictionHead runs on MI355X only (no CPU fallback)')
+        lib = _lib.load()
+        hidden = hidden.contiguous().float()
+        B, T, H = hidden.shape
+        M, N = B * T, head.output.out_features
+        w = lambda p: p.detach().contiguous()       # noqa: E731
+        h = self._gemm32(hidden.view(M, H), w(head.dense.weight), w(head.dense.bias), M, H, H, act=_lib.SE_ACT['GELU'])
+        h = self._ln32(h, head.LayerNorm, M, H)
+        raw = self._gemm32(h, w(head.output.weight), w(head.output.bias), M, N, H).view(B, T, N)
+        if mode == 'raw':
+            return raw
+        pred, logp = torch.empty_like(raw), torch.empty_like(raw)
+        _lib.check(lib.se_spec_epilogue_f32(_lib.ptr(raw), raw.numel(), int(bool(log_target)), _lib.SE_ACT[act], float(eps), _lib.ptr(pred), _lib.ptr(logp),
+                                            _lib.stream()), 'se_spec_epilogue_f32')
+        return pred, logp
+
     def encode(self, model, head, feats, lengths=None):
+        if self.precision == 'fp32':
+            return self.encode_fp32(model, feats, lengths)
         if not feats.is_cuda:
             raise _lib.SEError('TRANSFORMER runs on MI355X only (no CPU fallback): move the module and inputs to the GPU')
         lib = _lib.load()
@@ -356,6 +455,8 @@ class _Engine:
         return hidden
 
     def spechead(self, head, model, hidden, mode='raw', log_target=False, act='ReLU', eps=1e-6):
+        if self.precision == 'fp32':
+            return self.spechead_fp32(head, hidden, mode=mode, log_target=log_target, act=act, eps=eps)
         if not hidden.is_cuda:
             raise _lib.SEError('TransformerSpecPredictionHead runs on MI355X only (no CPU fallback)')
         lib = _lib.load()
@@ -426,8 +527,21 @@ class TRANSFORMER(nn.Module):
         self._warned = False
         self.all_states = None      # free the checkpoint copy
 
+    def set_precision(self, precision):
+        """'bf16' (default; BASELINE.json's configuration) or 'fp32': the exact-fp32 parity mode of the inference forward (1e-4 on enhanced
+        magnitudes against the reference's fp32 path; ~16x the matrix time, for verification rather than serving).  Also switches an
+        attached `SpecHead` (run_downstream.py:185)."""
+        assert precision in ('bf16', 'fp32')
+        self._engine.precision = precision
+        sh = getattr(self, 'SpecHead', None)
+        if sh is not None and hasattr(sh, 'spechead'):
+            sh.spechead.set_precision(precision)
+        return self
+
     def forward(self, x):
         train = torch.is_grad_enabled() and not self.no_grad and any(p.requires_grad for p in self.model.parameters())
+        if train and self._engine.precision == 'fp32':
+            raise NotImplementedError("precision 'fp32' is the inference parity mode; training runs the bf16 kernels")
         dropout_p = self.model_config.hidden_dropout_prob if self.training else 0.0
         if dropout_p > 0:
             if self.model_config.attention_probs_dropout_prob != dropout_p:

@@ -1,0 +1,102 @@
+"""GPU: the exact-fp32 parity mode of the encoder (TRANSFORMER.set_precision('fp32'), csrc/fp32path.hip) -- BASELINE.json configs 2 / 3 at the
+tolerance north_star states: enhanced magnitudes within 1e-4 relative of the reference's fp32 CPU path (here: the oracle restating it), at
+the reference geometry (6 x 768 x 12 x 3072, T' = 1001, 10 s utterances), through the whole evaluate()-style pass of runner.py:556-575.
+The bf16 path stays the bench default (BASELINE.json names bf16); its bounds live in test_gpu_encoder_pipeline.py."""
+import os
+
+import pytest
+import torch
+
+from oracle import decode as odec
+from oracle import encoder as oenc
+from oracle import heads as oheads
+from oracle import objective as oobj
+from oracle import preprocessor as opre
+
+pytestmark = pytest.mark.gpu
+
+from conftest import bounded  # noqa: E402
+
+
+def rel_l2(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).norm() / b.norm()).item()
+
+
+def test_gemm_f32_vs_fp64(gpu):
+    """se_gemm_f32 in all its addressing forms against fp64: nn.Linear layout with bias / gelu / residual-by-row-modulo, the batched
+    two-level-strided Q K^T form and the (K, N) row-major P V form; ragged sizes off the 64-tiles."""
+    from speech_enhancement_by_s3prl_amd import _lib as L
+    lib = L.load()
+    torch.manual_seed(0)
+    M, N, K = 131, 201, 77
+    A, W, b = torch.randn(M, K, device=gpu), torch.randn(N, K, device=gpu), torch.randn(N, device=gpu)
+    R = torch.randn(17, N, device=gpu)
+    C = torch.empty(M, N, device=gpu)
+    L.check(lib.se_gemm_f32(L.ptr(A), K, L.ptr(W), K, 0, L.ptr(b), L.ptr(R), 17, M, N, K, L.SE_ACT['GELU'], 1.0, L.ptr(C), N, 1, 1, 0, 0, 0, 0, 0, 0, L.stream()), 'gemm')
+    ref = torch.nn.functional.gelu(A.double() @ W.double().T + b.double()) + R.double()[torch.arange(M, device=gpu) % 17]
+    assert (C.double() - ref).abs().max().item() < 2e-5 * ref.abs().max().item()
+    # batched attention forms
+    B, heads, T = 2, 3, 70
+    H = heads * 64
+    q, k, v = (torch.randn(B * T, H, device=gpu) for _ in range(3))
+    S = torch.empty(B, heads, T, T, device=gpu)
+    L.check(lib.se_gemm_f32(L.ptr(q), H, L.ptr(k), H, 0, None, None, 0, T, T, 64, 0, 0.125, L.ptr(S), T, B, heads, T * H, 64, T * H, 64, heads * T * T, T * T,
+                            L.stream()), 'qk')
+    qh = q.double().view(B, T, heads, 64).permute(0, 2, 1, 3)
+    kh = k.double().view(B, T, heads, 64).permute(0, 2, 1, 3)
+    vh = v.double().view(B, T, heads, 64).permute(0, 2, 1, 3)
+    Sref = qh @ kh.transpose(-1, -2) / 8.0
+    assert (S.double() - Sref).abs().max().item() < 1e-5 * Sref.abs().max().item()
+    lengths = torch.tensor([T, 33], device=gpu, dtype=torch.int32)
+    L.check(lib.se_softmax_rows_f32(L.ptr(S), L.ptr(lengths), B, heads, T, L.stream()), 'softmax')
+    mask = (torch.arange(T, device=gpu)[None, :] >= lengths[:, None].long()).double() * -10000.0
+    Pref = torch.softmax(Sref + mask[:, None, None, :], dim=-1)
+    assert (S.double() - Pref).abs().max().item() < 2e-6
+    ctx = torch.empty(B * T, H, device=gpu)
+    L.check(lib.se_gemm_f32(L.ptr(S), T, L.ptr(v), H, 1, None, None, 0, T, 64, T, 0, 1.0, L.ptr(ctx), H, B, heads, heads * T * T, T * T, T * H, 64, T * H, 64,
+                            L.stream()), 'pv')
+    cref = (Pref @ vh).permute(0, 2, 1, 3).reshape(B * T, H)
+    assert (ctx.double() - cref).abs().max().item() < 1e-5 * cref.abs().max().item()
+
+
+def test_fp32_mode_meets_1e4_at_the_reference_geometry(gpu):
+    from speech_enhancement_by_s3prl_amd import pipeline, synth
+    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+    cfg = pipeline.make_config()                                   # 6 x 768 x 12 x 3072 (config/pretrain_sample.yaml)
+    ckpt = pipeline.synthetic_checkpoint(cfg, seed=0)
+    up = pipeline.build_upstream(ckpt, gpu).set_precision('fp32')
+    pre = pipeline.build_preprocessor(cfg, gpu)
+    step = pipeline.UpstreamEnhanceStep(pre, up)
+    lengths, wavs = synth.synth_batch(2, 160000)                   # two 10 s utterances ...
+    lengths[1] = 100000                                            # ... the second one cut to 6.25 s and zero padded as collate_fn does
+    wavs[1, :, 100000:] = 0.0                                      # (dataset.py:169-179): padded frames / masked keys
+    wav_pred, loss, predicted = step(wavs.to(gpu), lengths.to(gpu))
+    with torch.no_grad():
+        hidden = up(pre(wavs.to(gpu))[0])
+    geom = opre.Geometry()
+    f = opre.forward(wavs, pre.feat_list, geom)
+    ocfg = oenc.Config(cfg)
+    hid = oenc.encoder_forward(f[0], ckpt['Transformer'], ocfg)
+    rpred, rres = oheads.spec_head(hid, ckpt['SpecHead'], ocfg, log=True)
+    rwav = odec.decode_wav(rpred, f[3], lengths, geom, wavs[:, 1])
+    rloss = oobj.l1(rres['log_predicted'], f[4], odec.get_length_masks(lengths // 160 + 1))
+    assert hidden.shape == hid.shape == (2, 1001, 768)
+    bounded('fp32 mode: hidden rel-L2 (6 layers, T=1001)', rel_l2(hidden, hid), 2e-5)
+    bounded('fp32 mode: hidden max-norm', (hidden.cpu() - hid).abs().max().item() / hid.abs().max().item(), 1e-4)
+    mag, rmag = predicted.cpu().double().sqrt(), rpred.double().sqrt()
+    per_utt = ((mag - rmag).abs().flatten(1).max(dim=1).values / rmag.flatten(1).max(dim=1).values).max().item()
+    bounded('fp32 mode: enhanced magnitudes, max-norm per utterance (north_star: 1e-4)', per_utt, 1e-4)
+    bounded('fp32 mode: enhanced magnitudes rel-L2', rel_l2(mag, rmag), 1e-4)
+    bounded('fp32 mode: enhanced waveform max-norm', ((wav_pred.cpu() - rwav).abs().max() / rwav.abs().max()).item(), 1e-4)
+    bounded('fp32 mode: L1 loss', abs(loss.item() - rloss.item()) / abs(rloss.item()), 1e-5)
+    for i in range(2):
+        n = int(lengths[i])
+        a = oobj.sisdr_eval(wav_pred[i, :n].cpu(), wavs[i, 1, :n])
+        r = oobj.sisdr_eval(rwav[i, :n], wavs[i, 1, :n])
+        bounded(f'fp32 mode: SI-SDR delta utterance {i} (dB)', abs(a - r), 1e-3)
+    # and the mode is a switch: back to bf16 gives the bench path again
+    up.set_precision('bf16')
+    with torch.no_grad():
+        h16 = up(pre(wavs.to(gpu))[0])
+    assert 1e-4 < rel_l2(h16, hid) < 6e-3
