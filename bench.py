@@ -64,10 +64,14 @@ def cpu_baseline(batch, layers, seconds_budget=25.0):
             loss = oobj.l1(res['log_predicted'], f[4], odec.get_length_masks(lengths // 160 + 1))
         return wav, loss
 
+    # protocol of BASELINE.md section 3: 3 warm-ups, >= 10 timed iterations where the budget allows (a bounded sample: 10-30 s of CPU work)
     t0 = time.perf_counter()
-    one()                      # warm-up (also sizes the sample)
+    one()
     warm = time.perf_counter() - t0
-    iters = max(1, min(5, int(seconds_budget / max(warm, 1e-3)) - 1))
+    n_warm = 3 if warm * 14 < seconds_budget * 1.5 else 1
+    for _ in range(n_warm - 1):
+        one()
+    iters = max(3, min(10, int(seconds_budget / max(warm, 1e-3)) - n_warm))
     t0 = time.perf_counter()
     for _ in range(iters):
         one()
@@ -82,7 +86,7 @@ def cpu_baseline(batch, layers, seconds_budget=25.0):
     except OSError:
         pass
     return {'value': batch / dt, 'unit': 'utt/s', 'cores': cores, 'kind': 'port',
-            'sample': f'{iters} x batch of {batch} synthetic 10 s utterances, same pass (fp32 torch CPU oracle, L={layers}), '
+            'sample': f'{n_warm} warm-ups + {iters} timed x batch of {batch} synthetic 10 s utterances, same pass (fp32 torch CPU oracle, L={layers}), '
                       f'{dt:.2f} s per batch on {cpu_name}'}
 
 
@@ -366,7 +370,7 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == 'enhance':
         try:
-            out['cpu_baseline'] = cpu_baseline(batch=4, layers=args.layers)
+            out['cpu_baseline'] = cpu_baseline(batch=4, layers=args.layers, seconds_budget=28.0)
         except Exception as e:      # the baseline is a reported extra; never lose the GPU line
             out['cpu_baseline'] = {'value': None, 'unit': 'utt/s', 'cores': os.cpu_count(), 'kind': 'port', 'sample': f'failed: {e}'}
 

@@ -291,6 +291,9 @@ int se_wgrad_tn_slabs_bf16(const uint16_t* dY, int ldy, const uint16_t* X, int l
                            float* slabs, void* stream);
 /* bias gradient: out[c] (+)= sum_r x[r][c] */
 int se_colsum_f32(const float* x, int rows, int cols, int ld, float* out, int accumulate, void* stream);
+/* out[g][c] = sum over the `rows` rows of group g: per-utterance bias gradients of the active-sampling scoring (sampler.py:59-110) in one
+   launch; x is fp32 or (is_bf16) bf16, (groups * rows, ld). */
+int se_colsum_groups(const void* x, int is_bf16, int groups, int rows, int cols, int ld, float* out, void* stream);
 /* LayerNorm backward (TF style).  x_in = LayerNorm input (gelu_in: its pre-GELU value, i.e. y = LN(gelu(x_in)), and
  * the returned gradient is wrt x_in).  dx / dx_bf16 (M, H); dgamma, dbeta (H) accumulated by atomics.  H = 768. */
 int se_layernorm_bwd_f32(const float* x_in, const float* dy, const float* w, int M, int H, float eps, int gelu_in,

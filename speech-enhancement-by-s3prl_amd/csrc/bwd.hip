@@ -341,6 +341,38 @@ extern "C" int se_wgrad_bf16(const uint16_t* dYt, const uint16_t* Xt, int Mp, in
   return SE_OK;
 }
 
+namespace se {
+// out[g][c] = sum over the rows of group g of x[(g * rows + r) * ld + c]: per-utterance bias gradients (active-sampling scoring) in ONE launch.
+// Workgroup = (64-column strip, group); 4 waves walk the group's rows 4 apart, lanes own one column each; LDS combine.
+template <typename TIn>
+__global__ __launch_bounds__(256) void colsum_groups_kernel(const TIn* __restrict__ x, int rows, int cols, int ld, float* __restrict__ out) {
+  __shared__ float part[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6, g = blockIdx.y;
+  float acc = 0.f;
+  if (c < cols) {
+    const TIn* p = x + (size_t)g * rows * ld + c;
+    for (int r = w; r < rows; r += 4) {
+      if constexpr (sizeof(TIn) == 2) acc += bf2f(p[(size_t)r * ld]);
+      else acc += p[(size_t)r * ld];
+    }
+  }
+  part[w][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (w == 0 && c < cols) out[(size_t)g * cols + c] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+}  // namespace se
+
+extern "C" int se_colsum_groups(const void* x, int is_bf16, int groups, int rows, int cols, int ld, float* out, void* stream) {
+  SE_REQUIRE(x && out && groups > 0 && groups <= 65535 && rows > 0 && cols > 0 && ld >= cols, "se_colsum_groups: bad argument");
+  dim3 grid((cols + 63) / 64, groups);
+  if (is_bf16)
+    hipLaunchKernelGGL(se::colsum_groups_kernel<uint16_t>, grid, dim3(256), 0, se::as_stream(stream), static_cast<const uint16_t*>(x), rows, cols, ld, out);
+  else
+    hipLaunchKernelGGL(se::colsum_groups_kernel<float>, grid, dim3(256), 0, se::as_stream(stream), static_cast<const float*>(x), rows, cols, ld, out);
+  SE_LAUNCH_CHECK();
+  return SE_OK;
+}
+
 extern "C" int se_colsum_f32(const float* x, int rows, int cols, int ld, float* out, int accumulate, void* stream) {
   SE_REQUIRE(x && out && rows > 0 && cols > 0 && ld >= cols, "se_colsum_f32: bad argument");
   hipStream_t st = se::as_stream(stream);

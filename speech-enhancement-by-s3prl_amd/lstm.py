@@ -74,48 +74,81 @@ class _LSTMFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_out):
-        lib = _lib.load()
-        B, T, D, num_layers, ndir = ctx.meta
-        M = B * T
-        weights = ctx.weights
-        dev = d_out.device
-        dh = d_out.reshape(M, ndir * _H).contiguous().float()
-        grads = [None] * len(weights)
-        for l in range(num_layers - 1, -1, -1):
-            inp16, h16, gates, cst = ctx.saved[l]
-            ws = weights[4 * ndir * l: 4 * ndir * (l + 1)]
-            K = inp16.shape[1]
-            wq = torch.stack([_pack_hh_bwd(ws[4 * d + 1]) for d in range(ndir)]).contiguous()
-            dg = torch.empty(ndir, M, 4 * _H, device=dev, dtype=torch.bfloat16)
-            _lib.check(lib.se_lstm_bwd_bf16(_lib.ptr(wq), _lib.ptr(gates), _lib.ptr(cst), _lib.ptr(dh), ndir * _H, B, T, ndir, _lib.ptr(dg),
-                                            _lib.stream()), 'se_lstm_bwd_bf16')
-            hv = h16.view(B, T, ndir * _H)
-            dx = None
-            for d in range(ndir):
-                w_ih, w_hh, b_ih, b_hh = ws[4 * d: 4 * d + 4]
-                dgd = dg[d]                                                      # (M, 1024) bf16
-                # h of the previous step (in this direction's order), zero at the sequence start
-                hprev = torch.zeros(B, T, _H, device=dev, dtype=torch.bfloat16)
-                if d == 0:
-                    hprev[:, 1:] = hv[:, :-1, :_H]
-                else:
-                    hprev[:, :-1] = hv[:, 1:, _H:]
-                g_ih = st.wgrad_tn(dgd, inp16, 4 * _H, K)[:, :w_ih.shape[1]].contiguous()
-                g_hh = st.wgrad_tn(dgd, hprev.view(M, _H), 4 * _H, _H)
-                g_b = torch.empty(4 * _H, device=dev, dtype=torch.float32)
-                _lib.check(lib.se_colsum_bf16(_lib.ptr(dgd), M, 4 * _H, 4 * _H, _lib.ptr(g_b), _lib.stream()), 'se_colsum_bf16')
-                base = 4 * ndir * l + 4 * d
-                grads[base], grads[base + 1], grads[base + 2], grads[base + 3] = g_ih, g_hh, g_b, g_b.clone()
-                if l > 0:     # dx = sum over directions of dgates . W_ih ; the second direction rides the GEMM's residual input
-                    Din = ndir * _H
-                    wt = st.transpose_f32_bf16(w_ih.detach().float().contiguous(), 4 * _H)      # (Din, 1024) = W_ih^T
-                    nxt = torch.empty(M, Din, device=dev, dtype=torch.float32)
-                    _lib.check(lib.se_gemm_bf16(_lib.ptr(dgd), 4 * _H, _lib.ptr(wt), 4 * _H, None, _lib.ptr(dx), M, Din, 4 * _H, 0, None, _lib.ptr(nxt),
-                                                Din, _lib.stream()), 'se_gemm_bf16')
-                    dx = nxt
-            dh = dx
+        grads = _lstm_backward(ctx.saved, ctx.meta, ctx.weights, d_out, per_utterance=False)
         ctx.saved = None
         return (None, None, None) + tuple(grads)
+
+
+def _wgrad(dY16, X16, N, K, groups, rows):
+    """dW = dY^T X over all rows (groups == 0) or per group of `rows` rows (per-utterance slabs of the TN kernel: (groups, N, K))."""
+    if not groups:
+        return st.wgrad_tn(dY16, X16, N, K)
+    lib = _lib.load()
+    slabs = torch.empty(groups, N, K, device=dY16.device, dtype=torch.float32)
+    _lib.check(lib.se_wgrad_tn_slabs_bf16(_lib.ptr(dY16), dY16.shape[1], _lib.ptr(X16), X16.shape[1], dY16.shape[0], N, K, rows, _lib.ptr(slabs), _lib.stream()),
+               'se_wgrad_tn_slabs_bf16')
+    return slabs
+
+
+def _colsum(x, cols, groups, rows):
+    lib = _lib.load()
+    is16 = x.dtype == torch.bfloat16
+    if not groups:
+        out = torch.empty(cols, device=x.device, dtype=torch.float32)
+        if is16:
+            _lib.check(lib.se_colsum_bf16(_lib.ptr(x), x.shape[0], cols, x.shape[1], _lib.ptr(out), _lib.stream()), 'se_colsum_bf16')
+        else:
+            _lib.check(lib.se_colsum_f32(_lib.ptr(x), x.shape[0], cols, x.shape[1], _lib.ptr(out), 0, _lib.stream()), 'se_colsum_f32')
+        return out
+    out = torch.empty(groups, cols, device=x.device, dtype=torch.float32)
+    _lib.check(lib.se_colsum_groups(_lib.ptr(x), int(is16), groups, rows, cols, x.shape[1], _lib.ptr(out), _lib.stream()), 'se_colsum_groups')
+    return out
+
+
+def _lstm_backward(saved, meta, weights, d_out, per_utterance=False):
+    """BPTT of the stacked (Bi)LSTM.  per_utterance: every reduction over the B T rows (weight gradients, biases) is taken per utterance
+    instead -- the recurrence is per utterance anyway, so ONE sweep yields all B parameter gradients (active-sampling scoring,
+    sampler.py:59-110, replaces B sequential backward passes); gradients then carry a leading B dimension."""
+    lib = _lib.load()
+    B, T, D, num_layers, ndir = meta
+    M = B * T
+    G = B if per_utterance else 0
+    dev = d_out.device
+    dh = d_out.reshape(M, ndir * _H).contiguous().float()
+    grads = [None] * len(weights)
+    for l in range(num_layers - 1, -1, -1):
+        inp16, h16, gates, cst = saved[l]
+        ws = weights[4 * ndir * l: 4 * ndir * (l + 1)]
+        K = inp16.shape[1]
+        wq = torch.stack([_pack_hh_bwd(ws[4 * d + 1]) for d in range(ndir)]).contiguous()
+        dg = torch.empty(ndir, M, 4 * _H, device=dev, dtype=torch.bfloat16)
+        _lib.check(lib.se_lstm_bwd_bf16(_lib.ptr(wq), _lib.ptr(gates), _lib.ptr(cst), _lib.ptr(dh), ndir * _H, B, T, ndir, _lib.ptr(dg),
+                                        _lib.stream()), 'se_lstm_bwd_bf16')
+        hv = h16.view(B, T, ndir * _H)
+        dx = None
+        for d in range(ndir):
+            w_ih, w_hh, b_ih, b_hh = ws[4 * d: 4 * d + 4]
+            dgd = dg[d]                                                      # (M, 1024) bf16
+            # h of the previous step (in this direction's order), zero at the sequence start
+            hprev = torch.zeros(B, T, _H, device=dev, dtype=torch.bfloat16)
+            if d == 0:
+                hprev[:, 1:] = hv[:, :-1, :_H]
+            else:
+                hprev[:, :-1] = hv[:, 1:, _H:]
+            g_ih = _wgrad(dgd, inp16, 4 * _H, K, G, T)[..., :w_ih.shape[1]].contiguous()
+            g_hh = _wgrad(dgd, hprev.view(M, _H), 4 * _H, _H, G, T)
+            g_b = _colsum(dgd, 4 * _H, G, T)
+            base = 4 * ndir * l + 4 * d
+            grads[base], grads[base + 1], grads[base + 2], grads[base + 3] = g_ih, g_hh, g_b, g_b.clone()
+            if l > 0:     # dx = sum over directions of dgates . W_ih ; the second direction rides the GEMM's residual input
+                Din = ndir * _H
+                wt = st.transpose_f32_bf16(w_ih.detach().float().contiguous(), 4 * _H)      # (Din, 1024) = W_ih^T
+                nxt = torch.empty(M, Din, device=dev, dtype=torch.float32)
+                _lib.check(lib.se_gemm_bf16(_lib.ptr(dgd), 4 * _H, _lib.ptr(wt), 4 * _H, None, _lib.ptr(dx), M, Din, 4 * _H, 0, None, _lib.ptr(nxt),
+                                            Din, _lib.stream()), 'se_gemm_bf16')
+                dx = nxt
+        dh = dx
+    return grads
 
 
 class _DenseLogExpFn(torch.autograd.Function):
@@ -138,23 +171,29 @@ class _DenseLogExpFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_pred, d_logp):
-        lib = _lib.load()
         x16, p, w = ctx.saved_tensors
-        M, K = x16.shape
-        N = p.shape[1]
-        NP = max(128, (N + 63) // 64 * 64)
-        dev = p.device
-        dp32 = torch.empty(M, N, device=dev, dtype=torch.float32)
-        dp16 = torch.empty(M, NP, device=dev, dtype=torch.bfloat16)
-        gp = None if d_pred is None else d_pred.reshape(M, N).contiguous().float()
-        gl = None if d_logp is None else d_logp.reshape(M, N).contiguous().float()
-        _lib.check(lib.se_spec_epilogue_bwd_f32(_lib.ptr(p), _lib.ptr(gp), _lib.ptr(gl), M, N, NP, 1, _lib.SE_ACT['Identity'], 0.0, _lib.ptr(dp32),
-                                                _lib.ptr(dp16), _lib.stream()), 'se_spec_epilogue_bwd_f32')
-        g_w = st.wgrad_tn(dp16, x16, NP, K)[:N].contiguous()
-        g_b = st.colsum(dp32)
-        wt = st.transpose_f32_bf16(w.detach().float().contiguous(), NP)             # (K, NP) = W^T zero padded
-        d_x = st._gemm(dp16, wt, None, M, K, NP).view(*ctx.lead, K)
-        return d_x, g_w, g_b
+        d_x, g_w, g_b = _dense_logexp_backward(x16, p, w, d_pred, d_logp, 0, 0)
+        return d_x.view(*ctx.lead, x16.shape[1]), g_w, g_b
+
+
+def _dense_logexp_backward(x16, p, w, d_pred, d_logp, groups, rows):
+    """backward of log_predicted = x W^T + b, predicted = exp(log_predicted); groups > 0: (W, b) gradients per group of `rows` rows."""
+    lib = _lib.load()
+    M, K = x16.shape
+    N = p.shape[1]
+    NP = max(128, (N + 63) // 64 * 64)
+    dev = p.device
+    dp32 = torch.empty(M, N, device=dev, dtype=torch.float32)
+    dp16 = torch.empty(M, NP, device=dev, dtype=torch.bfloat16)
+    gp = None if d_pred is None else d_pred.reshape(M, N).contiguous().float()
+    gl = None if d_logp is None else d_logp.reshape(M, N).contiguous().float()
+    _lib.check(lib.se_spec_epilogue_bwd_f32(_lib.ptr(p), _lib.ptr(gp), _lib.ptr(gl), M, N, NP, 1, _lib.SE_ACT['Identity'], 0.0, _lib.ptr(dp32),
+                                            _lib.ptr(dp16), _lib.stream()), 'se_spec_epilogue_bwd_f32')
+    g_w = _wgrad(dp16, x16, NP, K, groups, rows)[..., :N, :].contiguous()
+    g_b = _colsum(dp32, N, groups, rows)
+    wt = st.transpose_f32_bf16(w.detach().float().contiguous(), NP)             # (K, NP) = W^T zero padded
+    d_x = st._gemm(dp16, wt, None, M, K, NP)
+    return d_x, g_w, g_b
 
 
 class LSTM(nn.Module):
@@ -192,6 +231,26 @@ class LSTM(nn.Module):
         h = _LSTMFn.apply(features, self.num_layers, 2 if self.bidirectional else 1, *self._flat_weights())
         predicted, log_predicted = _DenseLogExpFn.apply(h, self.scaling_layer[0].weight, self.scaling_layer[0].bias)
         return predicted, {'log_predicted': log_predicted}
+
+    def per_utterance_gradients(self, features, d_log_predicted_fn):
+        """One forward + ONE backward sweep -> {parameter name: (B, *shape) fp32}: the gradient of each utterance's own loss (the
+        reference replays B sequential `loss_b.backward(retain_graph=True)` passes, sampler.py:84-109).
+        `d_log_predicted_fn(log_predicted (B, T, N)) -> (B, T, N)` returns, row block b, d loss_b / d log_predicted[b]."""
+        import types
+        ndir = 2 if self.bidirectional else 1
+        weights = self._flat_weights()
+        B, T, _ = features.shape
+        with torch.no_grad():
+            c1, c2 = types.SimpleNamespace(), types.SimpleNamespace(save_for_backward=lambda *t: setattr(c2, 'saved_tensors', t))
+            h = _LSTMFn.forward(c1, features, self.num_layers, ndir, *weights)
+            w, b = self.scaling_layer[0].weight, self.scaling_layer[0].bias
+            _, logp = _DenseLogExpFn.forward(c2, h, w, b)
+            x16, p, _w = c2.saved_tensors
+            d_h, g_w, g_b = _dense_logexp_backward(x16, p, w, None, d_log_predicted_fn(logp), B, T)
+            grads = _lstm_backward(c1.saved, c1.meta, weights, d_h, per_utterance=True)
+        by_param = {id(pw): g for pw, g in zip(weights, grads)}
+        by_param[id(w)], by_param[id(b)] = g_w, g_b
+        return {n: by_param[id(pm)] for n, pm in self.named_parameters()}
 
 
 class Residual(nn.Module):

@@ -5,7 +5,12 @@ collecting each utterance's flattened parameter gradient; `matching` turns them 
 gradient.  Here ONE backward sweep produces all B gradients: the row-wise parts of the backward (epilogue, LayerNorm, GELU)
 are per-frame anyway, and the weight gradients come out of the TN weight-gradient kernel as its per-split slabs with the
 split boundaries on utterance boundaries (se_wgrad_tn_slabs_bf16) -- no reduce, no retain_graph, no B-fold replay.
-Implemented for the `SpecHead` downstream model (model.py:94-126), whose `log_predicted` the L1 criterion scores."""
+Implemented for the downstream models whose `log_predicted` the reference's `scoring` reads (sampler.py:72): `SpecHead` (model.py:94-126,
+per_sample_gradients) and `LSTM` (model.py:37-59 -- the head run_active.sh:11 actually scores; per_sample_gradients_lstm, with the
+`active_layerid` filter of sampler.py:91-100).  `LinearResidual` / `Residual` return `offset`, not `log_predicted`: the reference's own
+`scoring` raises KeyError on them, so there is nothing to mirror."""
+import re
+
 import torch
 
 from . import _lib
@@ -13,13 +18,44 @@ from . import spechead_train as st
 
 
 def _colsum_groups(x, groups, rows):
-    """(groups * rows, C) fp32 -> (groups, C): per-utterance bias gradients."""
+    """(groups * rows, C) fp32 -> (groups, C): per-utterance bias gradients, one grouped launch."""
     lib = _lib.load()
     C = x.shape[1]
     out = torch.empty(groups, C, device=x.device, dtype=torch.float32)
-    for g in range(groups):
-        _lib.check(lib.se_colsum_f32(_lib.ptr(x) + g * rows * C * 4, rows, C, C, _lib.ptr(out) + g * C * 4, 0, _lib.stream()), 'se_colsum_f32')
+    _lib.check(lib.se_colsum_groups(_lib.ptr(x), 0, groups, rows, C, C, _lib.ptr(out), _lib.stream()), 'se_colsum_groups')
     return out
+
+
+def _l1_row_gradients(log_predicted, linear_tar, stft_lengths, eps):
+    """d L1_b / d log_predicted, row block b: masked sign / (frames_b * N)  (objective.py:103-117 on ONE utterance, as sampler.py:84-86 slices it)"""
+    lib = _lib.load()
+    B, T, N = log_predicted.shape
+    dev = log_predicted.device
+    lens = stft_lengths.to(dev, torch.int64).contiguous()
+    sums = torch.empty(2, device=dev, dtype=torch.float64)
+    sign = torch.empty(B * T, N, device=dev, dtype=torch.float32)
+    _lib.check(lib.se_l1_masked_f32(_lib.ptr(log_predicted.contiguous().float()), _lib.ptr(linear_tar.contiguous().float()), _lib.ptr(lens), B, T, N, float(eps),
+                                    _lib.ptr(sums), _lib.ptr(sign), _lib.stream()), 'se_l1_masked_f32')
+    return (sign.view(B, T * N) / (lens.clamp(min=1).float() * N)[:, None]).view(B, T, N)
+
+
+def per_sample_gradients_lstm(head, features, linear_tar, stft_lengths, active_layerid=None, eps=1e-10):
+    """head: lstm.LSTM; features (B, T, D); linear_tar (B, T, N); stft_lengths (B,).  Returns grads (B, P): row b = the flattened gradient of
+    utterance b's masked log-L1 wrt the head's parameters in named_parameters() order; with `active_layerid` only the nn.LSTM parameters of
+    that layer, selected by the reference's own pattern (sampler.py:91-100: re.search('lstm.*l(\\d+)', key))."""
+    if not features.is_cuda:
+        raise _lib.SEError('per_sample_gradients_lstm runs on MI355X only (no CPU fallback)')
+    B = features.shape[0]
+    by_name = head.per_utterance_gradients(features, lambda logp: _l1_row_gradients(logp, linear_tar, stft_lengths, eps))
+    cols = []
+    for key, _ in head.named_parameters():
+        if active_layerid is None:
+            cols.append(by_name[key].reshape(B, -1))
+        else:
+            pattern = re.search(r'lstm.*l(\d+)', key)
+            if pattern is not None and int(pattern.group().split('_')[-1][1:]) == active_layerid:
+                cols.append(by_name[key].reshape(B, -1))
+    return torch.cat(cols, dim=1)
 
 
 def per_sample_gradients(head, features, linear_tar, stft_lengths, eps=1e-10):

@@ -5,9 +5,10 @@ Row E2; parity unpinned vs the original S3PRL (source absent offline).
 
 Parameters on the GPU are updated by two HIP launches for the whole model (se_multi_sumsq_f32 + se_bertadam_step_f32:
 per-tensor norms, then clip + Adam + decay fused) instead of ~15 torch kernels per parameter tensor -- for the 43 M
-parameter Mockingjay fine-tune that is the difference between ~2 and ~1700 launches a step.  CPU parameters (the gloo
-tests, `--cpu` runs of the reference) keep the torch arithmetic below, which is also what the fused kernel is tested
-against."""
+parameter Mockingjay fine-tune that is the difference between ~2 and ~1700 launches a step.  The per-tensor torch arithmetic below is
+the restated algorithm for parameter sets the fused launch does not take (heterogeneous groups, non-contiguous gradients) and what the
+fused kernel is tested against; it runs where the parameters live.  There is no CPU product path: the downstream modules themselves
+raise on host tensors, so an optimizer over host parameters is only ever reached by the world-size-2 gloo test of the reduction logic."""
 import ctypes
 
 import torch

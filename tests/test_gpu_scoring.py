@@ -62,3 +62,71 @@ def test_per_sample_gradients_vs_sequential_autograd(gpu):
     m_ref = scoring.matching(ref[:2].float(), ref.float())
     assert (m_got - m_ref).abs().max().item() < 0.02
     assert torch.equal(scoring.thresholding(m_got), scoring.thresholding(m_ref))
+
+
+@pytest.mark.parametrize('active_layerid', [None, 1])
+def test_lstm_per_sample_gradients_vs_sequential_autograd(gpu, active_layerid):
+    """The head the reference's active runs score (run_active.sh:11 `--downstream LSTM`; pseudo_noise.yaml:50-53): ONE sweep with
+    per-utterance slabs / grouped sums vs the reference's procedure (sampler.py:84-109: one `loss_b.backward(retain_graph=True)` per
+    utterance, gradients concatenated in named_parameters order, `active_layerid` filtering nn.LSTM parameters by the reference's own
+    pattern), run on torch.nn.LSTM in fp64."""
+    import re
+    from speech_enhancement_by_s3prl_amd import scoring
+    from speech_enhancement_by_s3prl_amd.lstm import LSTM
+    torch.manual_seed(5)
+    B, T, D, N = 3, 70, 120, 201
+    head = LSTM(input_size=D, output_size=N, hidden_size=256, num_layers=2, bidirectional=True).to(gpu)
+    feats = torch.randn(B, T, D)
+    tar = torch.rand(B, T, N) + 0.05
+    lens = torch.tensor([70, 41, 9])
+    got = scoring.per_sample_gradients_lstm(head, feats.to(gpu), tar.to(gpu), lens.to(gpu), active_layerid=active_layerid).double().cpu()
+    # reference procedure in fp64
+    ref_lstm = torch.nn.LSTM(input_size=D, hidden_size=256, num_layers=2, batch_first=True, bidirectional=True).double()
+    ref_lin = torch.nn.Linear(512, N).double()
+    sd = {k: v.detach().double().cpu() for k, v in head.state_dict().items()}
+    ref_lstm.load_state_dict({k[len('lstm.'):]: v for k, v in sd.items() if k.startswith('lstm.')})
+    ref_lin.load_state_dict({'weight': sd['scaling_layer.0.weight'], 'bias': sd['scaling_layer.0.bias']})
+    named = [('lstm.' + n, p) for n, p in ref_lstm.named_parameters()] + [('scaling_layer.0.weight', ref_lin.weight), ('scaling_layer.0.bias', ref_lin.bias)]
+    assert [n for n, _ in named] == [n for n, _ in head.named_parameters()]
+    out, _ = ref_lstm(feats.double())
+    log_predicted = ref_lin(out)
+    masks = (torch.arange(T)[None] < lens[:, None]).long()
+    ref = []
+    for b in range(B):
+        loss = oobj.l1(log_predicted[b:b + 1], tar[b:b + 1].double(), masks[b:b + 1])
+        grads = torch.autograd.grad(loss, [p for _, p in named], retain_graph=True)
+        grad = []
+        for (key, _), g in zip(named, grads):
+            if active_layerid is None:
+                grad.append(g.reshape(-1))
+            else:
+                pattern = re.search(r'lstm.*l(\d+)', key)
+                if pattern is not None and int(pattern.group().split('_')[-1][1:]) == active_layerid:
+                    grad.append(g.reshape(-1))
+        ref.append(torch.cat(grad))
+    ref = torch.stack(ref)
+    assert got.shape == ref.shape
+    for b in range(B):
+        cos = torch.nn.functional.cosine_similarity(got[b], ref[b], dim=0).item()
+        ratio = (got[b].norm() / ref[b].norm()).item()
+        assert cos > 0.99, (b, cos)
+        assert abs(ratio - 1) < 0.05, (b, ratio)
+    m_got = scoring.matching(got[:2].float(), got.float())
+    m_ref = scoring.matching(ref[:2].float(), ref.float())
+    assert (m_got - m_ref).abs().max().item() < 0.03
+    assert torch.equal(scoring.thresholding(m_got), scoring.thresholding(m_ref))
+
+
+def test_colsum_groups(gpu):
+    from speech_enhancement_by_s3prl_amd import _lib as L
+    lib = L.load()
+    torch.manual_seed(1)
+    G, R, C = 5, 37, 201
+    x = torch.randn(G * R, C, device=gpu)
+    out = torch.empty(G, C, device=gpu)
+    L.check(lib.se_colsum_groups(L.ptr(x), 0, G, R, C, C, L.ptr(out), L.stream()), 'colsum_groups')
+    assert (out.double() - x.double().view(G, R, C).sum(1)).abs().max().item() < 1e-4
+    xb = torch.randn(G * R, 1024, device=gpu).bfloat16()
+    out = torch.empty(G, 1024, device=gpu)
+    L.check(lib.se_colsum_groups(L.ptr(xb), 1, G, R, 1024, 1024, L.ptr(out), L.stream()), 'colsum_groups')
+    assert (out.double() - xb.double().view(G, R, 1024).sum(1)).abs().max().item() < 1e-4
