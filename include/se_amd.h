@@ -87,6 +87,10 @@ int se_num_frames(const se_plan* plan, int n_samples);
  */
 int se_stft_f32(const se_plan* plan, const float* wavs, int B, int C, int T, int channel,
                 float* power, float* phase, float* complx, float* mel, void* stream);
+/* The same transform for TWO channels of the batch in one launch (the reference transforms the noisy and the clean channel of every batch,
+   runner.py:433,558: feat_list entries with channel_inp / channel_tar); each output set as above, any pointer may be NULL. */
+int se_stft2_f32(const se_plan* plan, const float* wavs, int B, int C, int T, int channel_a, float* power_a, float* phase_a, float* complx_a,
+                 float* mel_a, int channel_b, float* power_b, float* phase_b, float* complx_b, float* mel_b, void* stream);
 
 /*
  * se_features_f32 -- row A4: OnlinePreprocessor.forward's select_feat: log(x+eps), `delta` stacked

@@ -59,12 +59,21 @@ __device__ __forceinline__ float fast_atan2(float y, float x) {
   return copysignf(r, y);
 }
 
+// blockIdx.z selects one of up to two (channel, output set) jobs of the same launch: the reference transforms the noisy AND the clean channel
+// of every batch (runner.py:433,558); as two launches each was 1.4 rounds of the 768 resident workgroups at B = 32, together 2.8
+struct StftOut { float* power; float* phase; float* complx; float* mel; int channel; int vec_ok; };
+
 __global__ __launch_bounds__(kThreads) void stft_kernel(
-    const float* __restrict__ wavs, int C, int T, int channel, int F,
+    const float* __restrict__ wavs, int C, int T, int F,
     const float* __restrict__ window, const float2* __restrict__ tw400g, const float2* __restrict__ tw200g,
     const int* __restrict__ mel_start, const int* __restrict__ mel_len, const float* __restrict__ mel_w, int n_mels,
-    float* __restrict__ power, float* __restrict__ phase, float* __restrict__ complx, float* __restrict__ mel,
-    unsigned long long* __restrict__ dbgbuf, int vec_ok) {
+    StftOut job0, StftOut job1, unsigned long long* __restrict__ dbgbuf) {
+  const StftOut job = blockIdx.z ? job1 : job0;
+  const int channel = job.channel, vec_ok = job.vec_ok;
+  float* __restrict__ power = job.power;
+  float* __restrict__ phase = job.phase;
+  float* __restrict__ complx = job.complx;
+  float* __restrict__ mel = job.mel;
   __shared__ __attribute__((aligned(16))) float2 Y[kPlane];   // FFT buffer (30 x 200 complex), later the two output planes
   __shared__ float2 tw[kHalf];        // (cos, sin)(2 pi k / 400), k < 200: the recombination twiddles
   __shared__ float2 tw2[kHalf];       // (cos, sin)(2 pi t / 200): pass-A twiddles W200^(j q), j q <= 168
@@ -300,25 +309,42 @@ __global__ __launch_bounds__(kThreads) void stft_kernel(
 
 }  // namespace se
 
+static int stft_launch(const se_plan* plan, const float* wavs, int B, int C, int T, const se::StftOut* jobs, int njobs, unsigned long long* dbgbuf, void* stream) {
+  const int F = T / se::kHop + 1;
+  dim3 grid((F + se::kFR - 1) / se::kFR, B, njobs);
+  double bytes = 0.0;
+  for (int j = 0; j < njobs; ++j)      // algorithmic bytes: 4 T in + 4 F K per written plane
+    bytes += (double)B * (4.0 * T + 4.0 * F * se::kBins * ((jobs[j].power != nullptr) + (jobs[j].phase != nullptr) + 2 * (jobs[j].complx != nullptr)) +
+                          (jobs[j].mel ? 4.0 * F * plan->geom.n_mels : 0.0));
+  se::ProfScope prof(se::kProfStft, bytes, se::as_stream(stream));
+  hipLaunchKernelGGL(se::stft_kernel, grid, dim3(se::kThreads), 0, se::as_stream(stream), wavs, C, T, F, plan->d_window, plan->d_tw400, plan->d_tw200,
+                     plan->d_mel_start, plan->d_mel_len, plan->d_mel_w, plan->geom.n_mels, jobs[0], jobs[njobs > 1 ? 1 : 0], dbgbuf);
+  SE_LAUNCH_CHECK();
+  return SE_OK;
+}
+
 extern "C" int se_stft_f32(const se_plan* plan, const float* wavs, int B, int C, int T, int channel,
                            float* power, float* phase, float* complx, float* mel, void* stream) {
   SE_REQUIRE(plan && wavs, "se_stft_f32: null plan / wavs");
   SE_REQUIRE(B > 0 && C > 0 && channel >= 0 && channel < C, "se_stft_f32: bad B=%d C=%d channel=%d", B, C, channel);
   SE_REQUIRE(T > se::kHalf, "se_stft_f32: T=%d must exceed n_fft/2=%d (reflect padding)", T, se::kHalf);
   SE_REQUIRE(B <= 65535, "se_stft_f32: B=%d exceeds grid.y limit", B);
-  const int F = T / se::kHop + 1;
-  dim3 grid((F + se::kFR - 1) / se::kFR, B);
-  const int vec_ok = (((uintptr_t)power | (uintptr_t)phase) % 16) == 0;
   unsigned long long* dbgbuf = nullptr;
   if (getenv("SE_AMD_STFT_DBG") && complx) {      // developer stamps ride in the `complx` buffer
     dbgbuf = reinterpret_cast<unsigned long long*>(complx);
     complx = nullptr;
   }
-  // algorithmic bytes: 4 T in + 4 F K per written plane
-  se::ProfScope prof(se::kProfStft, (double)B * (4.0 * T + 4.0 * F * se::kBins * ((power != nullptr) + (phase != nullptr) + 2 * (complx != nullptr)) + (mel ? 4.0 * F * plan->geom.n_mels : 0.0)), se::as_stream(stream));
-  hipLaunchKernelGGL(se::stft_kernel, grid, dim3(se::kThreads), 0, se::as_stream(stream), wavs, C, T, channel, F,
-                     plan->d_window, plan->d_tw400, plan->d_tw200, plan->d_mel_start, plan->d_mel_len, plan->d_mel_w,
-                     plan->geom.n_mels, power, phase, complx, mel, dbgbuf, vec_ok);
-  SE_LAUNCH_CHECK();
-  return SE_OK;
+  const se::StftOut job{power, phase, complx, mel, channel, (((uintptr_t)power | (uintptr_t)phase) % 16) == 0};
+  return stft_launch(plan, wavs, B, C, T, &job, 1, dbgbuf, stream);
+}
+
+extern "C" int se_stft2_f32(const se_plan* plan, const float* wavs, int B, int C, int T, int channel_a, float* power_a, float* phase_a, float* complx_a,
+                            float* mel_a, int channel_b, float* power_b, float* phase_b, float* complx_b, float* mel_b, void* stream) {
+  SE_REQUIRE(plan && wavs, "se_stft2_f32: null plan / wavs");
+  SE_REQUIRE(B > 0 && C > 0 && channel_a >= 0 && channel_a < C && channel_b >= 0 && channel_b < C, "se_stft2_f32: bad B=%d C=%d channels=%d,%d", B, C, channel_a, channel_b);
+  SE_REQUIRE(T > se::kHalf, "se_stft2_f32: T=%d must exceed n_fft/2=%d (reflect padding)", T, se::kHalf);
+  SE_REQUIRE(B <= 65535, "se_stft2_f32: B=%d exceeds grid.y limit", B);
+  const se::StftOut jobs[2] = {{power_a, phase_a, complx_a, mel_a, channel_a, (((uintptr_t)power_a | (uintptr_t)phase_a) % 16) == 0},
+                               {power_b, phase_b, complx_b, mel_b, channel_b, (((uintptr_t)power_b | (uintptr_t)phase_b) % 16) == 0}};
+  return stft_launch(plan, wavs, B, C, T, jobs, 2, nullptr, stream);
 }

@@ -128,6 +128,31 @@ class OnlinePreprocessor(nn.Module):
                                    _lib.stream()), 'se_stft_f32')
         return out
 
+    def _alloc_planes(self, B, F, need, dev):
+        K = self._n_freq
+        out = {}
+        if 'linear' in need:
+            out['linear'] = torch.empty(B, F, K, device=dev, dtype=torch.float32)
+        if 'phase' in need:
+            out['phase'] = torch.empty(B, F, K, device=dev, dtype=torch.float32)
+        if 'complx' in need:
+            out['complx'] = torch.empty(B, F, 2 * K, device=dev, dtype=torch.float32)
+        if 'mel' in need:
+            out['mel'] = torch.empty(B, self._n_mels, F, device=dev, dtype=torch.float32)
+        return out
+
+    def _stft_two_channels(self, wavs, need):
+        """One se_stft2_f32 launch for the two channels of `need` = {channel: kinds}."""
+        lib = _lib.load()
+        B, C, T = wavs.shape
+        F = T // self._win_args['hop_length'] + 1
+        (ca, ka), (cb, kb) = sorted(need.items())
+        oa, ob = self._alloc_planes(B, F, ka, wavs.device), self._alloc_planes(B, F, kb, wavs.device)
+        g = lambda o, k: _lib.ptr(o.get(k))       # noqa: E731
+        _lib.check(lib.se_stft2_f32(self._plan(wavs.device), _lib.ptr(wavs), B, C, T, ca, g(oa, 'linear'), g(oa, 'phase'), g(oa, 'complx'), g(oa, 'mel'),
+                                    cb, g(ob, 'linear'), g(ob, 'phase'), g(ob, 'complx'), g(ob, 'mel'), _lib.stream()), 'se_stft2_f32')
+        return {ca: oa, cb: ob}
+
     def _select(self, raw, raw_time_major, log, delta, cmvn):
         """se_features_f32: raw (B, D, F) feature-major or (B, F, D) time-major -> (B, F, D*(1+delta))."""
         lib = _lib.load()
@@ -163,7 +188,10 @@ class OnlinePreprocessor(nn.Module):
             if ft == 'mfcc':
                 raise NotImplementedError("feat_type 'mfcc' is not on the reference's configured path (SURVEY A5)")
             need.setdefault(int(a.get('channel', 0)), set()).add(ft)
-        planes = {ch: self._stft_channel(wavs3, ch, kinds) for ch, kinds in need.items()}
+        if len(need) == 2:       # the reference's standard list (noisy + clean channel): both transforms in ONE launch
+            planes = self._stft_two_channels(wavs3, need)
+        else:
+            planes = {ch: self._stft_channel(wavs3, ch, kinds) for ch, kinds in need.items()}
 
         feats = []
         for a in feat_list:
