@@ -255,6 +255,16 @@ int se_mhsa_fwd_bf16(const uint16_t* qkv, const int32_t* lengths, int B, int T, 
    fused QKV weights folds it into the query rows before their bf16 rounding), i.e. ctx = softmax_base2(Q' K^T + pad-mask) V.  Inference
    only; two-tile software pipeline with the running maximum carried as the MFMA C operand (csrc/mhsa.hip: mhsa_fwd2_kernel). */
 int se_mhsa_fwd_prescaled_bf16(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, void* stream);
+/* Row-complete projection on the encoder's 24-bit residual stream (bf16 hi rows + int8 lo bytes, tile-major: csrc/gemm4.hip), exported for
+ * tests / measurement: x = LayerNorm(A . W^T + bias + residual), out as fp32 rows or as (bf16, lo).  variant 0 = the encoder's dispatch,
+ * 7 = 128 x 768 tiles, 8 = 256 x 384 tiles with the LayerNorm statistics exchanged between the two column halves (csrc/gemm8.hip).
+ * scratch: se_gemm_res24_scratch_bytes() zeroed bytes; lo buffers: se_gemm_res24_lo_bytes(M) bytes. */
+size_t se_gemm_res24_scratch_bytes(void);
+size_t se_gemm_res24_lo_bytes(int M);
+int se_gemm_res24_ln_bf16(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias, const uint16_t* res_hi, const uint8_t* res_lo,
+                          const float* ln_w, const float* ln_b, float eps, int M, int N, int K, float* out_f32, uint16_t* out_bf16, uint8_t* out_lo,
+                          int variant, void* scratch, void* stream);
+
 /* y = LN(x) * w + b over the last dim H (TF style, eps inside sqrt); x fp32 (M,H); outputs fp32 and/or bf16. */
 int se_layernorm_f32(const float* x, const float* w, const float* b, int M, int H, float eps,
                      float* out_f32, uint16_t* out_bf16, void* stream);

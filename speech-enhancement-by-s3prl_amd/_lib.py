@@ -78,6 +78,9 @@ SIGNATURES = {
     'se_valid_lengths_i32': (c_int, [_P, c_int, c_int, c_int, _P, _P]),
     'se_gemm_bf16': (c_int, [_P, c_int, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, _P, _P, c_int, _P]),
     'se_gemm_res_ln_bf16': (c_int, [_P, c_int, _P, c_int, _P, _P, _P, _P, c_float, c_int, c_int, c_int, _P, _P, _P]),
+    'se_gemm_res24_scratch_bytes': (c_size_t, []),
+    'se_gemm_res24_lo_bytes': (c_size_t, [c_int]),
+    'se_gemm_res24_ln_bf16': (c_int, [_P, c_int, _P, c_int, _P, _P, _P, _P, _P, c_float, c_int, c_int, c_int, _P, _P, _P, c_int, _P, _P]),
     'se_mhsa_fwd_bf16': (c_int, [_P, _P, c_int, c_int, c_int, _P, _P]),
     'se_mhsa_fwd_prescaled_bf16': (c_int, [_P, _P, c_int, c_int, c_int, _P, _P]),
     'se_layernorm_f32': (c_int, [_P, _P, _P, c_int, c_int, c_float, _P, _P, _P]),

@@ -532,6 +532,7 @@ struct Ws {
   uint16_t *xin, *x_bf, *qkv, *ctx, *h;
   float *x_f32, *tmp, *slabs;
   uint8_t* lo;           // low bytes of the 24-bit residual stream (row-complete path)
+  char* g8;              // gemm8's statistics slabs + flags
   size_t total;
 };
 constexpr size_t kSplitKRows = 3072;   // small-batch path: split-K FFN2 up to this many rows (B = 1: 0.73 vs 0.85 ms, B = 2: 0.84 vs 0.93; B = 4: no gain)
@@ -551,6 +552,7 @@ Ws carve(const se_encoder* e, size_t M, char* base) {
   w.h = (uint16_t*)take(M * I * 2);
   w.slabs = (float*)take(M <= kSplitKRows ? (size_t)kSplitK * M * H * 4 : 0);
   w.lo = (uint8_t*)take(H == 768 ? se::gemm4_lo_bytes((int)M) : 0);
+  w.g8 = take(H == 768 ? se::gemm8_scratch_bytes() : 0);
   w.total = off;
   return w;
 }
@@ -591,6 +593,10 @@ extern "C" int se_encoder_fwd_bf16(const se_encoder* enc, const float* feats, co
   // B = 1: 8 workgroups, 0.85 vs 1.70 ms).  SE_AMD_FUSED_LN = 2 forces it.  Between its launches the residual stream travels as
   // bf16 + int8 (24 bits, gemm4.hip) instead of fp32 + bf16: 196 instead of 295 MB per K = 768 launch.
   const bool fused = fuse_env && H == 768 && I % 32 == 0 && I >= 128 && (fuse_env == 2 || M >= (enc->cfg.fused_ln_min_rows > 0 ? enc->cfg.fused_ln_min_rows : 24576));
+  if (fused) {      // gemm8's pair flags + error word start every pass at zero (each launch also leaves them zero)
+    const size_t fo = se::gemm8_scratch_bytes() - (128 * 2 * 4 + 256);
+    if ((rc = se::zero_async(w.g8 + fo, 128 * 2 * 4 + 256, st))) return rc;
+  }
   if (fused) {
     // one row-complete kernel: the positional table rides the residual input (row index modulo T)
     if ((rc = se::launch_gemm_pos_ln(w.xin, se::kInPad, enc->in_w, se::kInPad, enc->in_b, enc->pe, T, enc->in_ln_w, enc->in_ln_b, enc->cfg.ln_eps, M, H,
@@ -616,8 +622,12 @@ extern "C" int se_encoder_fwd_bf16(const se_encoder* enc, const float* feats, co
     // B3
     if ((rc = se_gemm_bf16(w.x_bf, H, y.ff1_w, H, y.ff1_b, nullptr, M, I, H, SE_ACT_GELU, w.h, nullptr, I, stream))) return rc;
     if (fused) {      // the last layer leaves the stream as the fp32 `hidden` the caller asked for
-      if (i == L - 1) rc = se::launch_gemm_res24_ln(w.h, I, y.ff2_w, I, y.ff2_b, w.x_bf, w.lo, y.oln_w, y.oln_b, enc->cfg.ln_eps, M, H, I, hidden, nullptr, nullptr, st);
-      else rc = se::launch_gemm_res24_ln(w.h, I, y.ff2_w, I, y.ff2_b, w.x_bf, w.lo, y.oln_w, y.oln_b, enc->cfg.ln_eps, M, H, I, nullptr, w.x_bf, w.lo, st);
+      float* of = (i == L - 1) ? hidden : nullptr;
+      uint16_t* ob = (i == L - 1) ? nullptr : w.x_bf;
+      uint8_t* ol = (i == L - 1) ? nullptr : w.lo;
+      // 256 x 384 tiles with the LayerNorm statistics exchanged between the two column halves (gemm8.hip) where it applies, else 128 x 768
+      rc = se::launch_gemm8_res24_ln(w.h, I, y.ff2_w, I, y.ff2_b, w.x_bf, w.lo, y.oln_w, y.oln_b, enc->cfg.ln_eps, M, H, I, of, ob, ol, w.g8, st);
+      if (rc == 1) rc = se::launch_gemm_res24_ln(w.h, I, y.ff2_w, I, y.ff2_b, w.x_bf, w.lo, y.oln_w, y.oln_b, enc->cfg.ln_eps, M, H, I, of, ob, ol, st);
       if (rc) return rc;
     } else {
       float* xo = (i == L - 1) ? hidden : w.x_f32;

@@ -21,6 +21,7 @@
 #include "common.h"
 #include "bf16.h"
 #include "prof.h"
+#include "encoder_impl.h"
 
 namespace se {
 
@@ -620,3 +621,23 @@ int launch_gemm_res24_ln(const uint16_t* A, int lda, const uint16_t* W, int ldw,
 }
 size_t gemm4_lo_bytes(int M) { return (size_t)((M + k4BM - 1) / k4BM) * k4BM * k4N; }
 }  // namespace se
+
+// test / measurement surface of the row-complete projection on the 24-bit stream: variant 0 = what the encoder would pick, 7 = the 128 x 768
+// tile (gemm7 / gemm4), 8 = the 256 x 384 pair-exchange tile (gemm8, forced at any size); scratch: se_gemm_res24_scratch_bytes() bytes, zeroed
+extern "C" size_t se_gemm_res24_scratch_bytes(void) { return se::gemm8_scratch_bytes(); }
+extern "C" size_t se_gemm_res24_lo_bytes(int M) { return se::gemm4_lo_bytes(M); }
+extern "C" int se_gemm_res24_ln_bf16(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias, const uint16_t* res_hi, const uint8_t* res_lo,
+                                     const float* ln_w, const float* ln_b, float eps, int M, int N, int K, float* out_f32, uint16_t* out_bf16, uint8_t* out_lo,
+                                     int variant, void* scratch, void* stream) {
+  SE_REQUIRE(A && W && res_hi && res_lo && ln_w && ln_b && (out_f32 || out_bf16), "se_gemm_res24_ln_bf16: null argument");
+  hipStream_t st = se::as_stream(stream);
+  if (variant == 0 || variant == 8) {
+    const int rc = se::launch_gemm8_res24_ln(A, lda, W, ldw, bias, res_hi, res_lo, ln_w, ln_b, eps, M, N, K, out_f32, out_bf16, out_lo, scratch, st, variant == 8);
+    if (rc != 1) return rc;
+    if (variant == 8) {
+      se::set_error("se_gemm_res24_ln_bf16: the 256 x 384 pair-exchange kernel does not take this call (N=%d K=%d M=%d)", N, K, M);
+      return SE_ERR_UNSUPPORTED;
+    }
+  }
+  return se::launch_gemm_res24_ln(A, lda, W, ldw, bias, res_hi, res_lo, ln_w, ln_b, eps, M, N, K, out_f32, out_bf16, out_lo, st);
+}

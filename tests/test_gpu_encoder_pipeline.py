@@ -197,10 +197,10 @@ def test_enhance_step_odd_shapes(gpu, small, n_samples, B):
 
 def test_bench_shape_default_dispatch_vs_oracle(gpu):
     """The shape and dispatch the headline bench times (runner.py:556-575 at B = 32, T' = 1001: 32 032 rows -> persistent 256 x 256 GEMMs for
-    QKV / FFN1, the row-complete GEMM + LayerNorm kernels on the 24-bit residual stream, the pre-scaled attention kernel), one encoder layer
-    + the spec head to bound the oracle's time, against the fp32 CPU oracle."""
+    QKV / FFN1, the row-complete GEMM + LayerNorm kernels on the 24-bit residual stream incl. the 256 x 384 pair-exchange kernel for FFN2, the
+    pre-scaled attention kernel), two encoder layers + the spec head to bound the oracle's time, against the fp32 CPU oracle."""
     from speech_enhancement_by_s3prl_amd import pipeline, synth
-    cfg = pipeline.make_config(layers=1)
+    cfg = pipeline.make_config(layers=2)               # two layers: both output forms of the FFN-output kernel (24-bit stream out / fp32 out)
     ckpt = pipeline.synthetic_checkpoint(cfg, seed=7)
     up = pipeline.build_upstream(ckpt, gpu)
     pre = pipeline.build_preprocessor(cfg, gpu)

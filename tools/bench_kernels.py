@@ -162,6 +162,27 @@ def bench_gemm_ln():
         print(f'gemm+res+LN M={M} N={N} K={K}: {ms*1e3:8.1f} us  {2.0*M*N*K/ms/1e9:8.1f} TF/s', flush=True)
 
 
+def bench_res24():
+    """FFN-output / attention-output projections on the 24-bit stream: 128 x 768 tiles (variant 7) vs the 256 x 384 pair-exchange tiles (8)"""
+    M, N = 32 * 1001, 768
+    for K in (768, 3072):
+        A = torch.randn(M, K, device=dev).bfloat16()
+        W = (torch.randn(N, K, device=dev) * 0.05).bfloat16()
+        bias, res = torch.randn(N, device=dev), torch.randn(M, N, device=dev).bfloat16()
+        nlo = lib.se_gemm_res24_lo_bytes(M)
+        rlo = torch.zeros(nlo, device=dev, dtype=torch.uint8)
+        lw, lb = torch.ones(N, device=dev), torch.zeros(N, device=dev)
+        o16 = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+        olo = torch.empty(nlo, device=dev, dtype=torch.uint8)
+        scratch = torch.zeros(lib.se_gemm_res24_scratch_bytes(), device=dev, dtype=torch.uint8)
+        for variant in (7, 8):
+            def run():
+                L.check(lib.se_gemm_res24_ln_bf16(L.ptr(A), K, L.ptr(W), K, L.ptr(bias), L.ptr(res), L.ptr(rlo), L.ptr(lw), L.ptr(lb), 1e-12, M, N, K, None,
+                                                  L.ptr(o16), L.ptr(olo), variant, L.ptr(scratch), L.stream()), 'res24')
+            ms = timeit(run)
+            print(f'gemm+res24+LN variant {variant} M={M} K={K}: {ms*1e3:8.1f} us  {2.0*M*N*K/ms/1e9:8.1f} TF/s', flush=True)
+
+
 def bench_mhsa():
     B, T, heads = 32, 1001, 12
     qkv = (torch.randn(B * T, 3 * 768, device=dev)).bfloat16()
@@ -210,6 +231,8 @@ if __name__ == '__main__':
         bench_gemm_qkv()
     if what in ('gemmln', 'all'):
         bench_gemm_ln()
+    if what in ('res24', 'all'):
+        bench_res24()
     if what in ('mhsa', 'all'):
         bench_mhsa()
     if what in ('stft', 'all'):
