@@ -361,6 +361,12 @@ int se_encoder_fwd_train_bf16(const se_encoder* enc, const float* feats, const i
 int se_encoder_bwd_bf16(const se_encoder* enc, const int32_t* lengths, int B, int T, const float* d_hidden, const void* saved,
                         size_t saved_bytes, const se_encoder_grads* grads, void* workspace, size_t workspace_bytes, float dropout_p,
                         uint64_t seed, void* stream);
+/* The same backward with a host callback after each layer's launches are enqueued (layer L-1 first, -1 = input stage): that layer's
+   parameter gradients are then ordered on `stream`, so a data-parallel caller can start the layer's gradient all-reduce while the
+   remaining layers' kernels run (dist.py: bucketed overlap).  layer_done may be NULL. */
+int se_encoder_bwd_cb_bf16(const se_encoder* enc, const int32_t* lengths, int B, int T, const float* d_hidden, const void* saved,
+                           size_t saved_bytes, const se_encoder_grads* g, void* workspace, size_t workspace_bytes, float dropout_p,
+                           uint64_t seed, void (*layer_done)(int layer, void* user), void* user, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Optimizer side of row E2 (runner.py:463-471): gradient norms and BertAdam for all parameter tensors in two launches.

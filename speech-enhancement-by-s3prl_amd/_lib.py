@@ -47,6 +47,7 @@ class EncoderGrads(ctypes.Structure):
 
 
 _P = c_void_p
+LAYER_DONE_CB = ctypes.CFUNCTYPE(None, c_int, c_void_p)      # se_encoder_bwd_cb_bf16's host callback
 # name -> (restype, argtypes); mirrors include/se_amd.h one to one
 SIGNATURES = {
     'se_last_error': (c_char_p, []),
@@ -108,6 +109,7 @@ SIGNATURES = {
     'se_encoder_train_workspace_bytes': (c_size_t, [_P, c_int, c_int]),
     'se_encoder_fwd_train_bf16': (c_int, [_P, _P, _P, c_int, c_int, _P, _P, c_size_t, _P, c_size_t, c_float, ctypes.c_uint64, _P]),
     'se_encoder_bwd_bf16': (c_int, [_P, _P, c_int, c_int, _P, _P, c_size_t, POINTER(EncoderGrads), _P, c_size_t, c_float, ctypes.c_uint64, _P]),
+    'se_encoder_bwd_cb_bf16': (c_int, [_P, _P, c_int, c_int, _P, _P, c_size_t, POINTER(EncoderGrads), _P, c_size_t, c_float, ctypes.c_uint64, _P, _P, _P]),
     'se_multi_sumsq_f32': (c_int, [_P, _P, c_int, _P, _P]),
     'se_bertadam_step_f32': (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, c_double, c_double, c_double, c_double, c_double, c_double, _P]),
     'se_multi_copy_f32': (c_int, [_P, _P, _P, c_int, _P]),

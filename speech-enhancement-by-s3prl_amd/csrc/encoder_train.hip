@@ -326,6 +326,15 @@ int input_grad(const uint16_t* dY, const uint16_t* W, int M, int N, int K, const
 extern "C" int se_encoder_bwd_bf16(const se_encoder* enc, const int32_t* lengths, int B, int T, const float* d_hidden, const void* saved,
                                    size_t saved_bytes, const se_encoder_grads* g, void* workspace, size_t workspace_bytes, float dropout_p,
                                    uint64_t seed, void* stream) {
+  return se_encoder_bwd_cb_bf16(enc, lengths, B, T, d_hidden, saved, saved_bytes, g, workspace, workspace_bytes, dropout_p, seed, nullptr, nullptr, stream);
+}
+
+// The same backward with a HOST callback after each layer's launches have been enqueued (layer L-1 first; -1 = the input stage): every
+// parameter gradient of that layer is then ordered on `stream`, so a data-parallel caller can start that layer's gradient all-reduce
+// (RCCL picks up the stream order) while the remaining layers' backward kernels run -- bucketed overlap instead of one collective at the end.
+extern "C" int se_encoder_bwd_cb_bf16(const se_encoder* enc, const int32_t* lengths, int B, int T, const float* d_hidden, const void* saved,
+                                      size_t saved_bytes, const se_encoder_grads* g, void* workspace, size_t workspace_bytes, float dropout_p,
+                                      uint64_t seed, void (*layer_done)(int layer, void* user), void* user, void* stream) {
   SE_REQUIRE(enc && d_hidden && saved && g && workspace, "se_encoder_bwd_bf16: null argument");
   SE_TRY(check_train_shape(enc, B, T, "se_encoder_bwd_bf16"));
   SE_REQUIRE(saved_bytes >= se_encoder_saved_bytes(enc, B, T), "se_encoder_bwd_bf16: saved buffer too small");
@@ -379,11 +388,13 @@ extern "C" int se_encoder_bwd_bf16(const se_encoder* enc, const int32_t* lengths
     }
     SE_TRY(input_grad(w.b3, y.qkv_w, M, 3 * H, H, w.fa, nullptr, w.fb, w, stream));                // dx0 = dqkv Wqkv + dpre1
     gy = w.fb;
+    if (layer_done) layer_done(i, user);
   }
   // ---- input stage:  x = LN(xin Win^T + b + PE)
   SE_TRY(se::launch_layernorm_bwd(s.pre0, enc->pe, T, gy, enc->in_ln_w, M, H, eps, 0, w.fa, w.b1, g->in_ln_w, g->in_ln_b, g->in_b, 0, st,
                                   dkey(L, 0), 0, dr.thr16, dr.scale));
   SE_TRY(weight_grad(w.b1, H, s.xin, se::kInPad, M, H, se::kInPad, w.gfused, w, stream));
   SE_HIP(hipMemcpy2DAsync(g->in_w, (size_t)D * 4, w.gfused, (size_t)se::kInPad * 4, (size_t)D * 4, H, hipMemcpyDeviceToDevice, st));
+  if (layer_done) layer_done(-1, user);
   return SE_OK;
 }

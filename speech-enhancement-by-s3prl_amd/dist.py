@@ -69,11 +69,13 @@ class FlatGradAllReducer:
             self.views.append(self.flat[off:off + p.numel()].view_as(p))
             off += p.numel()
 
-    def _gather(self):
-        """per-parameter gradients -> the flat buffer.  On the GPU: ONE batched copy launch (se_multi_copy_f32) instead of a torch
+    def _gather(self, skip=()):
+        """per-parameter gradients -> the flat buffer (`skip`: parameter indices whose views were written in place by the backward).  On the GPU: ONE batched copy launch (se_multi_copy_f32) instead of a torch
         copy kernel per tensor (~100 launches per step for the Mockingjay encoder)."""
         if not self.flat.is_cuda:
-            for p, v in zip(self.params, self.views):
+            for i, (p, v) in enumerate(zip(self.params, self.views)):
+                if i in skip:
+                    continue
                 if p.grad is None:
                     v.zero_()
                 else:
@@ -82,7 +84,9 @@ class FlatGradAllReducer:
         import ctypes
         from . import _lib
         src, dst, sizes, keep = [], [], [], []
-        for p, v in zip(self.params, self.views):
+        for i, (p, v) in enumerate(zip(self.params, self.views)):
+            if i in skip:
+                continue
             g = p.grad
             if g is None:
                 v.zero_()
@@ -103,11 +107,28 @@ class FlatGradAllReducer:
                 _lib.check(lib.se_multi_copy_f32((ctypes.c_void_p * n)(*dst), (ctypes.c_void_p * n)(*src), (ctypes.c_uint64 * n)(*sizes), n,
                                                  _lib.stream()), 'se_multi_copy_f32')
 
-    def reduce(self, copy_back=True):
-        """copy_back=False leaves the reduced gradients in the flat buffer's views only (the fused optimizer reads them there)."""
-        self._gather()
+    def reduce(self, copy_back=True, sink=None):
+        """copy_back=False leaves the reduced gradients in the flat buffer's views only (the fused optimizer reads them there).
+        sink: a BucketedGradSink whose buckets were already written in place and all-reduced during the backward: only the rest of the
+        buffer (parameters outside the encoder trunk) is gathered and reduced here."""
+        done = sink.done if sink is not None else set()
+        self._gather(skip=done)
         if is_distributed():
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            if not done:
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            else:
+                rest = [i for i in range(len(self.params)) if i not in done]
+                lo = None
+                for i in rest + [None]:          # contiguous runs of the remaining parameters
+                    if lo is not None and (i is None or i != prev + 1):
+                        a = sink.offsets[lo]
+                        b = sink.offsets[prev] + self.params[prev].numel()
+                        dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM)
+                        lo = None
+                    if i is not None and lo is None:
+                        lo = i
+                    prev = i
+                sink.wait()
         if copy_back:
             for p, v in zip(self.params, self.views):
                 if p.grad is None:
@@ -115,6 +136,60 @@ class FlatGradAllReducer:
                 else:
                     p.grad.copy_(v)
         return self.flat
+
+
+class BucketedGradSink:
+    """Gradient sink for the encoder's HIP backward (transformer._EncoderTrainFn): the backward kernels write each parameter's gradient
+    straight into its view of the reducer's flat buffer, and after every encoder layer (host callback of se_encoder_bwd_cb_bf16, last layer
+    first) that layer's contiguous slice of the buffer is all-reduced asynchronously: the collective is ordered behind the layer's kernels
+    on the stream and runs under the backward of the layers still to come, instead of one 173 MB all-reduce after the last of them
+    (Mockingjay, 6 layers: 6 x 28 MB + a tail).  Parameters outside the encoder trunk are reduced by FlatGradAllReducer.reduce() as before."""
+
+    def __init__(self, reducer):
+        self.reducer = reducer
+        self.by_param = {id(p): (i, v) for i, (p, v) in enumerate(zip(reducer.params, reducer.views))}
+        offs, o = [], 0
+        for p in reducer.params:
+            offs.append(o)
+            o += p.numel()
+        self.offsets = offs
+        self.handles = []
+        self.done = set()
+        self.buckets = self.collectives = 0          # of the last step (tests read them)
+
+    def begin(self):
+        self.handles, self.done = [], set()
+        self.buckets = self.collectives = 0
+
+    def view(self, p):
+        e = self.by_param.get(id(p))
+        return None if e is None else e[1]
+
+    def bucket_done(self, params):
+        idx = sorted(self.by_param[id(p)][0] for p in params if id(p) in self.by_param)
+        if not idx:
+            return
+        self.done.update(idx)
+        self.buckets += 1
+        if not is_distributed():
+            return
+        # contiguous runs of parameter indices = contiguous slices of the flat buffer
+        run = [idx[0]]
+        for i in idx[1:] + [None]:
+            if i is not None and i == run[-1] + 1:
+                run.append(i)
+                continue
+            lo = self.offsets[run[0]]
+            hi = self.offsets[run[-1]] + self.reducer.params[run[-1]].numel()
+            self.handles.append(dist.all_reduce(self.reducer.flat[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+            self.collectives += 1
+            if i is not None:
+                run = [i]
+
+    def wait(self):
+        for h in self.handles:
+            h.wait()
+        self.handles = []
 
 
 class DataParallelTrainStep:
@@ -126,16 +201,33 @@ class DataParallelTrainStep:
         self.criterion.reduce_fn = all_reduce_sums
         self.reducer = FlatGradAllReducer(list(model.parameters()))
         broadcast_parameters(model)
+        # encoder trunks with the HIP backward (Mockingjay): their gradients go straight into the flat buffer, bucket by bucket
+        self.sink = None
+        engines = []
+        if self.reducer.flat.is_cuda:
+            engines = [m._engine for m in model.modules() if hasattr(m, '_engine') and hasattr(m, 'model') and hasattr(m._engine, 'encode_train')]
+            if engines:
+                self.sink = BucketedGradSink(self.reducer)
+                for e in engines:
+                    e.grad_sink = self.sink
+        self._engines = engines if self.sink is not None else []
 
+    def close(self):
+        """Detach the gradient sink: a plain loss.backward() on the model fills .grad again."""
+        for e in self._engines:
+            e.grad_sink = None
+        self._engines, self.sink = [], None
 
     def step(self, loss):
         """loss already computed with the global-mean criterion; backward, all-reduce, clip, (maybe) step."""
+        if self.sink is not None:
+            self.sink.begin()
         loss.backward()
         fused = getattr(self.optimizer, 'step_fused', None) is not None and self.reducer.flat.is_cuda
         if fused:
             # device path: gradients stay in the flat (all-reduced) buffer; norms in one launch, global clip + per-tensor clip +
             # BertAdam in one more.  The skip decision reads the reduced norm, identically on every rank.
-            self.reducer.reduce(copy_back=False)
+            self.reducer.reduce(copy_back=False, sink=self.sink)
             tab = self.optimizer._fused_table(grads=dict(zip(self.reducer.params, self.reducer.views)))
             if tab is not None:
                 sumsq = self.optimizer.grad_sumsq(tab)
@@ -148,7 +240,7 @@ class DataParallelTrainStep:
             for p, v in zip(self.reducer.params, self.reducer.views):
                 p.grad = v.clone() if p.grad is None else p.grad.copy_(v)
         else:
-            self.reducer.reduce()
+            self.reducer.reduce(sink=self.sink)
         grad_norm = torch.nn.utils.clip_grad_norm_(self.reducer.params, self.grad_clip)
         gn = float(grad_norm)
         skipped = math.isnan(gn) or math.isinf(gn)          # identical on every rank: taken on the reduced gradient

@@ -203,18 +203,35 @@ class _EncoderTrainFn(torch.autograd.Function):
         d_hidden = d_hidden.contiguous().float()
         dev = d_hidden.device
         head, per = _trunk_tensors(model)
-        ghead = {k: torch.empty_like(v, dtype=torch.float32) for k, v in head.items()}
-        gper = {k: [torch.empty_like(v, dtype=torch.float32) for v in vs] for k, vs in per.items()}
+        # a data-parallel step may register a gradient sink on the engine (dist.BucketedGradSink): the kernels then write straight into
+        # its flat all-reduce buffer and each layer's bucket is reduced from the per-layer host callback, under the remaining backward
+        sink = getattr(ctx.engine, 'grad_sink', None)
+
+        def out(p):
+            v = sink.view(p) if sink is not None else None
+            return v if v is not None else torch.empty_like(p, dtype=torch.float32)
+        ghead = {k: out(v) for k, v in head.items()}
+        gper = {k: [out(v) for v in vs] for k, vs in per.items()}
         keep = []
         gs = _device_struct(_lib.EncoderGrads, ghead, gper, keep)
         nws = lib.se_encoder_train_workspace_bytes(h, B, T)
         ws = torch.empty(nws, device=dev, dtype=torch.uint8)
-        _lib.check(lib.se_encoder_bwd_bf16(h, _lib.ptr(ctx.lengths), B, T, _lib.ptr(d_hidden), _lib.ptr(saved), saved.numel(), gs,
-                                           _lib.ptr(ws), nws, ctx.dropout[0], ctx.dropout[1], _lib.stream()), 'se_encoder_bwd_bf16')
+        cb = None
+        if sink is not None:
+            def _done(layer, _user):      # exactly the parameters whose gradients the launches enqueued so far have produced
+                sink.bucket_done([vs[layer] for vs in per.values()] if layer >= 0 else list(head.values()))
+            cb = _lib.LAYER_DONE_CB(_done)
+        _lib.check(lib.se_encoder_bwd_cb_bf16(h, _lib.ptr(ctx.lengths), B, T, _lib.ptr(d_hidden), _lib.ptr(saved), saved.numel(), gs,
+                                              _lib.ptr(ws), nws, ctx.dropout[0], ctx.dropout[1], cb, None, _lib.stream()), 'se_encoder_bwd_bf16')
         ctx.buf = None
         grads = [ghead[k] for k in ('in_w', 'in_b', 'in_ln_w', 'in_ln_b')]
         for k in _TRUNK_FIELDS:
             grads.extend(gper[k])
+        if sink is not None:
+            # gradients that live in the sink's flat buffer are NOT handed to autograd (it would clone 173 MB of views into .grad):
+            # dist.DataParallelTrainStep reads them from the buffer, and copies them back to .grad only on its unfused path
+            plist = _trunk_param_list(model)
+            grads = [None if sink.view(p) is not None else g for p, g in zip(plist, grads)]
         return (None, None, None, None, None, None) + tuple(grads)
 
 

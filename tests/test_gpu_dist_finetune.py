@@ -1,6 +1,7 @@
 """Two ranks on ONE MI355X (gloo over device tensors; RCCL needs a device per rank) running the real HIP training path:
 a data-parallel Mockingjay fine-tune step on two half batches must reproduce the single-process step on the whole ragged
-batch -- global masked mean (the (sum, count) pair is all-reduced before dividing), one flat-buffer gradient all-reduce,
+batch -- global masked mean (the (sum, count) pair is all-reduced before dividing), the flat-buffer gradient all-reduce
+issued bucket by bucket from the encoder backward's per-layer callback (dist.BucketedGradSink) plus one for the spec head,
 identical gradient norm / skip decision, identical fused BertAdam update."""
 import os
 import socket
@@ -25,7 +26,7 @@ def _free_port():
 def _setup(device):
     from speech_enhancement_by_s3prl_amd import pipeline
     from speech_enhancement_by_s3prl_amd.solver import get_optimizer
-    cfg = pipeline.make_config(layers=1)
+    cfg = pipeline.make_config(layers=2)
     ckpt = pipeline.synthetic_checkpoint(cfg, seed=21)
     model = pipeline.build_mockingjay(ckpt, device)
     model.eval()                       # dropout off: the two runs must see the same function (gradients stay enabled)
@@ -48,6 +49,13 @@ def _step(model, opt, feats, tar, lens, device):
     pred, res = model(features=feats.to(device))
     loss, _ = crit(log_predicted=res['log_predicted'], linear_tar=tar.to(device), stft_lengths=lens.to(device))
     gn, skipped = dp.step(loss)
+    # the encoder trunk's gradients went through the bucketed sink: written in place (no .grad clone), one bucket per layer + the input stage
+    assert dp.sink is not None and dp.sink.buckets == 3, dp.sink and dp.sink.buckets
+    trunk = sum(1 for _ in model.mockingjay.model.parameters())
+    assert len(dp.sink.done) == trunk, (len(dp.sink.done), trunk)
+    assert all(p.grad is None for p in model.mockingjay.model.parameters())      # fused step: gradients are read from the flat buffer
+    if dist.is_initialized():
+        assert dp.sink.collectives == 3, dp.sink.collectives
     # numpy (pickled by value): torch tensors travel through an mp.Queue by file descriptor, which dies with the worker
     return float(loss.detach()), gn, skipped, dp.reducer.flat.detach().cpu().numpy().copy(), [p.detach().cpu().numpy().copy() for p in model.parameters()]
 
