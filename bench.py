@@ -90,7 +90,12 @@ def cpu_baseline(batch, layers, seconds_budget=25.0):
                       f'{dt:.2f} s per batch on {cpu_name}'}
 
 
-PMC_FILE = os.path.join(ROOT, 'profiles', 'r01_h_pmc_fetch_write.json')
+PMC_FILE = os.path.join(ROOT, 'profiles', 'r02_pmc_fetch_write.json')
+
+
+# every kernel the prof family 'gemm_bf16' times (csrc/gemm*.hip): the traffic figure is the launch-weighted mean over the same launches
+GEMM_KERNELS = ('gemm2_bf16_kernel', 'gemm3_bf16_kernel', 'gemm4_res_ln_kernel', 'gemm6_bf16_kernel', 'gemm6p_bf16_kernel', 'gemm7_res_ln_kernel',
+                'gemm8_res24_ln_kernel', 'gemm5_bf16_kernel')
 
 
 def pmc_traffic(substrings):
@@ -325,10 +330,10 @@ def main():
         achieved = g_flop / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
         # the committed PMC passes are of the default command: report them only when this run is that command
         pmc_matches = (args.workload == 'enhance' and args.batch == 32 and args.layers == 6 and args.streams == 1 and not args.graph)
-        traffic = pmc_traffic(('gemm2_bf16_kernel', 'gemm3_bf16_kernel', 'gemm4_res_ln_kernel')) if pmc_matches else None
+        traffic = pmc_traffic(GEMM_KERNELS) if pmc_matches else None
         out['roofline'] = {'bound': 'mfma', 'kernel': 'gemm_bf16_kernel', 'achieved': achieved, 'peak': MFMA_BF16_PEAK_TFLOPS,
                            'unit': 'TFLOP/s', 'frac': achieved / MFMA_BF16_PEAK_TFLOPS, 'traffic': traffic,
-                           'traffic_unit': 'HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, committed PMC passes: profiles/r01_h_pmc_fetch_write.json)',
+                           'traffic_unit': 'HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, committed PMC passes: profiles/' + os.path.basename(PMC_FILE) + ')',
                            'launches': g_n, 'avg_launch_ms': g_ms / max(g_n, 1),
                            'algorithmic_flop_per_launch': g_flop / max(g_n, 1)}
         others = {}

@@ -4,13 +4,18 @@
 //
 // iSTFT workgroup = 256 threads = 27 hop-blocks (4 320 output samples) of one utterance; it inverse-
 // transforms the 30 frames that overlap that span (3 of them shared with the neighbours, re-read from L2):
-//   load   : X[k] = sqrt(P) (cos phi, sin phi), Im X[0] = Im X[200] = 0 (c2r semantics); X[200].re rides in X[0].y
-//   fold   : Z[k] = E[k] + i O[k]  in place on pairs (k, 200-k)
-//   pass A / pass B : fft200.h with DIR = +1
-//   ola    : out[n] = sum_f w[n - 160 f] z_f[n - 160 f] / sum_f w^2[n - 160 f]      (1/200 folded into w)
+//   polar + fold : one item = the bin PAIR (k, 200-k) of a frame, k = 0..100: X = sqrt(P) (cos phi, sin phi) for both bins (hardware
+//                  sin / cos / sqrt), then Z[k] = E + i O, Z[200-k] = conj(E) + i conj(O) straight into LDS.  Im X[0] = Im X[200] = 0
+//                  (c2r semantics).  The first version wrote X to LDS and folded in a second pass (a barrier, an LDS round trip, and a
+//                  25-times unrolled loop with the k = 0 / k = 200 special cases as branches); it also carried both the sqrt and the
+//                  general pow() of linear_power in every iteration -- ~6 000 vector instructions per thread, which at 3 workgroups per
+//                  CU IS the kernel's time (4 cycles each x 3 waves per SIMD = 30 us per round of 768 workgroups, 1.6 rounds at B = 32).
+//                  Now: the kernel is specialised on linear_power == 2 and the pair loop is branch-free.
+//   pass A / pass B : fft200.h with DIR = +1; pass B multiplies by window / 400 (1/200 of the inverse transform, 1/2 of the fold)
+//   ola    : out[n] = sum_f w[n - 160 f] z_f[n - 160 f] / sum_f w^2[n - 160 f]
 // All tables (twiddles, window) live in LDS and every global load of a thread is issued up front, so the output loop
 // holds stores only (a load there would drain the stores every iteration: one in-order vmcnt on gfx950).
-// LDS 52 816 B -> 3 workgroups per CU.  Bound: HBM (2 249 608 B per utterance).
+// LDS 52.8 KB -> 3 workgroups per CU.  Bound: vector issue (the HBM floor, 2 249 608 B per utterance, is ~9 us at B = 32).
 #include "plan.h"
 #include "prof.h"
 #include "fft200.h"
@@ -21,15 +26,19 @@ constexpr int kIFR = 30;                 // frames transformed per workgroup (30
 constexpr int kIHB = 27;                 // hop-blocks of output per workgroup
 constexpr int kISpan = kIHB * kHop;      // 4320 samples
 constexpr int kIThreads = 256;
-constexpr int kILoadIters = (kIFR * kBins + kIThreads - 1) / kIThreads;   // 25
+constexpr int kIPairs = 101;             // bin pairs (k, 200 - k) per frame
+constexpr int kIPairIters = (kIFR * kIPairs + kIThreads - 1) / kIThreads;   // 12
+constexpr float kIScale = 1.0f / 400.0f; // 1/200 (inverse transform) x 1/2 (E, O of the fold are kept doubled)
 
+template <int SQRT>
 __global__ __launch_bounds__(kIThreads) void istft_kernel(
     const float* __restrict__ power, const float* __restrict__ phase, int F, float inv_lp,
-    const float* __restrict__ window, const float2* __restrict__ tw400g,
+    const float* __restrict__ window, const float2* __restrict__ tw400g, const float2* __restrict__ tw200g,
     float* __restrict__ wav, int wav_stride, const int64_t* __restrict__ lengths, float* __restrict__ sumsq) {
-  __shared__ __attribute__((aligned(16))) float2 Y[kIFR * kHalf];
-  __shared__ float2 tw[kHalf];            // (cos, sin)(2 pi k / 400), k < 200
-  __shared__ __attribute__((aligned(16))) float win[kNfft];
+  __shared__ __attribute__((aligned(16))) float2 Y[kIFR * kHalf + 1];   // +1: the dump slot of the k = 0 pair's second write
+  __shared__ float2 tw[kHalf];            // (cos, sin)(2 pi k / 400), k < 200: fold twiddles
+  __shared__ float2 tw2[kHalf];           // (cos, sin)(2 pi t / 200): pass-A twiddles W200^(j q), j q <= 168
+  __shared__ __attribute__((aligned(16))) float win[kNfft];             // window / 400
   __shared__ float red[kIThreads / 64];
 
   const int tid = threadIdx.x;
@@ -40,85 +49,60 @@ __global__ __launch_bounds__(kIThreads) void istft_kernel(
   const int flo = max(fbase, 0);
   const int fhi = min(fbase + kIFR, F);               // exclusive
   const int nfr = fhi - flo;
-  // table loads are issued together with the spectrum loads below and written to LDS afterwards (one memory latency)
-  const float2 twv = tw400g[min(tid, kHalf - 1)];
-  const float wv0 = window[tid], wv1 = window[min(tid + kIThreads, kNfft - 1)];
 
-  // ---- load + polar: item (f, k), k = 0..200, contiguous in (B, F, K); all global loads issued before any use
+  // ---- tables -> LDS first (their loads lead the queue), then every spectrum load of the thread back to back
   {
+    const float2 twv = tw400g[min(tid, kHalf - 1)], tw2v = tw200g[min(tid, kHalf - 1)];
+    const float wv0 = window[tid], wv1 = window[min(tid + kIThreads, kNfft - 1)];
     const size_t gbase = ((size_t)b * F + flo) * kBins;
-    const int nitems = nfr * kBins;
-    float pv[kILoadIters], hv[kILoadIters];
+    float p0[kIPairIters], h0[kIPairIters], p1[kIPairIters], h1[kIPairIters];
 #pragma unroll
-    for (int r = 0; r < kILoadIters; ++r) {
+    for (int r = 0; r < kIPairIters; ++r) {
       const int it = tid + kIThreads * r;
-      const bool ok = it < nitems;
-      pv[r] = ok ? power[gbase + it] : 0.f;
-      hv[r] = ok ? phase[gbase + it] : 0.f;
+      const int fl = it / kIPairs, k = it - fl * kIPairs;
+      const bool ok = fl < nfr;
+      const size_t g = gbase + (size_t)(ok ? fl : 0) * kBins;
+      p0[r] = power[g + k];
+      h0[r] = phase[g + k];
+      p1[r] = power[g + kHalf - k];
+      h1[r] = phase[g + kHalf - k];
     }
-    if (tid < kHalf) tw[tid] = twv;
-    win[tid] = wv0;
-    if (tid + kIThreads < kNfft) win[tid + kIThreads] = wv1;
-    int fl = tid / kBins, k = tid - fl * kBins;
+    if (tid < kHalf) { tw[tid] = twv; tw2[tid] = tw2v; }
+    win[tid] = wv0 * kIScale;
+    if (tid + kIThreads < kNfft) win[tid + kIThreads] = wv1 * kIScale;
+    __syncthreads();
+    float2* Z0 = Y + (flo - fbase) * kHalf;
 #pragma unroll
-    for (int r = 0; r < kILoadIters; ++r) {
-      if (fl < nfr) {
-        const float mag = (inv_lp == 0.5f) ? sqrtf(pv[r]) : powf(pv[r], inv_lp);
-        // sin / cos through the hardware units (argument in revolutions, reduced to [-0.5, 0.5])
-        float rev = hv[r] * 0.15915494309189535f;
-        rev -= rintf(rev);
-        const float c = __builtin_amdgcn_cosf(rev), sn = __builtin_amdgcn_sinf(rev);
-        float2* Z = Y + (flo + fl - fbase) * kHalf;
-        if (k == 0) Z[0].x = mag * c;                  // Im X[0], Im X[200] are ignored (c2r semantics)
-        else if (k == kHalf) Z[0].y = mag * c;         // X[200].re rides in X[0].y
-        else Z[k] = make_float2(mag * c, mag * sn);
-      }
-      k += kIThreads - kBins;                          // 256 = 201 + 55
-      fl += 1;
-      if (k >= kBins) { k -= kBins; fl += 1; }
-    }
-  }
-  __syncthreads();
-
-  // ---- fold pairs (k, 200-k): Z[k] = E + iO, Z[200-k] = conj(E) + i conj(O)
-  for (int it = tid; it < nfr * 101; it += kIThreads) {
-    const int fl = it / 101, k = it - fl * 101;
-    float2* Z = Y + (flo + fl - fbase) * kHalf;
-    if (k == 0) {
-      const float a = Z[0].x, c = Z[0].y;
-      Z[0] = make_float2(0.5f * (a + c), 0.5f * (a - c));
-    } else if (k == 100) {
-      const float2 v = Z[100];
-      Z[100] = make_float2(v.x, -v.y);
-    } else {
-      const float2 xk = Z[k], xn = Z[kHalf - k];
-      const float2 E = make_float2(0.5f * (xk.x + xn.x), 0.5f * (xk.y - xn.y));
-      const float2 D = make_float2(0.5f * (xk.x - xn.x), 0.5f * (xk.y + xn.y));
-      const float2 w = tw[k];                                      // W^-k = (cos, +sin)
+    for (int r = 0; r < kIPairIters; ++r) {
+      const int it = tid + kIThreads * r;
+      const int fl = it / kIPairs, k = it - fl * kIPairs;
+      const float m0 = SQRT ? __builtin_amdgcn_sqrtf(p0[r]) : powf(p0[r], inv_lp);
+      const float m1 = SQRT ? __builtin_amdgcn_sqrtf(p1[r]) : powf(p1[r], inv_lp);
+      // sin / cos through the hardware units (argument in revolutions, reduced to [-0.5, 0.5])
+      float r0 = h0[r] * 0.15915494309189535f, r1 = h1[r] * 0.15915494309189535f;
+      r0 -= rintf(r0);
+      r1 -= rintf(r1);
+      const bool k0 = (k == 0);
+      const float2 xk = make_float2(m0 * __builtin_amdgcn_cosf(r0), k0 ? 0.f : m0 * __builtin_amdgcn_sinf(r0));
+      const float2 xn = make_float2(m1 * __builtin_amdgcn_cosf(r1), k0 ? 0.f : m1 * __builtin_amdgcn_sinf(r1));
+      // doubled E, D (the 1/2 rides in the window scale); k = 100 pairs the bin with itself and both writes agree
+      const float2 E = make_float2(xk.x + xn.x, xk.y - xn.y);
+      const float2 D = make_float2(xk.x - xn.x, xk.y + xn.y);
+      const float2 w = tw[k];                                       // W^-k = (cos, +sin)
       const float2 O = make_float2(D.x * w.x - D.y * w.y, D.x * w.y + D.y * w.x);
-      Z[k] = make_float2(E.x - O.y, E.y + O.x);                    // E + iO
-      Z[kHalf - k] = make_float2(E.x + O.y, -E.y + O.x);           // conj(E) + i conj(O)
+      if (fl < nfr) {
+        float2* Z = Z0 + fl * kHalf;
+        Z[k] = make_float2(E.x - O.y, E.y + O.x);                   // E + iO
+        (k0 ? Y + kIFR * kHalf : Z + (kHalf - k))[0] = make_float2(E.x + O.y, O.x - E.y);   // conj(E) + i conj(O); k = 0 has no partner slot
+      }
     }
   }
   __syncthreads();
 
-  // ---- pass A (inverse): W200^(+j q) from the 400-table
+  // ---- pass A (inverse)
   for (int it = tid; it < nfr * 25; it += kIThreads) {
     const int fl = it / 25, j = it - fl * 25;
-    float2* frame = Y + (flo + fl - fbase) * kHalf;
-    float2 v[8];
-#pragma unroll
-    for (int m = 0; m < 8; ++m) v[m] = frame[25 * m + j];
-    fft8<+1>(v);
-#pragma unroll
-    for (int q = 1; q < 8; ++q) {
-      const int t2 = 2 * j * q;
-      const float2 w = tw[t2 < kHalf ? t2 : t2 - kHalf];
-      const float sg = t2 < kHalf ? 1.f : -1.f;
-      v[q] = cmul(v[q], make_float2(sg * w.x, sg * w.y));
-    }
-#pragma unroll
-    for (int q = 0; q < 8; ++q) frame[25 * q + j] = v[q];
+    fft200_pass_a<+1>(Y + (flo + fl - fbase) * kHalf, j, tw2);
   }
   __syncthreads();
 
@@ -133,14 +117,13 @@ __global__ __launch_bounds__(kIThreads) void istft_kernel(
     }
     __syncthreads();
     if (active) {
-      const float sc = 1.0f / (float)kHalf;            // inverse-transform scale
 #pragma unroll
       for (int c = 0; c < 5; ++c)
 #pragma unroll
         for (int d = 0; d < 5; ++d) {
           const int n = q + 8 * (c + 5 * d);
           const float2 w = *reinterpret_cast<const float2*>(win + 2 * n);
-          Y[f * kHalf + n] = make_float2(y[5 * c + d].x * (w.x * sc), y[5 * c + d].y * (w.y * sc));
+          Y[f * kHalf + n] = make_float2(y[5 * c + d].x * w.x, y[5 * c + d].y * w.y);
         }
     }
   }
@@ -148,12 +131,14 @@ __global__ __launch_bounds__(kIThreads) void istft_kernel(
 
   // ---- overlap-add + envelope + masked square sum; the loop contains LDS reads and global STORES only.  Four consecutive samples
   //      per thread: hop, n_fft/2 and the workgroup span are multiples of 4, so a quad shares its (up to three) frames, the LDS reads
-  //      are aligned ds_read_b128 and the store is one 16-B store (scalar fallback when the output row is not 16-B aligned)
+  //      are aligned ds_read_b128 and the store is one 16-B store (scalar fallback when the output row is not 16-B aligned).
+  //      The LDS window is w / 400: sum w^2 = 160 000 x sum win^2.
   const float* xs = reinterpret_cast<const float*>(Y);
   const int len_b = lengths ? (int)min((int64_t)n_out, lengths[b]) : 0;
   float ss = 0.f;
   float* wrow = wav + (size_t)b * wav_stride;
   const bool vec_out = ((reinterpret_cast<uintptr_t>(wrow) & 15) == 0);
+  constexpr float kEnvScale = kIScale * kIScale;
 #pragma unroll 1
   for (int o = 4 * tid; o < kISpan; o += 4 * kIThreads) {
     const int n = o0 + o;
@@ -174,8 +159,8 @@ __global__ __launch_bounds__(kIThreads) void istft_kernel(
       }
     }
     // v_rcp_f32 (1 ulp) instead of the IEEE division sequence: ~10 instructions per sample in a VALU-bound kernel
-    const float4 v = make_float4(acc.x * __builtin_amdgcn_rcpf(env.x), acc.y * __builtin_amdgcn_rcpf(env.y),
-                                 acc.z * __builtin_amdgcn_rcpf(env.z), acc.w * __builtin_amdgcn_rcpf(env.w));
+    const float4 v = make_float4(acc.x * (kEnvScale * __builtin_amdgcn_rcpf(env.x)), acc.y * (kEnvScale * __builtin_amdgcn_rcpf(env.y)),
+                                 acc.z * (kEnvScale * __builtin_amdgcn_rcpf(env.z)), acc.w * (kEnvScale * __builtin_amdgcn_rcpf(env.w)));
     if (vec_out) {
       *reinterpret_cast<float4*>(wrow + n) = v;
     } else {
@@ -270,8 +255,12 @@ extern "C" int se_istft_f32(const se_plan* plan, const float* power, const float
   if (sumsq_out) { const int zrc_ = se::zero_async(sumsq_out, sizeof(float) * B, st); if (zrc_) return zrc_; }
   dim3 grid((n_out + se::kISpan - 1) / se::kISpan, B);
   se::ProfScope prof(se::kProfIstft, (double)B * (8.0 * F * se::kBins + 4.0 * n_out), st);
-  hipLaunchKernelGGL(se::istft_kernel, grid, dim3(se::kIThreads), 0, st, power, phase, F, 1.0f / linear_power,
-                     plan->d_window, plan->d_tw400, wav_out, wav_stride, lengths, sumsq_out);
+  if (linear_power == 2.0f)
+    hipLaunchKernelGGL(se::istft_kernel<1>, grid, dim3(se::kIThreads), 0, st, power, phase, F, 0.5f, plan->d_window, plan->d_tw400, plan->d_tw200,
+                       wav_out, wav_stride, lengths, sumsq_out);
+  else
+    hipLaunchKernelGGL(se::istft_kernel<0>, grid, dim3(se::kIThreads), 0, st, power, phase, F, 1.0f / linear_power, plan->d_window, plan->d_tw400,
+                       plan->d_tw200, wav_out, wav_stride, lengths, sumsq_out);
   SE_LAUNCH_CHECK();
   return SE_OK;
 }
