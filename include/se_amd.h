@@ -312,6 +312,10 @@ int se_colsum_groups(const void* x, int is_bf16, int groups, int rows, int cols,
  * the returned gradient is wrt x_in).  dx / dx_bf16 (M, H); dgamma, dbeta (H) accumulated by atomics.  H = 768. */
 int se_layernorm_bwd_f32(const float* x_in, const float* dy, const float* w, int M, int H, float eps, int gelu_in,
                          float* dx, uint16_t* dx_bf16, float* dgamma, float* dbeta, int accumulate, void* stream);
+/* The same over `groups` blocks of `rows` rows with one (dgamma, dbeta) row per block: every utterance's LayerNorm parameter gradient
+   of the active-sampling scoring in one launch (sampler.py:84-104 runs one backward per utterance).  dgamma / dbeta: (groups, H). */
+int se_layernorm_bwd_groups_f32(const float* x_in, const float* dy, const float* w, int groups, int rows, int H, float eps, int gelu_in,
+                                float* dx, uint16_t* dx_bf16, float* dgamma, float* dbeta, void* stream);
 /* y = LayerNorm(gelu(pre)) (spec-head transform, training path keeps `pre`).  H = 768. */
 int se_gelu_layernorm_f32(const float* pre, const float* w, const float* b, int M, int H, float eps,
                           float* out_f32, uint16_t* out_bf16, void* stream);

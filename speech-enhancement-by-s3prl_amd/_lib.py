@@ -96,6 +96,7 @@ SIGNATURES = {
     'se_wgrad_tn_slabs_bf16': (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     'se_colsum_f32': (c_int, [_P, c_int, c_int, c_int, _P, c_int, _P]),
     'se_colsum_groups': (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    'se_layernorm_bwd_groups_f32': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_float, c_int, _P, _P, _P, _P, _P]),
     'se_layernorm_bwd_f32': (c_int, [_P, _P, _P, c_int, c_int, c_float, c_int, _P, _P, _P, _P, c_int, _P]),
     'se_gelu_layernorm_f32': (c_int, [_P, _P, _P, c_int, c_int, c_float, _P, _P, _P]),
     'se_spec_epilogue_f32': (c_int, [_P, c_size_t, c_int, c_int, c_float, _P, _P, _P]),

@@ -206,8 +206,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             const float* __restrict__ w, int M, float eps, float* __restrict__ dx,
                                                             uint16_t* __restrict__ dx_bf16, float* __restrict__ dgamma,
                                                             float* __restrict__ dbeta, float* __restrict__ dbias, int rows_per_wave,
-                                                            uint32_t key_dy, uint32_t key_dx, uint32_t thr16, float dscale) {
+                                                            uint32_t key_dy, uint32_t key_dx, uint32_t thr16, float dscale, int group_rows) {
   constexpr int H = 256 * NV;
+  // group_rows > 0: blockIdx.y = group g owns rows [g group_rows, (g + 1) group_rows) and its own (dgamma, dbeta, dbias) rows --
+  // per-utterance parameter gradients in one launch (scoring.py); 0: one group of M rows
+  const int gbase = blockIdx.y * group_rows;
+  const int gend = group_rows ? min(M, gbase + group_rows) : M;
+  if (dgamma) dgamma += (size_t)blockIdx.y * H;
+  if (dbeta) dbeta += (size_t)blockIdx.y * H;
+  if (dbias) dbias += (size_t)blockIdx.y * H;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   float4 gsum[NV], bsum[NV], xsum[NV];     // column sums of dy xhat (dgamma), dy (dbeta), dx (bias gradient of the producing linear)
 #pragma unroll
@@ -215,8 +222,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
   float4 ww[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) ww[i] = *reinterpret_cast<const float4*>(w + (i * 64 + lane) * 4);
-  const int row0 = (blockIdx.x * 4 + wv) * rows_per_wave;
-  for (int row = row0; row < min(M, row0 + rows_per_wave); ++row) {
+  const int row0 = gbase + (blockIdx.x * 4 + wv) * rows_per_wave;
+  for (int row = row0; row < min(gend, row0 + rows_per_wave); ++row) {
     float4 pre[NV], v[NV], g[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -386,25 +393,27 @@ extern "C" int se_colsum_f32(const float* x, int rows, int cols, int ld, float* 
 
 int se::launch_layernorm_bwd(const float* x_in, const float* pe, int T, const float* dy, const float* w, int M, int H, float eps, int gelu_in,
                              float* dx, uint16_t* dx_bf16, float* dgamma, float* dbeta, float* dbias, int accumulate, hipStream_t st,
-                             uint32_t key_dy, uint32_t key_dx, uint32_t thr16, float dscale) {
+                             uint32_t key_dy, uint32_t key_dx, uint32_t thr16, float dscale, int group_rows) {
   SE_REQUIRE(H == 768 || H == 256, "layernorm backward: only H = 768 / 256 are built (got %d)", H);
+  const int groups = group_rows ? (M + group_rows - 1) / group_rows : 1;
+  SE_REQUIRE(groups <= 65535, "layernorm backward: %d groups exceed grid.y", groups);
   if (!accumulate) {
-    if (dgamma) { const int zrc_ = se::zero_async(dgamma, sizeof(float) * H, st); if (zrc_) return zrc_; }
-    if (dbeta) { const int zrc_ = se::zero_async(dbeta, sizeof(float) * H, st); if (zrc_) return zrc_; }
-    if (dbias) { const int zrc_ = se::zero_async(dbias, sizeof(float) * H, st); if (zrc_) return zrc_; }
+    if (dgamma) { const int zrc_ = se::zero_async(dgamma, sizeof(float) * H * groups, st); if (zrc_) return zrc_; }
+    if (dbeta) { const int zrc_ = se::zero_async(dbeta, sizeof(float) * H * groups, st); if (zrc_) return zrc_; }
+    if (dbias) { const int zrc_ = se::zero_async(dbias, sizeof(float) * H * groups, st); if (zrc_) return zrc_; }
   }
   const int rows_per_wave = 16;
-  const int grid = (M + 4 * rows_per_wave - 1) / (4 * rows_per_wave);
+  const dim3 grid(((group_rows ? group_rows : M) + 4 * rows_per_wave - 1) / (4 * rows_per_wave), groups);
   if (H == 768) {
     if (gelu_in)
-      hipLaunchKernelGGL((se::layernorm_bwd_kernel<3, 1>), dim3(grid), dim3(256), 0, st, x_in, pe, T, dy, w, M, eps, dx, dx_bf16, dgamma, dbeta, dbias, rows_per_wave, key_dy, key_dx, thr16, dscale);
+      hipLaunchKernelGGL((se::layernorm_bwd_kernel<3, 1>), grid, dim3(256), 0, st, x_in, pe, T, dy, w, M, eps, dx, dx_bf16, dgamma, dbeta, dbias, rows_per_wave, key_dy, key_dx, thr16, dscale, group_rows);
     else
-      hipLaunchKernelGGL((se::layernorm_bwd_kernel<3, 0>), dim3(grid), dim3(256), 0, st, x_in, pe, T, dy, w, M, eps, dx, dx_bf16, dgamma, dbeta, dbias, rows_per_wave, key_dy, key_dx, thr16, dscale);
+      hipLaunchKernelGGL((se::layernorm_bwd_kernel<3, 0>), grid, dim3(256), 0, st, x_in, pe, T, dy, w, M, eps, dx, dx_bf16, dgamma, dbeta, dbias, rows_per_wave, key_dy, key_dx, thr16, dscale, group_rows);
   } else {
     if (gelu_in)
-      hipLaunchKernelGGL((se::layernorm_bwd_kernel<1, 1>), dim3(grid), dim3(256), 0, st, x_in, pe, T, dy, w, M, eps, dx, dx_bf16, dgamma, dbeta, dbias, rows_per_wave, key_dy, key_dx, thr16, dscale);
+      hipLaunchKernelGGL((se::layernorm_bwd_kernel<1, 1>), grid, dim3(256), 0, st, x_in, pe, T, dy, w, M, eps, dx, dx_bf16, dgamma, dbeta, dbias, rows_per_wave, key_dy, key_dx, thr16, dscale, group_rows);
     else
-      hipLaunchKernelGGL((se::layernorm_bwd_kernel<1, 0>), dim3(grid), dim3(256), 0, st, x_in, pe, T, dy, w, M, eps, dx, dx_bf16, dgamma, dbeta, dbias, rows_per_wave, key_dy, key_dx, thr16, dscale);
+      hipLaunchKernelGGL((se::layernorm_bwd_kernel<1, 0>), grid, dim3(256), 0, st, x_in, pe, T, dy, w, M, eps, dx, dx_bf16, dgamma, dbeta, dbias, rows_per_wave, key_dy, key_dx, thr16, dscale, group_rows);
   }
   SE_LAUNCH_CHECK();
   return SE_OK;
@@ -414,6 +423,16 @@ extern "C" int se_layernorm_bwd_f32(const float* x_in, const float* dy, const fl
                                     float* dx, uint16_t* dx_bf16, float* dgamma, float* dbeta, int accumulate, void* stream) {
   SE_REQUIRE(x_in && dy && w && (dx || dx_bf16) && M > 0, "se_layernorm_bwd_f32: bad argument");
   return se::launch_layernorm_bwd(x_in, nullptr, 1, dy, w, M, H, eps, gelu_in, dx, dx_bf16, dgamma, dbeta, nullptr, accumulate, se::as_stream(stream));
+}
+
+// the same with the rows cut into `groups` blocks of `rows` and one (dgamma, dbeta) row per block: the per-utterance LayerNorm parameter
+// gradients of the active-sampling scoring (sampler.py:84-104) in ONE launch
+extern "C" int se_layernorm_bwd_groups_f32(const float* x_in, const float* dy, const float* w, int groups, int rows, int H, float eps, int gelu_in,
+                                           float* dx, uint16_t* dx_bf16, float* dgamma, float* dbeta, void* stream) {
+  SE_REQUIRE(x_in && dy && w && (dx || dx_bf16) && groups > 0 && rows > 0, "se_layernorm_bwd_groups_f32: bad argument");
+  SE_REQUIRE((long)groups * rows <= 0x7fffffffL, "se_layernorm_bwd_groups_f32: too many rows");
+  return se::launch_layernorm_bwd(x_in, nullptr, 1, dy, w, groups * rows, H, eps, gelu_in, dx, dx_bf16, dgamma, dbeta, nullptr, 0, se::as_stream(stream), 0, 0,
+                                  0, 1.f, rows);
 }
 
 int se::launch_colsum_bf16(const uint16_t* x, int rows, int cols, int ld, float* out, hipStream_t st) {

@@ -29,7 +29,7 @@ int launch_layernorm(const float* x, const float* pe, int T, const float* w, con
 int launch_cast_pad(const float* x, size_t rows, int cols, int ld_out, uint16_t* out, hipStream_t st);
 int launch_layernorm_bwd(const float* x_in, const float* pe, int T, const float* dy, const float* w, int M, int H, float eps, int gelu_in,
                          float* dx, uint16_t* dx_bf16, float* dgamma, float* dbeta, float* dbias, int accumulate, hipStream_t st,
-                         uint32_t key_dy = 0, uint32_t key_dx = 0, uint32_t thr16 = 0, float dscale = 1.f);
+                         uint32_t key_dy = 0, uint32_t key_dx = 0, uint32_t thr16 = 0, float dscale = 1.f, int group_rows = 0);
 int launch_gelu_bwd_colsum(const uint16_t* dy, const uint16_t* pre, uint16_t* dx, int rows, int cols, float* colsum, hipStream_t st);
 int launch_colsum_bf16(const uint16_t* x, int rows, int cols, int ld, float* out, hipStream_t st);
 inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }

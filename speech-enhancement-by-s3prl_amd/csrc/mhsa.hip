@@ -250,6 +250,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
 
 }  // namespace se
 
+int se_mhsa_fwd_pipe_launch(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, int occ, hipStream_t st);   // mhsa_pipe.hip
+
 static int mhsa_fwd_launch(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, float* lse, float dropout_p,
                            uint64_t seed, uint32_t site, void* stream) {
   SE_REQUIRE(qkv && ctx, "se_mhsa_fwd_bf16: null argument");
@@ -286,6 +288,14 @@ extern "C" int se_mhsa_fwd_prescaled_bf16(const uint16_t* qkv, const int32_t* le
   const int H = heads * se::kHD;
   dim3 grid((T + se::kAQ - 1) / se::kAQ, heads, B);
   se::ProfScope prof(se::kProfMhsa, 4.0 * B * (double)heads * T * (double)T * se::kHD, se::as_stream(stream));
+  static int pipe = -1, pipe_occ = 2;
+  if (pipe < 0) {
+    const char* e = getenv("SE_AMD_MHSA_PIPE");
+    const char* o = getenv("SE_AMD_MHSA_PIPE_OCC");
+    pipe_occ = o ? atoi(o) : 2;
+    pipe = e ? atoi(e) : 0;      // measured slower than this file's kernel (169 vs 143 us): see the header of mhsa_pipe.hip
+  }
+  if (pipe) return se_mhsa_fwd_pipe_launch(qkv, lengths, B, T, heads, ctx, pipe_occ, se::as_stream(stream));
   hipLaunchKernelGGL((se::mhsa_fwd_kernel<3, 0, 1>), grid, dim3(256), 0, se::as_stream(stream), qkv, lengths, T, H, ctx, nullptr, 0u, 0u, 1.f);
   SE_LAUNCH_CHECK();
   return SE_OK;

@@ -3,7 +3,7 @@
 The reference's `scoring` runs the downstream model once and then B sequential `loss_b.backward(retain_graph=True)` passes,
 collecting each utterance's flattened parameter gradient; `matching` turns them into cosine scores against the mean query
 gradient.  Here ONE backward sweep produces all B gradients: the row-wise parts of the backward (epilogue, LayerNorm, GELU)
-are per-frame anyway, and the weight gradients come out of the TN weight-gradient kernel as its per-split slabs with the
+are per-frame anyway, the LayerNorm parameter gradients come from one grouped launch (grid.y = utterance), and the weight gradients come out of the TN weight-gradient kernel as its per-split slabs with the
 split boundaries on utterance boundaries (se_wgrad_tn_slabs_bf16) -- no reduce, no retain_graph, no B-fold replay.
 Implemented for the downstream models whose `log_predicted` the reference's `scoring` reads (sampler.py:72): `SpecHead` (model.py:94-126,
 per_sample_gradients) and `LSTM` (model.py:37-59 -- the head run_active.sh:11 actually scores; per_sample_gradients_lstm, with the
@@ -106,11 +106,9 @@ def per_sample_gradients(head, features, linear_tar, stft_lengths, eps=1e-10):
     dpre16 = torch.empty(M, H, device=dev, dtype=torch.bfloat16)
     d_lnw = torch.empty(B, H, device=dev, dtype=torch.float32)
     d_lnb = torch.empty(B, H, device=dev, dtype=torch.float32)
-    for b in range(B):      # LayerNorm parameter gradients reduce over rows: one launch per utterance (row-wise outputs land in place)
-        o = b * T * H
-        _lib.check(lib.se_layernorm_bwd_f32(_lib.ptr(pre) + o * 4, _lib.ptr(dxn) + o * 4, _lib.ptr(lnw), T, H, ln_eps, 1, _lib.ptr(dpre32) + o * 4,
-                                            _lib.ptr(dpre16) + o * 2, _lib.ptr(d_lnw) + b * H * 4, _lib.ptr(d_lnb) + b * H * 4, 0, _lib.stream()),
-                   'se_layernorm_bwd_f32')
+    # LayerNorm parameter gradients reduce over an utterance's rows: grid.y = utterance, one launch (row-wise outputs land in place)
+    _lib.check(lib.se_layernorm_bwd_groups_f32(_lib.ptr(pre), _lib.ptr(dxn), _lib.ptr(lnw), B, T, H, ln_eps, 1, _lib.ptr(dpre32), _lib.ptr(dpre16),
+                                               _lib.ptr(d_lnw), _lib.ptr(d_lnb), _lib.stream()), 'se_layernorm_bwd_groups_f32')
     # ---- per-utterance weight gradients: the TN kernel's slabs, split on utterance boundaries
     d_wo = torch.empty(B, NP, H, device=dev, dtype=torch.float32)
     _lib.check(lib.se_wgrad_tn_slabs_bf16(_lib.ptr(dp16), NP, _lib.ptr(xn16), H, M, NP, H, T, _lib.ptr(d_wo), _lib.stream()), 'se_wgrad_tn_slabs_bf16')
