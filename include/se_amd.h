@@ -252,9 +252,12 @@ int se_gemm_res_ln_bf16(const uint16_t* A, int lda, const uint16_t* W, int ldw, 
 /* qkv (B*T, 3H) bf16 = [Q | K | V] per row, heads of 64 columns; ctx (B*T, H) bf16. */
 int se_mhsa_fwd_bf16(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, void* stream);
 /* The same attention on PRE-SCALED queries: the Q block of `qkv` already carries log2(e) / sqrt(64) (the encoder's inference copy of the
-   fused QKV weights folds it into the query rows before their bf16 rounding), i.e. ctx = softmax_base2(Q' K^T + pad-mask) V.  Inference
-   only; two-tile software pipeline with the running maximum carried as the MFMA C operand (csrc/mhsa.hip: mhsa_fwd2_kernel). */
+   fused QKV weights folds it into the query rows before their bf16 rounding), i.e. ctx = softmax_base2(Q' K^T + pad-mask) V: no
+   per-score multiply in front of the exponential, and the running reference starts at 0 (csrc/mhsa.hip, PRE = 1).  Inference only. */
 int se_mhsa_fwd_prescaled_bf16(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, void* stream);
+/* Test / measurement surface: variant 0 = the kernel above, 1 = the software-pipelined half-tile experiment (csrc/mhsa_pipe.hip; measured
+   slower, off by default, SE_AMD_MHSA_PIPE=1 routes se_mhsa_fwd_prescaled_bf16 to it). */
+int se_mhsa_fwd_prescaled_variant_bf16(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, int variant, void* stream);
 /* Row-complete projection on the encoder's 24-bit residual stream (bf16 hi rows + int8 lo bytes, tile-major: csrc/gemm4.hip), exported for
  * tests / measurement: x = LayerNorm(A . W^T + bias + residual), out as fp32 rows or as (bf16, lo).  variant 0 = the encoder's dispatch,
  * 7 = 128 x 768 tiles, 8 = 256 x 384 tiles with the LayerNorm statistics exchanged between the two column halves (csrc/gemm8.hip).
@@ -319,7 +322,8 @@ int se_layernorm_bwd_groups_f32(const float* x_in, const float* dy, const float*
 /* y = LayerNorm(gelu(pre)) (spec-head transform, training path keeps `pre`).  H = 768. */
 int se_gelu_layernorm_f32(const float* pre, const float* w, const float* b, int M, int H, float eps,
                           float* out_f32, uint16_t* out_bf16, void* stream);
-/* SpecHead.forward's epilogue (model.py:121-125) on a raw linear output p (n elements) and its backward wrt p */
+/* SpecHead.forward's epilogue (model.py:121-125) on a raw linear output p (n elements) and its backward wrt p.
+   log_target 0 / 1: SpecHead's two branches; 2: LSTM.forward's (model.py:56-58) log_predicted = act(p), predicted = exp(log_predicted). */
 int se_spec_epilogue_f32(const float* p, size_t n, int log_target, int act, float eps, float* predicted, float* log_predicted, void* stream);
 int se_spec_epilogue_bwd_f32(const float* p, const float* d_pred, const float* d_logp, int M, int N, int ldp, int log_target,
                              int act, float eps, float* dp_f32, uint16_t* dp_bf16, void* stream);

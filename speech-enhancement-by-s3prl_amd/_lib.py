@@ -84,6 +84,7 @@ SIGNATURES = {
     'se_gemm_res24_ln_bf16': (c_int, [_P, c_int, _P, c_int, _P, _P, _P, _P, _P, c_float, c_int, c_int, c_int, _P, _P, _P, c_int, _P, _P]),
     'se_mhsa_fwd_bf16': (c_int, [_P, _P, c_int, c_int, c_int, _P, _P]),
     'se_mhsa_fwd_prescaled_bf16': (c_int, [_P, _P, c_int, c_int, c_int, _P, _P]),
+    'se_mhsa_fwd_prescaled_variant_bf16': (c_int, [_P, _P, c_int, c_int, c_int, _P, c_int, _P]),
     'se_layernorm_f32': (c_int, [_P, _P, _P, c_int, c_int, c_float, _P, _P, _P]),
     'se_cast_f32_bf16': (c_int, [_P, c_size_t, _P, _P]),
     'se_gemm_f32': (c_int, [_P, ctypes.c_long, _P, ctypes.c_long, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, c_float, _P, ctypes.c_long, c_int, c_int,

@@ -204,15 +204,20 @@ __global__ __launch_bounds__(256) void spec_epilogue_kernel(const float* __restr
   for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     const float v = p[i];
     float pred, lp;
-    if (log_target) {
-      pred = expf(v);
-      lp = v;
+    if (log_target == 2) {        // LSTM.forward (model.py:56-58): log_predicted = act(p), predicted = exp(log_predicted)
+      lp = (act == SE_ACT_RELU) ? fmaxf(v, 0.f) : (act == SE_ACT_SIGMOID) ? 1.f / (1.f + expf(-v)) : v;
+      pred = expf(lp);
     } else {
-      pred = v;
-      lp = logf(v + eps);
+      if (log_target) {
+        pred = expf(v);
+        lp = v;
+      } else {
+        pred = v;
+        lp = logf(v + eps);
+      }
+      if (act == SE_ACT_RELU) pred = fmaxf(pred, 0.f);
+      else if (act == SE_ACT_SIGMOID) pred = 1.f / (1.f + expf(-pred));
     }
-    if (act == SE_ACT_RELU) pred = fmaxf(pred, 0.f);
-    else if (act == SE_ACT_SIGMOID) pred = 1.f / (1.f + expf(-pred));
     if (predicted) predicted[i] = pred;
     if (log_predicted) log_predicted[i] = lp;
   }
@@ -242,7 +247,7 @@ __global__ __launch_bounds__(256) void spec_epilogue_rows_kernel(const float* __
   }
 }
 
-// backward of SpecHead.forward's epilogue (model.py:121-125) wrt the raw linear output p:
+// backward of SpecHead.forward's epilogue (model.py:121-125) wrt the raw linear output p (log_target 2: LSTM.forward's, model.py:56-58):
 //   log_target: predicted = act(exp(p)), log_predicted = p      -> dp = d_logp + d_pred act'(exp p) exp(p)
 //   else      : predicted = act(p),      log_predicted = log(p+eps) -> dp = d_pred act'(p) + d_logp / (p + eps)
 // writes dp as fp32 (M, N) and as bf16 (M, ldp) with columns N..ldp-1 zeroed (GEMM operand padding)
@@ -258,7 +263,12 @@ __global__ __launch_bounds__(256) void spec_epilogue_bwd_kernel(const float* __r
       const size_t j = r * N + c;
       const float v = p[j];
       const float gp = d_pred ? d_pred[j] : 0.f, gl = d_logp ? d_logp[j] : 0.f;
-      if (log_target) {
+      if (log_target == 2) {      // lp = act(p), pred = exp(lp): dp = (d_logp + d_pred exp(lp)) act'(p)
+        const float sg = 1.f / (1.f + expf(-v));
+        const float lp = (act == SE_ACT_RELU) ? fmaxf(v, 0.f) : (act == SE_ACT_SIGMOID) ? sg : v;
+        const float da = (act == SE_ACT_RELU) ? (v > 0.f ? 1.f : 0.f) : (act == SE_ACT_SIGMOID) ? sg * (1.f - sg) : 1.f;
+        g = (gl + gp * expf(lp)) * da;
+      } else if (log_target) {
         const float e = expf(v);
         const float da = (act == SE_ACT_RELU) ? (e > 0.f ? 1.f : 0.f) : 1.f;
         g = gl + gp * da * e;
@@ -351,7 +361,8 @@ extern "C" int se_spec_epilogue_f32(const float* p, size_t n, int log_target, in
 extern "C" int se_spec_epilogue_bwd_f32(const float* p, const float* d_pred, const float* d_logp, int M, int N, int ldp, int log_target,
                                         int act, float eps, float* dp_f32, uint16_t* dp_bf16, void* stream) {
   SE_REQUIRE(p && (d_pred || d_logp) && (dp_f32 || dp_bf16) && M > 0 && N > 0 && ldp >= N, "se_spec_epilogue_bwd_f32: bad argument");
-  SE_REQUIRE(act == SE_ACT_RELU || act == SE_ACT_IDENTITY, "se_spec_epilogue_bwd_f32: activation must be ReLU or Identity");
+  SE_REQUIRE(act == SE_ACT_RELU || act == SE_ACT_IDENTITY || (log_target == 2 && act == SE_ACT_SIGMOID),
+             "se_spec_epilogue_bwd_f32: activation must be ReLU or Identity (Sigmoid only with log_target 2)");
   const size_t n = (size_t)M * ldp;
   const int grid = (int)std::min<size_t>((n + 255) / 256, 8192);
   hipLaunchKernelGGL(se::spec_epilogue_bwd_kernel, dim3(grid), dim3(256), 0, se::as_stream(stream), p, d_pred, d_logp, M, N, ldp, log_target,

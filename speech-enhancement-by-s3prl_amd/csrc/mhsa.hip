@@ -282,23 +282,37 @@ extern "C" int se_mhsa_fwd_bf16(const uint16_t* qkv, const int32_t* lengths, int
   return mhsa_fwd_launch(qkv, lengths, B, T, heads, ctx, nullptr, 0.f, 0, 0, stream);
 }
 
-extern "C" int se_mhsa_fwd_prescaled_bf16(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, void* stream) {
+static int mhsa_prescaled_launch(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, int pipe, void* stream) {
   SE_REQUIRE(qkv && ctx, "se_mhsa_fwd_prescaled_bf16: null argument");
   SE_REQUIRE(B > 0 && B <= 65535 && T > 0 && heads > 0 && heads <= 65535, "se_mhsa_fwd_prescaled_bf16: bad shape B=%d T=%d heads=%d", B, T, heads);
   const int H = heads * se::kHD;
   dim3 grid((T + se::kAQ - 1) / se::kAQ, heads, B);
   se::ProfScope prof(se::kProfMhsa, 4.0 * B * (double)heads * T * (double)T * se::kHD, se::as_stream(stream));
-  static int pipe = -1, pipe_occ = 2;
-  if (pipe < 0) {
-    const char* e = getenv("SE_AMD_MHSA_PIPE");
+  static int pipe_occ = -1;
+  if (pipe_occ < 0) {
     const char* o = getenv("SE_AMD_MHSA_PIPE_OCC");
     pipe_occ = o ? atoi(o) : 2;
-    pipe = e ? atoi(e) : 0;      // measured slower than this file's kernel (169 vs 143 us): see the header of mhsa_pipe.hip
   }
   if (pipe) return se_mhsa_fwd_pipe_launch(qkv, lengths, B, T, heads, ctx, pipe_occ, se::as_stream(stream));
   hipLaunchKernelGGL((se::mhsa_fwd_kernel<3, 0, 1>), grid, dim3(256), 0, se::as_stream(stream), qkv, lengths, T, H, ctx, nullptr, 0u, 0u, 1.f);
   SE_LAUNCH_CHECK();
   return SE_OK;
+}
+
+extern "C" int se_mhsa_fwd_prescaled_bf16(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, void* stream) {
+  static int pipe = -1;
+  if (pipe < 0) {
+    const char* e = getenv("SE_AMD_MHSA_PIPE");
+    pipe = e ? atoi(e) : 0;      // measured slower than this file's kernel (169 vs 143 us): see the header of mhsa_pipe.hip
+  }
+  return mhsa_prescaled_launch(qkv, lengths, B, T, heads, ctx, pipe, stream);
+}
+
+// test / measurement surface: variant 0 = this file's kernel, 1 = the software-pipelined experiment of mhsa_pipe.hip
+extern "C" int se_mhsa_fwd_prescaled_variant_bf16(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, int variant,
+                                                  void* stream) {
+  SE_REQUIRE(variant == 0 || variant == 1, "se_mhsa_fwd_prescaled_variant_bf16: variant %d (0 / 1)", variant);
+  return mhsa_prescaled_launch(qkv, lengths, B, T, heads, ctx, variant, stream);
 }
 
 extern "C" int se_mhsa_fwd_lse_bf16(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, float* lse,

@@ -84,9 +84,10 @@ def test_mhsa_vs_torch(gpu, B, T, heads, lens):
 
 
 @pytest.mark.parametrize('B,T,heads,lens', [(2, 1001, 12, None), (3, 300, 4, [300, 17, 129]), (1, 64, 1, None), (2, 130, 2, [1, 65]), (8, 257, 1, [257, 200, 64, 63, 1, 128, 129, 256])])
-def test_mhsa_prescaled_vs_torch(gpu, B, T, heads, lens):
-    """the inference kernel on pre-scaled queries (two-tile pipeline, running maximum in the MFMA C operand) vs fp64 on the SAME bf16
-    operands: softmax_base2(Q' K^T) V with Q' = bf16(Q log2(e) / 8)"""
+@pytest.mark.parametrize('variant', [0, 1])
+def test_mhsa_prescaled_vs_torch(gpu, B, T, heads, lens, variant):
+    """the inference kernel on pre-scaled queries (variant 0) and the software-pipelined half-tile experiment (variant 1, csrc/mhsa_pipe.hip)
+    vs fp64 on the SAME bf16 operands: softmax_base2(Q' K^T) V with Q' = bf16(Q log2(e) / 8)"""
     L = _lib()
     lib = L.load()
     torch.manual_seed(T + 1)
@@ -96,7 +97,8 @@ def test_mhsa_prescaled_vs_torch(gpu, B, T, heads, lens):
     qkv = x.bfloat16()
     lengths = torch.tensor(lens if lens else [T] * B, device=gpu, dtype=torch.int32)
     ctx = torch.empty(B * T, H, device=gpu, dtype=torch.bfloat16)
-    L.check(lib.se_mhsa_fwd_prescaled_bf16(L.ptr(qkv), L.ptr(lengths) if lens else None, B, T, heads, L.ptr(ctx), L.stream()), 'se_mhsa_fwd_prescaled_bf16')
+    L.check(lib.se_mhsa_fwd_prescaled_variant_bf16(L.ptr(qkv), L.ptr(lengths) if lens else None, B, T, heads, L.ptr(ctx), variant, L.stream()),
+            'se_mhsa_fwd_prescaled_variant_bf16')
     # reference: undo the scale exactly in fp64 on the rounded operands (scores / 8 in nats == Q' K^T in bits)
     q = qkv.double().reshape(B, T, 3, heads, 64)
     Q, K, V = q[:, :, 0].transpose(1, 2), q[:, :, 1].transpose(1, 2), q[:, :, 2].transpose(1, 2)
@@ -111,7 +113,8 @@ def test_mhsa_prescaled_vs_torch(gpu, B, T, heads, lens):
     assert err.max().item() < 8e-3 * ref.abs().max().item(), err.max().item()      # P and the output are rounded to bf16 (2^-9 relative)
 
 
-def test_mhsa_prescaled_rising_maxima(gpu):
+@pytest.mark.parametrize('variant', [0, 1])
+def test_mhsa_prescaled_rising_maxima(gpu, variant):
     """rising row maxima across key tiles (both sides of the deferred-rescale branch, which here must also shift the S' tile computed ahead)"""
     L = _lib()
     lib = L.load()
@@ -127,7 +130,7 @@ def test_mhsa_prescaled_rising_maxima(gpu):
     qkv = torch.cat([one[:, 0:64], one[:, 0:64].flip(0), one[:, 64:128], one[:, 64:128], one[:, 128:], one[:, 128:]], dim=1).bfloat16()
     ctx = torch.empty(T, 128, device=gpu, dtype=torch.bfloat16)
     lengths = torch.tensor([T - 30], device=gpu, dtype=torch.int32)
-    L.check(lib.se_mhsa_fwd_prescaled_bf16(L.ptr(qkv), L.ptr(lengths), B, T, heads, L.ptr(ctx), L.stream()), 'se_mhsa_fwd_prescaled_bf16')
+    L.check(lib.se_mhsa_fwd_prescaled_variant_bf16(L.ptr(qkv), L.ptr(lengths), B, T, heads, L.ptr(ctx), variant, L.stream()), 'se_mhsa_fwd_prescaled_variant_bf16')
     x = qkv.double().reshape(1, T, 3, heads, 64)
     Q, K, V = x[:, :, 0].transpose(1, 2), x[:, :, 1].transpose(1, 2), x[:, :, 2].transpose(1, 2)
     S = (Q @ K.transpose(-1, -2)) * 0.6931471805599453

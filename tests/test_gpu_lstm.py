@@ -18,10 +18,10 @@ def rel_l2(a, b):
 
 
 class RefLSTM(nn.Module):      # the reference's class body (model.py:37-59), fp64 on the CPU
-    def __init__(self, input_size, output_size, hidden_size, num_layers, bidirectional):
+    def __init__(self, input_size, output_size, hidden_size, num_layers, bidirectional, activation='Identity'):
         super().__init__()
         self.lstm = nn.LSTM(input_size=input_size, hidden_size=hidden_size, num_layers=num_layers, batch_first=True, bidirectional=bidirectional)
-        self.scaling_layer = nn.Sequential(nn.Linear(max(1, int(bidirectional) * 2) * hidden_size, output_size), nn.Identity())
+        self.scaling_layer = nn.Sequential(nn.Linear(max(1, int(bidirectional) * 2) * hidden_size, output_size), getattr(nn, activation)())
 
     def forward(self, features):
         predicted, _ = self.lstm(features)
@@ -56,6 +56,40 @@ def test_lstm_head_forward_backward_vs_torch(gpu, B, T, D, layers, bidir):
     refp = dict(ref.named_parameters())
     for n, p in head.named_parameters():
         assert p.grad is not None, n
+        r = rel_l2(p.grad, refp[n].grad)
+        assert r < 4e-2, (n, r)
+
+
+@pytest.mark.parametrize('hidden,bidir,act', [(201, False, 'Identity'), (201, True, 'ReLU'), (64, True, 'Sigmoid'), (256, False, 'ReLU')])
+def test_lstm_head_other_widths_and_activations(gpu, hidden, bidir, act):
+    """the reference's class defaults (model.py:38: hidden_size 201, any nn activation on the scaling layer): hidden sizes below the
+    kernels' 256 run on zero-padded weights (exact: a padded unit stays at h = c = 0), log_predicted = act(linear), predicted = exp(.)"""
+    from speech_enhancement_by_s3prl_amd.lstm import LSTM
+    torch.manual_seed(hidden)
+    B, T, D, layers = 2, 41, 201, 2
+    head = LSTM(input_size=D, output_size=201, hidden_size=hidden, num_layers=layers, bidirectional=bidir, activation=act)
+    with torch.no_grad():
+        for n, p in head.named_parameters():
+            if 'bias' in n:
+                p.normal_(0, 0.05)
+            if 'scaling_layer.0.weight' in n:
+                p.mul_(0.3)
+    ref = RefLSTM(D, 201, hidden, layers, bidir, act).double()
+    ref.load_state_dict({k: v.double() for k, v in head.state_dict().items()})
+    head = head.to(gpu)
+    feats = torch.randn(B, T, D)
+    G1, G2 = torch.randn(B, T, 201) * 0.1, torch.randn(B, T, 201)
+    pred, res = head(features=feats.to(gpu))
+    logp = res['log_predicted']
+    assert logp.shape == (B, T, 201)
+    ((pred * G1.to(gpu)).sum() + (logp * G2.to(gpu)).sum()).backward()
+    rpred, rlogp = ref(feats.double())
+    ((rpred * G1.double()).sum() + (rlogp * G2.double()).sum()).backward()
+    assert rel_l2(logp, rlogp) < 1.5e-2
+    assert rel_l2(pred, rpred) < 2.5e-2
+    refp = dict(ref.named_parameters())
+    for n, p in head.named_parameters():
+        assert p.grad is not None and p.grad.shape == p.shape, n
         r = rel_l2(p.grad, refp[n].grad)
         assert r < 4e-2, (n, r)
 
@@ -99,19 +133,19 @@ class RefResidual(nn.Module):      # the reference's class body (model.py:62-91)
         return linears * offset, offset
 
 
-@pytest.mark.parametrize('bidir,cmvn', [(False, True), (True, False)])
-def test_residual_head_vs_torch(gpu, bidir, cmvn):
+@pytest.mark.parametrize('bidir,cmvn,hidden', [(False, True, 256), (True, False, 256), (True, True, 201)])
+def test_residual_head_vs_torch(gpu, bidir, cmvn, hidden):
     """LSTM -> CMVN over time -> Linear + Sigmoid mask -> mask (.) noisy power, trained through `predicted` AND the mask
     (SISDR + WSD style gradients), against the reference's class body on torch.nn.LSTM in fp64."""
     from speech_enhancement_by_s3prl_amd.lstm import Residual
     torch.manual_seed(5)
     B, T, D = 3, 60, 120
-    head = Residual(input_size=D, output_size=201, hidden_size=256, num_layers=2, bidirectional=bidir, activation='Sigmoid', cmvn=cmvn)
+    head = Residual(input_size=D, output_size=201, hidden_size=hidden, num_layers=2, bidirectional=bidir, activation='Sigmoid', cmvn=cmvn)
     with torch.no_grad():
         for n, p in head.named_parameters():
             if 'bias' in n:
                 p.normal_(0, 0.05)
-    ref = RefResidual(D, 201, 256, 2, bidir, cmvn).double()
+    ref = RefResidual(D, 201, hidden, 2, bidir, cmvn).double()
     ref.load_state_dict({k: v.double() for k, v in head.state_dict().items()})
     head = head.to(gpu)
     feats, lin = torch.randn(B, T, D), torch.rand(B, T, 201) + 0.1
