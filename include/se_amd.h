@@ -64,7 +64,7 @@ typedef struct se_geometry {
   int win;         /* 400 samples (win_ms 25) */
   int hop;         /* 160 samples (hop_ms 10) */
   int n_freq;      /* 201 */
-  int n_mels;      /* 40 (<= 64) */
+  int n_mels;      /* 40 in the shipped configs; <= 128 (the MFCC branch builds its own 128-filter bank) */
 } se_geometry;
 
 int se_plan_create(const se_geometry* geom, se_plan** out);

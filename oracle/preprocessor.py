@@ -6,6 +6,9 @@ run_downstream.py:153-164, runner.py:267,433,558 and sampler.py:60,226-228.  Wha
 (sampler.py:229 takes sqrt of _magphase, objective.py:89); outputs are time-major (B, T', D)
 (model.py:30, objective.py:110-111).  Mel / delta / CMVN follow torchaudio 0.6 (MelScale HTK, no norm;
 compute_deltas win 5 replicate) as recalled -- PARITY UNPINNED vs original S3PRL for those (A3, A4).
+The MFCC branch (A5) restates torchaudio-0.6 `transforms.MFCC(sample_rate, n_mfcc, log_mels=True, melkwargs=win_args)` as S3PRL
+is recalled to construct it: its OWN mel spectrogram on the same STFT geometry with torchaudio's default 128 filters, log(mel + 1e-6),
+orthonormal DCT-II -- PARITY UNPINNED (neither S3PRL nor torchaudio is in the container; no shipped config selects `mfcc`).
 """
 import math
 
@@ -23,6 +26,7 @@ class Geometry:
         self.n_fft = (n_freq - 1) * 2
         self.n_freq = n_freq
         self.n_mels = n_mels
+        self.n_mfcc = n_mfcc
         self.eps = eps
 
 
@@ -69,6 +73,31 @@ def melscale(power, geom):
     return torch.matmul(power.transpose(-1, -2), fb).transpose(-1, -2)
 
 
+MFCC_N_MELS = 128          # torchaudio MelSpectrogram default, not the preprocessor's n_mels
+MFCC_LOG_OFFSET = 1e-6     # torchaudio MFCC(log_mels=True)
+
+
+def dct_matrix(n_mfcc, n_mels, dtype=torch.float32):
+    """torchaudio-0.6 functional.create_dct(n_mfcc, n_mels, norm='ortho'): (n_mels, n_mfcc), DCT-II,
+    dct[n, k] = cos(pi / n_mels * (n + 0.5) * k) * sqrt(2 / n_mels), column 0 additionally * 1 / sqrt(2)."""
+    n = torch.arange(n_mels, dtype=torch.float64)
+    k = torch.arange(n_mfcc, dtype=torch.float64).unsqueeze(1)
+    dct = torch.cos(math.pi / n_mels * (n + 0.5) * k)            # (n_mfcc, n_mels)
+    dct[0] *= 1.0 / math.sqrt(2.0)
+    dct *= math.sqrt(2.0 / n_mels)
+    return dct.t().contiguous().to(dtype)
+
+
+def mfcc(power, geom, n_mfcc=13):
+    """A5: power (..., K, F) -> mfcc (..., n_mfcc, F): 128-filter HTK mel of the power spectrogram, log(. + 1e-6), DCT-II (ortho)."""
+    g128 = Geometry.__new__(Geometry)
+    g128.__dict__.update(geom.__dict__)
+    g128.n_mels = MFCC_N_MELS
+    mel = melscale(power, g128)
+    logmel = (mel + MFCC_LOG_OFFSET).log()
+    return torch.matmul(logmel.transpose(-1, -2), dct_matrix(n_mfcc, MFCC_N_MELS, power.dtype)).transpose(-1, -2)
+
+
 def compute_deltas(x, win_length=5):
     """A4: torchaudio.functional.compute_deltas along the last (time) dim, replicate padding.
     kernel = [-2,-1,0,1,2] / 10."""
@@ -104,8 +133,7 @@ def select_feat(raw, eps, log=False, delta=0, cmvn=False):
 
 def forward(wavs, feat_list, geom):
     """OnlinePreprocessor.forward: wavs (B, C, T) -> list of time-major (B, T', D) features.
-    The MFCC branch (A5) is computed-and-discarded in S3PRL; it is only produced if requested, and
-    'mfcc' is not supported by this oracle (not on the reference's configured path)."""
+    The MFCC branch (A5) is computed-and-discarded in S3PRL on every call; here it is only produced if requested."""
     shape = wavs.shape
     complx = stft(wavs.reshape(-1, shape[-1]), geom)
     complx = complx.reshape(shape[:-1] + complx.shape[-2:])      # (B, C, K, F)
@@ -120,6 +148,8 @@ def forward(wavs, feat_list, geom):
             raw = phase[:, ch]
         elif ft == 'mel':
             raw = melscale(linear[:, ch], geom)
+        elif ft == 'mfcc':
+            raw = mfcc(linear[:, ch], geom, getattr(geom, 'n_mfcc', 13))
         elif ft == 'complx':
             c = complx[:, ch]
             raw = torch.stack([c.real, c.imag], dim=-1).transpose(-1, -2).reshape(c.shape[0], -1, c.shape[-1])

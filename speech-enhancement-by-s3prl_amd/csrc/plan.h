@@ -9,7 +9,7 @@ constexpr int kHalf = 200;      // complex FFT size
 constexpr int kBins = 201;
 constexpr int kHop = 160;
 constexpr int kMelMaxW = 32;    // max bins under one mel triangle
-constexpr int kMelMax = 64;
+constexpr int kMelMax = 128;     // 40 (the reference's configs) ... 128 (the MFCC branch's own mel bank, torchaudio's default)
 }  // namespace se
 
 struct se_plan {

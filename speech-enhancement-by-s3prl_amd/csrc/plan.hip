@@ -74,7 +74,7 @@ extern "C" int se_plan_create(const se_geometry* geom, se_plan** out) {
   if (geom->n_freq != se::kBins || geom->hop != se::kHop || geom->win > se::kNfft || geom->win < 2 ||
       geom->n_mels < 1 || geom->n_mels > se::kMelMax) {
     se::set_error("se_plan_create: unsupported geometry (n_freq=%d hop=%d win=%d n_mels=%d); the gfx950 kernels are "
-                  "specialised for n_freq=201, hop=160, win<=400, n_mels<=64", geom->n_freq, geom->hop, geom->win, geom->n_mels);
+                  "specialised for n_freq=201, hop=160, win<=400, n_mels<=128", geom->n_freq, geom->hop, geom->win, geom->n_mels);
     return SE_ERR_UNSUPPORTED;
   }
   se_plan* p = new se_plan();

@@ -280,18 +280,16 @@ __global__ __launch_bounds__(kThreads) void stft_kernel(
   // ---- mel: sparse HTK triangles over the power plane; the filter table is staged into the (now dead) phase plane
   float* Tb = reinterpret_cast<float*>(Y) + kPlane + 4;     // [kMelMax * kMelMaxW weights][kMelMax starts][kMelMax lengths]
   {
-    float wv[5];
+    constexpr int kTbIters = kMelMax * kMelMaxW / kThreads;      // 16: the whole table, whatever n_mels (40 ... 128)
+    float wv[kTbIters];
 #pragma unroll
-    for (int r = 0; r < 5; ++r) {
-      const int i = tid + kThreads * r;                     // < 1280 = 40 x 32
+    for (int r = 0; r < kTbIters; ++r) {
+      const int i = tid + kThreads * r;
       wv[r] = (i < n_mels * kMelMaxW) ? mel_w[i] : 0.f;
     }
     const int ms = (tid < n_mels) ? mel_start[tid] : 0, ml = (tid < n_mels) ? mel_len[tid] : 0;
 #pragma unroll
-    for (int r = 0; r < 5; ++r) {
-      const int i = tid + kThreads * r;
-      if (i < kMelMax * kMelMaxW) Tb[i] = wv[r];
-    }
+    for (int r = 0; r < kTbIters; ++r) Tb[tid + kThreads * r] = wv[r];
     if (tid < kMelMax) {
       Tb[kMelMax * kMelMaxW + tid] = __int_as_float(ms);
       Tb[kMelMax * kMelMaxW + kMelMax + tid] = __int_as_float(ml);

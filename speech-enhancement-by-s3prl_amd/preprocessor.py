@@ -50,6 +50,7 @@ class OnlinePreprocessor(nn.Module):
     def __getstate__(self):
         state = self.__dict__.copy()
         state['_plans'] = {}
+        state.pop('_tables', None)
         return state
 
     def __deepcopy__(self, memo):
@@ -58,7 +59,7 @@ class OnlinePreprocessor(nn.Module):
         new = cls.__new__(cls)
         memo[id(self)] = new
         for k, v in self.__dict__.items():
-            new.__dict__[k] = {} if k == '_plans' else copy.deepcopy(v, memo)
+            new.__dict__[k] = {} if k in ('_plans', '_tables') else copy.deepcopy(v, memo)
         return new
 
     def __del__(self):
@@ -70,18 +71,58 @@ class OnlinePreprocessor(nn.Module):
         except Exception:
             pass
 
-    def _plan(self, device):
+    def _plan(self, device, n_mels=None):
         idx = device.index if device.index is not None else torch.cuda.current_device()
-        plan = self._plans.get(idx)
+        n_mels = self._n_mels if n_mels is None else n_mels
+        key = idx if n_mels == self._n_mels else (idx, n_mels)       # the MFCC branch has its own 128-filter plan
+        plan = self._plans.get(key)
         if plan is None:
             lib = _lib.load()
             geom = _lib.Geometry(self._sample_rate, self._win_args['win_length'], self._win_args['hop_length'],
-                                 self._n_freq, self._n_mels)
+                                 self._n_freq, n_mels)
             out = _lib.c_void_p()
             with torch.cuda.device(idx):
                 _lib.check(lib.se_plan_create(geom, out), 'se_plan_create')
-            plan = self._plans[idx] = out.value
+            plan = self._plans[key] = out.value
         return plan
+
+    # ---- row A5: MFCC (torchaudio-0.6 transforms.MFCC(log_mels=True, melkwargs=win_args) as S3PRL builds it; parity unpinned) ----
+    _MFCC_N_MELS = 128          # torchaudio's MelSpectrogram default: the MFCC transform has its OWN mel bank
+    _MFCC_LOG_OFFSET = 1e-6
+
+    def _dct(self, dev):
+        """(n_mfcc, 128) fp32 = the transposed orthonormal DCT-II matrix of torchaudio's create_dct, built in float64"""
+        import math
+        key = ('dct', dev.index)
+        d = self.__dict__.setdefault('_tables', {}).get(key)
+        if d is None:
+            n = torch.arange(self._MFCC_N_MELS, dtype=torch.float64)
+            k = torch.arange(self._n_mfcc, dtype=torch.float64).unsqueeze(1)
+            d = torch.cos(math.pi / self._MFCC_N_MELS * (n + 0.5) * k)
+            d[0] *= 1.0 / math.sqrt(2.0)
+            d = (d * math.sqrt(2.0 / self._MFCC_N_MELS)).float().contiguous().to(dev)
+            self.__dict__['_tables'][key] = d
+        return d
+
+    def _mfcc_channel(self, wavs, channel):
+        """wavs (B, C, T) -> raw MFCC (B, F, n_mfcc) time-major: STFT + 128-filter sparse mel in the STFT kernel (no power / phase
+        planes are written), log(mel + 1e-6) + transpose in the feature kernel, DCT-II as an exact-fp32 GEMM (se_gemm_f32)."""
+        lib = _lib.load()
+        B, C, T = wavs.shape
+        F = T // self._win_args['hop_length'] + 1
+        dev = wavs.device
+        NM = self._MFCC_N_MELS
+        mel = torch.empty(B, NM, F, device=dev, dtype=torch.float32)
+        _lib.check(lib.se_stft_f32(self._plan(dev, NM), _lib.ptr(wavs), B, C, T, channel, None, None, None, _lib.ptr(mel), _lib.stream()), 'se_stft_f32')
+        logmel = torch.empty(B, F, NM, device=dev, dtype=torch.float32)
+        nbytes = lib.se_features_workspace_bytes(B, NM, F, 0)
+        ws = torch.empty(max(nbytes, 1), device=dev, dtype=torch.uint8)
+        _lib.check(lib.se_features_f32(_lib.ptr(mel), 0, B, NM, F, 1, 0, 0, float(self._MFCC_LOG_OFFSET), _lib.ptr(logmel), _lib.ptr(ws), nbytes,
+                                       _lib.stream()), 'se_features_f32')
+        out = torch.empty(B, F, self._n_mfcc, device=dev, dtype=torch.float32)
+        _lib.check(lib.se_gemm_f32(_lib.ptr(logmel), NM, _lib.ptr(self._dct(dev)), NM, 0, None, None, 0, B * F, self._n_mfcc, NM, 0, 1.0,
+                                   _lib.ptr(out), self._n_mfcc, 1, 1, 0, 0, 0, 0, 0, 0, _lib.stream()), 'se_gemm_f32')
+        return out
 
     # ---- S3PRL surface ---------------------------------------------------------------------------
     @classmethod
@@ -181,23 +222,26 @@ class OnlinePreprocessor(nn.Module):
         wavs3 = wavs.reshape(-1, wavs.shape[-2], wavs.shape[-1])
 
         # which raw planes does each channel need?  (the reference transforms every channel every step and
-        # also computes an unused MFCC -- row A5; here only requested channels / planes are produced)
-        need = {}
+        # also computes an MFCC it discards -- row A5; here only requested channels / planes are produced)
+        need, mfcc_channels = {}, set()
         for a in feat_list:
             ft = a['feat_type']
-            if ft == 'mfcc':
-                raise NotImplementedError("feat_type 'mfcc' is not on the reference's configured path (SURVEY A5)")
+            if ft == 'mfcc':      # its own transform (128-filter mel bank): _mfcc_channel
+                mfcc_channels.add(int(a.get('channel', 0)))
+                continue
             need.setdefault(int(a.get('channel', 0)), set()).add(ft)
         if len(need) == 2:       # the reference's standard list (noisy + clean channel): both transforms in ONE launch
             planes = self._stft_two_channels(wavs3, need)
         else:
             planes = {ch: self._stft_channel(wavs3, ch, kinds) for ch, kinds in need.items()}
+        for ch in mfcc_channels:
+            planes.setdefault(ch, {})['mfcc'] = self._mfcc_channel(wavs3, ch)
 
         feats = []
         for a in feat_list:
             ft, ch = a['feat_type'], int(a.get('channel', 0))
             log, delta, cmvn = bool(a.get('log', False)), int(a.get('delta', 0)), bool(a.get('cmvn', False))
-            raw = planes[ch][ft]
+            raw = planes[ch][ft]                 # mel: (B, D, F) feature-major; everything else time-major
             if ft == 'mel':
                 feat = self._select(raw, False, log, delta, cmvn)
             elif log or delta or cmvn:

@@ -135,3 +135,22 @@ def test_bert_adam_step_and_schedule():
             state[n] = (m, v)
     for n, p in lin.named_parameters():
         assert torch.allclose(p.detach(), p0[n], rtol=1e-5, atol=1e-7)
+
+
+def test_mfcc_dct_is_orthonormal_and_flat_spectrum_has_one_coefficient():
+    """row A5 oracle, first principles: create_dct(norm='ortho') with n_mfcc = n_mels is an orthogonal matrix; a flat log-mel vector
+    has all its energy in coefficient 0 (= value * sqrt(n_mels))."""
+    import torch
+    from oracle import preprocessor as opre
+    d = opre.dct_matrix(128, 128, torch.float64)
+    assert torch.allclose(d.t() @ d, torch.eye(128, dtype=torch.float64), atol=1e-12)
+    d13 = opre.dct_matrix(13, 128, torch.float64)
+    c = torch.full((128,), 0.7, dtype=torch.float64) @ d13
+    assert abs(c[0].item() - 0.7 * 128 ** 0.5) < 1e-12 and c[1:].abs().max().item() < 1e-12
+    # 128 HTK filters over 201 bins: every filter spans < 32 bins (the HIP plan's sparse-bank limit); a few of the low ones are EMPTY
+    # (torchaudio warns about exactly that for n_fft = 400), which the plan must tolerate
+    g = opre.Geometry(n_mels=128)
+    fb = opre.mel_filterbank(g, torch.float64)
+    nz = (fb > 0)
+    spans = [(int(nz[:, m].nonzero().max() - nz[:, m].nonzero().min()) + 1) if nz[:, m].any() else 0 for m in range(128)]
+    assert max(spans) < 32
