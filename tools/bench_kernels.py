@@ -219,6 +219,19 @@ def bench_stft():
         print(f'istft B={B}: {ms*1e3:8.1f} us  {byts/ms/1e6:8.1f} GB/s', flush=True)
 
 
+def bench_hbm():
+    """the box's achievable HBM rate for roofline.json's 'confirmed' column: device-to-device copy (read + write) and fill of 2 GiB"""
+    n = 1 << 29
+    a = torch.empty(n, device=dev, dtype=torch.float32)
+    b = torch.empty(n, device=dev, dtype=torch.float32)
+    ms = timeit(lambda: b.copy_(a), iters=10)
+    print(f'hbm copy 2 GiB -> 2 GiB: {ms*1e3:8.1f} us  {2*4*n/ms/1e6:8.1f} GB/s (read + write)', flush=True)
+    ms = timeit(lambda: b.zero_(), iters=10)
+    print(f'hbm fill 2 GiB: {ms*1e3:8.1f} us  {4*n/ms/1e6:8.1f} GB/s (write)', flush=True)
+    ms = timeit(lambda: a.sum(), iters=10)
+    print(f'hbm read 2 GiB (sum): {ms*1e3:8.1f} us  {4*n/ms/1e6:8.1f} GB/s (read)', flush=True)
+
+
 if __name__ == '__main__':
     what = sys.argv[1] if len(sys.argv) > 1 else 'all'
     if what in ('gemm', 'all'):
@@ -241,3 +254,5 @@ if __name__ == '__main__':
         bench_wgrad()
     if what in ('lstm',):
         bench_lstm()
+    if what in ('hbm',):
+        bench_hbm()

@@ -1,0 +1,26 @@
+#!/bin/bash
+# Round-end evidence run on the GPU box (everything under gpurun_out/<tag>/): full GPU test-suite, the profile set of
+# tools/collect_profiles.sh, the side workloads' bench lines, per-kernel SQ / matrix-pipe counter passes, the micro-benchmarks.
+#   tools/final_evidence.sh r02b
+set -e
+tag=$1
+root=$(cd "$(dirname "$0")/.." && pwd)
+out=$root/gpurun_out/$tag
+mkdir -p "$out"
+cd "$root"
+python3 -m pytest tests -m gpu -x -q > "$out/pytest_gpu.log" 2>&1 || { tail -30 "$out/pytest_gpu.log"; exit 1; }
+tail -3 "$out/pytest_gpu.log"
+tools/collect_profiles.sh $tag
+cd "$root"
+python3 bench.py --workload finetune --no-cpu-baseline > "$out/${tag}_finetune_bench.json" 2> "$out/ft.err"
+python3 bench.py --workload lstm --no-cpu-baseline > "$out/${tag}_lstm_bench.json" 2> "$out/lstm.err"
+python3 tools/bench_kernels.py all > "$out/${tag}_bench_kernels.txt" 2>&1
+python3 tools/bench_kernels.py hbm >> "$out/${tag}_bench_kernels.txt" 2>&1
+python3 tools/bench_kernels.py square >> "$out/${tag}_bench_kernels.txt" 2>&1
+python3 tools/bench_kernels.py ksweep >> "$out/${tag}_bench_kernels.txt" 2>&1
+tools/micro/valu_rate > "$out/${tag}_micro_valu_rate.txt" 2>&1
+for k in gemm gemmln mhsa stft; do
+  tools/pmc_sq.sh ${tag}_$k tools/bench_kernels.py $k > "$out/pmc_sq_$k.log" 2>&1
+  cp "$root/gpurun_out/pmc_${tag}_$k/summary.json" "$out/${tag}_pmc_sq_$k.json"
+done
+ls "$out"
