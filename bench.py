@@ -372,6 +372,17 @@ def main():
         out['host_fed'] = {'value': args.batch * args.steps / el, 'unit': 'utt/s', 'ms_per_step': 1000.0 * el / args.steps,
                            'bytes_per_step': host_w.numel() * 4 + host_l.numel() * 8,
                            'note': 'rank 0 only; batches DMA-ed from pinned host memory on a copy stream, double buffered (PCIe-inclusive; not the headline value)'}
+        # the same with only the channels the pass reads (0 = noisy, 1 = clean; runner.py:558-561) crossing PCIe
+        for dl, dw in HostBatchFeeder([(host_l, host_w)] * args.warmup, dev, channels=2):
+            step(dw, dl, max_len)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for dl, dw in HostBatchFeeder([(host_l, host_w)] * args.steps, dev, channels=2):
+            step(dw, dl, max_len)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        out['host_fed']['two_channels'] = {'value': args.batch * args.steps / el, 'ms_per_step': 1000.0 * el / args.steps,
+                                           'bytes_per_step': host_w.numel() * 4 * 2 // host_w.shape[1] + host_l.numel() * 8}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == 'enhance':
         try:

@@ -56,4 +56,22 @@ __device__ __forceinline__ f32x2 gelu_erf2(f32x2 v) {
   return v * 0.5f * (er + one);
 }
 
+// GELU for epilogues whose output is ROUNDED TO bf16 (the FFN hidden activation): x * Phi(x) with Phi(x) = 1/2 + xc P(xc^2), xc = x clamped to
+// +-3.75, P an even degree-12 polynomial fitted (weighted minimax) to the exact erf form: |Phi error| <= 8.5e-5 everywhere, |gelu error|
+// <= 2.7e-4 absolute (3.3e-5 of |x| for large |x|) -- a tenth of the bf16 rounding of the result -- with NO transcendental: 2 v_med3 +
+// 9 packed fp32 instructions per PAIR against ~20 incl. two v_rcp + two v_exp for gelu_erf2.  The FFN1 epilogue was 40 % of that GEMM's
+// vector issue time (profiles/r02b_pmc_sq_gemm.json).  Exact-erf GELU stays wherever the value is kept in fp32 (spec head, fp32 mode).
+__device__ __forceinline__ f32x2 gelu_poly2(f32x2 v) {
+  const f32x2 xc = {__builtin_amdgcn_fmed3f(v.x, -3.75f, 3.75f), __builtin_amdgcn_fmed3f(v.y, -3.75f, 3.75f)};
+  const f32x2 t = xc * xc;
+  f32x2 p = __builtin_elementwise_fma(t, (f32x2){3.912436597e-08f, 3.912436597e-08f}, (f32x2){-2.376253633e-06f, -2.376253633e-06f});
+  p = __builtin_elementwise_fma(p, t, (f32x2){6.234780449e-05f, 6.234780449e-05f});
+  p = __builtin_elementwise_fma(p, t, (f32x2){-9.441798320e-04f, -9.441798320e-04f});
+  p = __builtin_elementwise_fma(p, t, (f32x2){9.362553246e-03f, 9.362553246e-03f});
+  p = __builtin_elementwise_fma(p, t, (f32x2){-6.578987092e-02f, -6.578987092e-02f});
+  p = __builtin_elementwise_fma(p, t, (f32x2){3.987064660e-01f, 3.987064660e-01f});
+  const f32x2 phi = __builtin_elementwise_fma(xc, p, (f32x2){0.5f, 0.5f});
+  return v * phi;
+}
+
 }  // namespace se

@@ -57,7 +57,9 @@ __device__ __forceinline__ float act6(float v, int act) {
       const int gn = n0 + wc * 64 + j * 16 + ncol;                                                                         \
       float v0 = acc[i][j][0] + bb[j].x, v1 = acc[i][j][1] + bb[j].y, v2 = acc[i][j][2] + bb[j].z, v3 = acc[i][j][3] + bb[j].w; \
       if constexpr (ACT == SE_ACT_GELU) {                                                                                  \
-        const f32x2 ga = gelu_erf2((f32x2){v0, v1}), gb = gelu_erf2((f32x2){v2, v3});                                      \
+        /* bf16 output: the transcendental-free polynomial (bf16.h); fp32 output keeps the erf form */                      \
+        const f32x2 ga = (OBF && !OF32) ? gelu_poly2((f32x2){v0, v1}) : gelu_erf2((f32x2){v0, v1});                        \
+        const f32x2 gb = (OBF && !OF32) ? gelu_poly2((f32x2){v2, v3}) : gelu_erf2((f32x2){v2, v3});                        \
         v0 = ga.x; v1 = ga.y; v2 = gb.x; v3 = gb.y;                                                                        \
       } else {                                                                                                             \
         v0 = act6(v0, ACT); v1 = act6(v1, ACT); v2 = act6(v2, ACT); v3 = act6(v3, ACT);                                    \

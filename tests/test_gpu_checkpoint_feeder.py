@@ -99,6 +99,12 @@ def test_host_batch_feeder_delivers_batches_in_order(gpu):
         assert torch.equal(dw.cpu(), hw) and torch.equal(dl.cpu(), hl) and torch.equal(lin, ref)
         seen += 1
     assert seen == len(batches)
+    # only the channels the pass reads cross PCIe: channels 0, 1 equal the host batch, the shape stays (B, C, T)
+    for (dl, dw), (hl, hw) in zip(HostBatchFeeder(batches, gpu, channels=2), batches):
+        assert dw.shape == hw.shape
+        assert torch.equal(dw[:, :2].cpu(), hw[:, :2]) and torch.equal(dl.cpu(), hl)
+        lin = pre(dw, [pre.get_feat_config('linear', 1)])[0]
+        assert torch.equal(lin, pre(hw.to(gpu), [pre.get_feat_config('linear', 1)])[0])
     # fewer batches than slots, and an empty source
     assert sum(1 for _ in HostBatchFeeder(batches[:1], gpu)) == 1
     assert sum(1 for _ in HostBatchFeeder([], gpu)) == 0

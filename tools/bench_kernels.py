@@ -228,6 +228,12 @@ def bench_hbm():
     print(f'hbm copy 2 GiB -> 2 GiB: {ms*1e3:8.1f} us  {2*4*n/ms/1e6:8.1f} GB/s (read + write)', flush=True)
     ms = timeit(lambda: b.zero_(), iters=10)
     print(f'hbm fill 2 GiB: {ms*1e3:8.1f} us  {4*n/ms/1e6:8.1f} GB/s (write)', flush=True)
+    h = torch.empty(1 << 26, dtype=torch.float32).pin_memory()      # 256 MiB pinned
+    d = torch.empty(1 << 26, device=dev, dtype=torch.float32)
+    ms = timeit(lambda: d.copy_(h, non_blocking=True), iters=5)
+    print(f'pinned H2D 256 MiB: {ms*1e3:8.1f} us  {4*(1<<26)/ms/1e6:8.1f} GB/s', flush=True)
+    ms = timeit(lambda: h.copy_(d, non_blocking=True), iters=5)
+    print(f'pinned D2H 256 MiB: {ms*1e3:8.1f} us  {4*(1<<26)/ms/1e6:8.1f} GB/s', flush=True)
     ms = timeit(lambda: a.sum(), iters=10)
     print(f'hbm read 2 GiB (sum): {ms*1e3:8.1f} us  {4*n/ms/1e6:8.1f} GB/s (read)', flush=True)
 
