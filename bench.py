@@ -361,11 +361,13 @@ def main():
         # double-buffered feeder (feeder.py; the reference copies synchronously on the compute stream, runner.py:431-432, 556-557)
         from speech_enhancement_by_s3prl_amd.feeder import HostBatchFeeder
         host_l, host_w = lengths.cpu().pin_memory(), wavs.cpu().pin_memory()
-        for dl, dw in HostBatchFeeder([(host_l, host_w)] * args.warmup, dev):
+        feeder = HostBatchFeeder([(host_l, host_w)] * args.warmup, dev)
+        for dl, dw in feeder:
             step(dw, dl, max_len)
         torch.cuda.synchronize()
+        feeder.batches = [(host_l, host_w)] * args.steps          # same slots: device buffers are allocated once, as in a real loop
         t0 = time.perf_counter()
-        for dl, dw in HostBatchFeeder([(host_l, host_w)] * args.steps, dev):
+        for dl, dw in feeder:
             step(dw, dl, max_len)
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
@@ -373,11 +375,13 @@ def main():
                            'bytes_per_step': host_w.numel() * 4 + host_l.numel() * 8,
                            'note': 'rank 0 only; batches DMA-ed from pinned host memory on a copy stream, double buffered (PCIe-inclusive; not the headline value)'}
         # the same with only the channels the pass reads (0 = noisy, 1 = clean; runner.py:558-561) crossing PCIe
-        for dl, dw in HostBatchFeeder([(host_l, host_w)] * args.warmup, dev, channels=2):
+        feeder = HostBatchFeeder([(host_l, host_w)] * args.warmup, dev, channels=2)
+        for dl, dw in feeder:
             step(dw, dl, max_len)
         torch.cuda.synchronize()
+        feeder.batches = [(host_l, host_w)] * args.steps
         t0 = time.perf_counter()
-        for dl, dw in HostBatchFeeder([(host_l, host_w)] * args.steps, dev, channels=2):
+        for dl, dw in feeder:
             step(dw, dl, max_len)
         torch.cuda.synchronize()
         el = time.perf_counter() - t0

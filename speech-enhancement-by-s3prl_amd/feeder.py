@@ -1,8 +1,8 @@
 """Host -> HBM input stage in front of the hot path (second half).
 
 The reference hands each batch over as pageable host tensors and copies them synchronously on the compute stream
-(`wavs.to(device=self.device)`, runner.py:431-432, 556-557): 32 x 3 x 640 000 B = 61 MB per batch of 10 s utterances, ~1.2 ms of PCIe
-time in front of a ~4.4 ms step.  `HostBatchFeeder` keeps that copy off the compute stream: two pinned staging buffers, a dedicated
+(`wavs.to(device=self.device)`, runner.py:431-432, 556-557): 32 x 3 x 640 000 B = 61 MB per batch of 10 s utterances, ~1.1 ms of PCIe
+time (57 GB/s pinned) in front of a ~4.1 ms step -- 10+ ms if the source is pageable.  `HostBatchFeeder` keeps that copy off the compute stream: two pinned staging buffers, a dedicated
 copy stream, and an event per slot, so batch i+1 crosses PCIe while batch i is being enhanced (double buffering; 288 GB of HBM make the
 two device-side batch buffers irrelevant).  It wraps any iterable of (lengths, wavs) host pairs -- the DataLoader of
 runner.get_dataloader (runner.py:203-213) or a list -- and yields device tensors that are safe to use on the caller's current stream.
@@ -10,8 +10,8 @@ PyTorch is plumbing here (pinned allocations, streams, events); no kernel of the
 
 `channels=n` copies only the first n channels of every utterance (one contiguous block per utterance; the device tensor keeps the
 (B, C, T) shape, the remaining channels are left untouched): the evaluate() / train() paths read channels 0 (noisy) and 1 (clean) only
-(runner.py:433-436, 558-561: `feat_list` never names channel 2, the scaled noise), so a third of the PCIe bytes is dead weight --
-on the measured ~7 GB/s host link of the pool's boxes the host-fed loop is copy-bound, and this takes it from 8.6 to ~5.8 ms per batch.
+(runner.py:433-436, 558-561: `feat_list` never names channel 2, the scaled noise), so a third of the PCIe bytes is dead weight when the
+link, not the step, is the bound (it is not on the pool's boxes: pinned H2D runs at 57 GB/s, the 61 MB of a batch take 1.1 ms).
 """
 import torch
 
@@ -25,28 +25,35 @@ class HostBatchFeeder:
         if self.device.type != 'cuda':
             raise RuntimeError('HostBatchFeeder feeds an MI355X: device must be a HIP device')
         self.copy_stream = torch.cuda.Stream(device=self.device)
-        self._slots = [None] * self.depth          # per slot: (pinned lengths, pinned wavs, device lengths, device wavs, ready event, consumed event)
+        self._slots = [None] * self.depth          # per slot: [pinned lengths, pinned wavs, device lengths, device wavs, ready event, consumed event]
 
     def _slot(self, i, lengths, wavs):
         s = self._slots[i]
-        if s is None or s[1].shape != wavs.shape or s[0].shape != lengths.shape or s[1].dtype != wavs.dtype:
-            s = (torch.empty(lengths.shape, dtype=lengths.dtype).pin_memory(), torch.empty(wavs.shape, dtype=wavs.dtype).pin_memory(),
+        if s is None or s[3].shape != wavs.shape or s[2].shape != lengths.shape or s[3].dtype != wavs.dtype:
+            s = [None, None,                         # pinned staging: allocated only for pageable sources (pinning 61 MB takes ~25 ms)
                  torch.empty(lengths.shape, dtype=lengths.dtype, device=self.device), torch.empty(wavs.shape, dtype=wavs.dtype, device=self.device),
-                 torch.cuda.Event(), torch.cuda.Event())
+                 torch.cuda.Event(), torch.cuda.Event()]
             self._slots[i] = s
         return s
 
     def _stage(self, i, lengths, wavs):
-        """host batch -> pinned slot i -> device slot i on the copy stream; returns the slot"""
+        """host batch -> (pinned slot i ->) device slot i on the copy stream; returns the slot.  Nothing here blocks the host on COMPUTE:
+        the copy stream waits for the slot's previous consumer on the device (a host-side wait at this point would sit between two steps'
+        launches and let the GPU drain -- the first version did that and ran at 8.4 ms per batch for a 4.1 ms step)."""
         s = self._slot(i, lengths, wavs)
         pl, pw, dl, dw, ready, consumed = s
-        consumed.synchronize()                      # the compute stream is done with this slot's previous batch (no-op the first time)
         if wavs.is_pinned() and lengths.is_pinned():            # DataLoader(pin_memory=True): DMA straight from the loader's buffers
             src_l, src_w = lengths, wavs
         else:                                       # pageable -> pinned staging (one host memcpy)
+            if pl is None:
+                s[0] = pl = torch.empty(lengths.shape, dtype=lengths.dtype).pin_memory()
+                s[1] = pw = torch.empty(wavs.shape, dtype=wavs.dtype).pin_memory()
+            else:
+                ready.synchronize()                 # the previous DMA out of this staging buffer has finished (a copy, not a step)
             pl.copy_(lengths)
             pw.copy_(wavs)
             src_l, src_w = pl, pw
+        self.copy_stream.wait_event(consumed)       # device-side: the compute stream is done with this slot's previous batch
         with torch.cuda.stream(self.copy_stream):
             dl.copy_(src_l, non_blocking=True)
             n = self.channels
