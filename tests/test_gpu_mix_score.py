@@ -1,6 +1,7 @@
 """GPU parity of the stages either side of the hot path against the reference's own outputs
 (tests/golden/reference_golden.npz: add_noise, normalize_wav_decibel, sisdr_eval run from /root/reference) and against the
 host restatement (synth.py) on batches the reference cannot run (its add_noise only works at batch 1)."""
+import numpy as np
 import pytest
 import torch
 
@@ -66,3 +67,46 @@ def test_sisdr_golden_and_batch(gpu, golden):
     for b in range(B):
         ref = oobj.sisdr_eval(src[b, :lens[b]].double(), tar[b, :lens[b]].double())
         assert abs(got[b].item() - ref) < 2e-3, (b, got[b].item(), ref)
+
+
+def test_metric_stage_overlaps_and_matches_direct_scoring(gpu):
+    """runner.py:586-617 through evaluation.MetricStage: host metrics (callables of evaluation.py's shape) scored from pinned D2H copies in a
+    worker pool, 'sisdr' on the device; the aggregate equals the reference's procedure (per-batch utterance means, averaged over batches) run
+    directly, submit() does not wait for the host metrics, and results are independent of the slot reuse (3 batches through 2 slots)."""
+    import time
+    from speech_enhancement_by_s3prl_amd.evaluation import MetricStage, sisdr_batch
+    torch.manual_seed(3)
+
+    def snr_db(src, tar):                    # stands in for pesq / stoi: numpy arithmetic on 1-D CPU tensors
+        s, t = src.numpy().astype(np.float64), tar.numpy().astype(np.float64)
+        return 10.0 * np.log10((t * t).sum() / (((s - t) ** 2).sum() + 1e-12))
+
+    def slow_energy(src, tar):
+        time.sleep(0.02)
+        return float((src * src).mean())
+
+    batches = []
+    for i in range(3):
+        B, T = 4, 16000
+        tar = torch.randn(B, T) * 0.1
+        pred = tar + 0.02 * (i + 1) * torch.randn(B, T)
+        lens = torch.tensor([T, T - 1000 * (i + 1), 9000, 400])
+        batches.append((pred, tar, lens))
+    stage = MetricStage([snr_db, 'sisdr', slow_energy], gpu, n_jobs=4)
+    t0 = time.perf_counter()
+    for pred, tar, lens in batches:
+        stage.submit(pred.to(gpu), tar.to(gpu), lens.to(gpu))
+    t_submit = time.perf_counter() - t0
+    got = stage.average()
+    t_total = time.perf_counter() - t0
+    stage.close()
+    # reference procedure, directly
+    want = torch.zeros(3, dtype=torch.float64)
+    for pred, tar, lens in batches:
+        want[0] += np.mean([snr_db(pred[b, :lens[b]], tar[b, :lens[b]]) for b in range(4)])
+        want[1] += float(sisdr_batch(pred.to(gpu), tar.to(gpu), lens.to(gpu)).double().mean())
+        want[2] += np.mean([float((pred[b, :lens[b]] ** 2).mean()) for b in range(4)])
+    want /= 3
+    assert torch.allclose(got.double(), want, rtol=1e-5, atol=1e-6), (got, want)
+    # 12 sleeps of 20 ms on 4 workers >= 60 ms of host metric time: submit() must not have waited for the last batch's
+    assert t_submit < t_total - 0.015, (t_submit, t_total)

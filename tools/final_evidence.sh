@@ -16,7 +16,7 @@ python3 bench.py --workload finetune --no-cpu-baseline > "$out/${tag}_finetune_b
 python3 bench.py --workload lstm --no-cpu-baseline > "$out/${tag}_lstm_bench.json" 2> "$out/lstm.err"
 python3 tools/bench_kernels.py all > "$out/${tag}_bench_kernels.txt" 2>&1
 python3 tools/bench_kernels.py hbm >> "$out/${tag}_bench_kernels.txt" 2>&1
-python3 tools/bench_kernels.py square >> "$out/${tag}_bench_kernels.txt" 2>&1
+SE_AMD_GEMM_SMALL_M=0 python3 tools/bench_kernels.py square >> "$out/${tag}_bench_kernels.txt" 2>&1
 python3 tools/bench_kernels.py ksweep >> "$out/${tag}_bench_kernels.txt" 2>&1
 tools/micro/valu_rate > "$out/${tag}_micro_valu_rate.txt" 2>&1
 for k in gemm gemmln mhsa stft; do
