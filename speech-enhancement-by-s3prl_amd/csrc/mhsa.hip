@@ -26,11 +26,13 @@ namespace se {
 // DROP = 1 (training): the attention probabilities are dropped (counter-based mask of dropout.h, site key `dkey`) AFTER the
 // row sum, i.e. O = (P . mask / (1 - p)) V with P normalised by the full sum -- torch's dropout(softmax(.)) V
 // PRE = 1 (inference): the queries arrive PRE-SCALED by log2(e) / sqrt(64) (the encoder's inference copy of the QKV weights folds it into the
-// query rows before their bf16 rounding), so K Q'^T is already the base-2 exponent, and the running reference starts at 0 instead of -inf:
-// while every row's reference is still 0 -- the normal case: it moves only when a score exceeds it by 2^kDefer, or the first tile sits
-// below 2^-64 -- the probabilities are exp2(S) with NO per-element VALU op in front of the exponential (was one v_fma each: 32 of the
-// ~190 vector instructions of a wave's key tile, in a loop whose vector issue is busy 64 % of the cycles against 36 % for the matrix pipe;
-// profiles/r02_pmc_*.json).  fp32 / bf16 keep their relative precision anywhere in |S| < 64 + kDefer.
+// query rows before their bf16 rounding), so K Q'^T is already the base-2 exponent, and the running reference starts at 0 instead of -inf.
+// Tiles are then SPECULATIVE: P = exp2(S) against the reference 0 with no row maximum, no lane exchange, no reference update and no
+// rescale test (~50 of the ~190 vector instructions of a wave's key tile, in a loop whose vector issue is the bound: PMC 56-63 % vector
+// issue against 36 % matrix pipe, profiles/r02*_pmc_sq_mhsa.json); the scores stay intact in their accumulators, and a row sum outside
+// [2^-60, 2^60) (overflow, inf / nan, or -- first tile -- a row far below the reference) sends the wave to the exact online-softmax tile
+// for this tile and every later one.  fp32 / bf16 keep their relative precision anywhere in that range.  Same box: 133 us speculative
+// against 147 us always-exact (SE_AMD_MHSA_SPEC=0) per B = 32 launch.
 template <int OCC, int DROP, int PRE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void mhsa_fwd_kernel(
     const uint16_t* __restrict__ qkv, const int32_t* __restrict__ lengths, int T, int H, uint16_t* __restrict__ ctx,
@@ -101,6 +103,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
 #pragma unroll
   for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
   float m_run = PRE ? 0.f : -INFINITY, l_run = 0.f;
+  bool slow = dscale < 0.f;           // wave-uniform: the speculative (no row maximum) path failed once (PRE only); dscale < 0: never speculate (A/B switch)
   const float c = PRE ? 1.0f : 0.125f * 1.44269504088896340736f;     // 1/sqrt(64) * log2(e), unless the queries carry it already
   constexpr float kDefer = 8.f;
   typedef float f2 __attribute__((ext_vector_type(2)));
@@ -148,6 +151,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
         if (key + 32 >= len) s1[r] = -INFINITY;                                                                            \
       }                                                                                                                    \
     }                                                                                                                      \
+    bf16x8 pf[2][2];                                                                                                       \
+    bool spec_ok = false;                                                                                                  \
+    if (PRE && !DROP && !slow) {                                                                                           \
+      /* SPECULATIVE tile: probabilities against the initial reference 0, no row maximum at all -- 16 v_max3, the lane exchange,  */ \
+      /* the reference update and the rescale test are ~30 of the tile's ~135 vector instructions (8 % of the launch, measured).  */ \
+      /* The scores stay intact in s0 / s1 (the exponentials go straight into the bf16 fragments), and the row sums tell whether   */ \
+      /* the speculation held: a partial sum that left [2^-60, 2^60) (overflow / inf / nan; on the first tile also underflow: a    */ \
+      /* row far below the reference) sends the wave down the exact online-softmax path below, for this tile and all later ones.  */ \
+      float rs0 = 0.f, rs1 = 0.f;                                                                                          \
+      _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                                        \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                                    \
+          const float a0 = __builtin_amdgcn_exp2f(s0[8 * s + j]);                                                          \
+          const float a1 = __builtin_amdgcn_exp2f(s1[8 * s + j]);                                                          \
+          rs0 += a0;                                                                                                       \
+          rs1 += a1;                                                                                                       \
+          pf[0][s][j] = (__bf16)a0;                                                                                        \
+          pf[1][s][j] = (__bf16)a1;                                                                                        \
+        }                                                                                                                  \
+      const float rs = rs0 + rs1;                                                                                          \
+      const bool bad = !(rs < 0x1p60f) || (kt == 0 && rs < 0x1p-60f);                                                      \
+      if (!__any(bad)) {                                                                                                   \
+        l_run += rs;                                                                                                       \
+        spec_ok = true;                                                                                                    \
+      } else {                                                                                                             \
+        slow = true;                                                                                                       \
+      }                                                                                                                    \
+    }                                                                                                                      \
+    if (!spec_ok) {                                                                                                        \
     float mx = fmaxf(s0[0], s1[0]);                                                                                        \
     _Pragma("unroll") for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, s0[r]), s1[r]);       /* v_max3_f32 */            \
     {   /* the other 32 keys of this query row live in lane ^ 32: v_permlane32_swap (VALU) instead of ds_bpermute (an LDS round trip */ \
@@ -164,22 +195,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
     /* the two plain instructions they replace in this VALU-bound loop (148 -> 141 us per launch)                               */  \
     const float mc = -m_new * c;                                                                                           \
     float rs0 = 0.f, rs1 = 0.f;                                                                                            \
-    if (PRE && __all(m_new == 0.f)) {                                                                                      \
-      _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                                     \
-        const float a0 = __builtin_amdgcn_exp2f(s0[r]);                                                                    \
-        const float a1 = __builtin_amdgcn_exp2f(s1[r]);                                                                    \
-        rs0 += a0;                                                                                                         \
-        rs1 += a1;                                                                                                         \
-        s0[r] = a0; s1[r] = a1;                                                                                            \
-      }                                                                                                                    \
-    } else {                                                                                                               \
-      _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                                     \
-        const float a0 = __builtin_amdgcn_exp2f(PRE ? s0[r] + mc : fmaf(s0[r], c, mc));                                    \
-        const float a1 = __builtin_amdgcn_exp2f(PRE ? s1[r] + mc : fmaf(s1[r], c, mc));                                    \
-        rs0 += a0;                                                                                                         \
-        rs1 += a1;                                                                                                         \
-        s0[r] = a0; s1[r] = a1;                                                                                            \
-      }                                                                                                                    \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                                       \
+      const float a0 = __builtin_amdgcn_exp2f(PRE ? s0[r] + mc : fmaf(s0[r], c, mc));                                      \
+      const float a1 = __builtin_amdgcn_exp2f(PRE ? s1[r] + mc : fmaf(s1[r], c, mc));                                      \
+      rs0 += a0;                                                                                                           \
+      rs1 += a1;                                                                                                           \
+      s0[r] = a0; s1[r] = a1;                                                                                              \
     }                                                                                                                      \
     const f2 rs2 = {rs0, rs1};                                                                                             \
     l_run = fmaf(l_run, alpha, rs2.x + rs2.y);                                                                             \
@@ -196,12 +217,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
         s1[r] *= dropout_mul(b1, 0, thr16, dscale); s1[r + 1] *= dropout_mul(b1, 1, thr16, dscale);                        \
       }                                                                                                                    \
     }                                                                                                                      \
-    bf16x8 pf[2][2];                                                                                                       \
     _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                                          \
       _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                                      \
         pf[0][s][j] = (__bf16)s0[8 * s + j];                                                                               \
         pf[1][s][j] = (__bf16)s1[8 * s + j];                                                                               \
       }                                                                                                                    \
+    }                                                                                                                      \
     _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                                                       \
       _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                                      \
         _Pragma("unroll") for (int dblk = 0; dblk < 2; ++dblk) {                                                           \
@@ -294,7 +315,9 @@ static int mhsa_prescaled_launch(const uint16_t* qkv, const int32_t* lengths, in
     pipe_occ = o ? atoi(o) : 2;
   }
   if (pipe) return se_mhsa_fwd_pipe_launch(qkv, lengths, B, T, heads, ctx, pipe_occ, se::as_stream(stream));
-  hipLaunchKernelGGL((se::mhsa_fwd_kernel<3, 0, 1>), grid, dim3(256), 0, se::as_stream(stream), qkv, lengths, T, H, ctx, nullptr, 0u, 0u, 1.f);
+  static int spec = -1;
+  if (spec < 0) { const char* e = getenv("SE_AMD_MHSA_SPEC"); spec = e ? atoi(e) : 1; }      // 0: always the exact online-softmax tile (A/B)
+  hipLaunchKernelGGL((se::mhsa_fwd_kernel<3, 0, 1>), grid, dim3(256), 0, se::as_stream(stream), qkv, lengths, T, H, ctx, nullptr, 0u, 0u, spec ? 1.f : -1.f);
   SE_LAUNCH_CHECK();
   return SE_OK;
 }

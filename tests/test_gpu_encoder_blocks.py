@@ -140,6 +140,30 @@ def test_mhsa_prescaled_rising_maxima(gpu, variant):
     assert err < 2e-2 * ref.abs().max().item(), err
 
 
+@pytest.mark.parametrize('variant', [0, 1])
+@pytest.mark.parametrize('level', [-90.0, -30.0, 70.0])
+def test_mhsa_prescaled_far_from_reference(gpu, variant, level):
+    """every score sits near `level` (base-2 exponent domain): far BELOW the initial reference 0 the speculative exp2(S) of the first tile
+    underflows its range test, far ABOVE it overflows -- both must fall back to the exact online softmax (and -30 must not need to)."""
+    L = _lib()
+    lib = L.load()
+    B, T, heads = 1, 200, 1
+    torch.manual_seed(int(abs(level)))
+    u = torch.ones(64, device=gpu) / 8.0
+    q = (u[None, :] * level).repeat(T, 1)                                      # q' . k = level * (1 + small)
+    k = u[None, :] * (1.0 + 0.02 * torch.randn(T, 1, device=gpu))
+    v = torch.randn(T, 64, device=gpu)
+    qkv = torch.cat([q, k, v], dim=1).bfloat16()
+    ctx = torch.empty(T, 64, device=gpu, dtype=torch.bfloat16)
+    L.check(lib.se_mhsa_fwd_prescaled_variant_bf16(L.ptr(qkv), None, B, T, heads, L.ptr(ctx), variant, L.stream()), 'se_mhsa_fwd_prescaled_variant_bf16')
+    x = qkv.double()
+    S = (x[:, :64] @ x[:, 64:128].T) * 0.6931471805599453
+    ref = torch.softmax(S, dim=-1) @ x[:, 128:]
+    got = ctx.double()
+    assert torch.isfinite(got).all()
+    assert (got - ref).abs().max().item() < 2e-2 * ref.abs().max().item()
+
+
 def test_mhsa_rising_maxima(gpu):
     """Row maxima that climb tile after tile, by less than the deferred-rescale threshold for some query rows and by more for
     others in the same wave: exercises both sides of the (rare, data-dependent) rescale branch of the online softmax."""
