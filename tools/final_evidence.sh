@@ -18,6 +18,7 @@ python3 tools/bench_kernels.py all > "$out/${tag}_bench_kernels.txt" 2>&1
 python3 tools/bench_kernels.py hbm >> "$out/${tag}_bench_kernels.txt" 2>&1
 SE_AMD_GEMM_SMALL_M=0 python3 tools/bench_kernels.py square >> "$out/${tag}_bench_kernels.txt" 2>&1
 python3 tools/bench_kernels.py ksweep >> "$out/${tag}_bench_kernels.txt" 2>&1
+[ -x tools/micro/valu_rate ] || /opt/rocm/bin/hipcc -O3 -fno-slp-vectorize --offload-arch=gfx950 -o tools/micro/valu_rate tools/micro/valu_rate.hip
 tools/micro/valu_rate > "$out/${tag}_micro_valu_rate.txt" 2>&1
 for k in gemm gemmln mhsa stft; do
   tools/pmc_sq.sh ${tag}_$k tools/bench_kernels.py $k > "$out/pmc_sq_$k.log" 2>&1
