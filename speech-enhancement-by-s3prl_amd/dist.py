@@ -208,21 +208,24 @@ class DataParallelTrainStep:
             engines = [m._engine for m in model.modules() if hasattr(m, '_engine') and hasattr(m, 'model') and hasattr(m._engine, 'encode_train')]
             if engines:
                 self.sink = BucketedGradSink(self.reducer)
-                for e in engines:
-                    e.grad_sink = self.sink
         self._engines = engines if self.sink is not None else []
 
-    def close(self):
-        """Detach the gradient sink: a plain loss.backward() on the model fills .grad again."""
+    def _attach(self, on):
+        """The sink is registered on the engines only while step() runs its backward: a plain loss.backward() on the same model --
+        outside this class -- fills .grad as usual."""
         for e in self._engines:
-            e.grad_sink = None
-        self._engines, self.sink = [], None
+            e.grad_sink = self.sink if on else None
 
     def step(self, loss):
         """loss already computed with the global-mean criterion; backward, all-reduce, clip, (maybe) step."""
         if self.sink is not None:
             self.sink.begin()
-        loss.backward()
+            self._attach(True)
+        try:
+            loss.backward()
+        finally:
+            if self.sink is not None:
+                self._attach(False)
         fused = getattr(self.optimizer, 'step_fused', None) is not None and self.reducer.flat.is_cuda
         if fused:
             # device path: gradients stay in the flat (all-reduced) buffer; norms in one launch, global clip + per-tensor clip +
