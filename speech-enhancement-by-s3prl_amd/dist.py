@@ -70,8 +70,11 @@ class FlatGradAllReducer:
             off += p.numel()
 
     def _gather(self, skip=()):
-        """per-parameter gradients -> the flat buffer (`skip`: parameter indices whose views were written in place by the backward).  On the GPU: ONE batched copy launch (se_multi_copy_f32) instead of a torch
+        """per-parameter gradients -> the flat buffer (`skip`: parameter indices whose views were written in place by the backward).
+        Records which parameters HAD a gradient this step (`self.active`): the optimizer must skip the others entirely -- BertAdam's
+        `if p.grad is None: continue` -- instead of decaying them against a zero gradient.  On the GPU: ONE batched copy launch (se_multi_copy_f32) instead of a torch
         copy kernel per tensor (~100 launches per step for the Mockingjay encoder)."""
+        self.active = [(i in skip) or (p.grad is not None) for i, p in enumerate(self.params)]
         if not self.flat.is_cuda:
             for i, (p, v) in enumerate(zip(self.params, self.views)):
                 if i in skip:
@@ -130,7 +133,9 @@ class FlatGradAllReducer:
                     prev = i
                 sink.wait()
         if copy_back:
-            for p, v in zip(self.params, self.views):
+            for p, v, a in zip(self.params, self.views, self.active):
+                if not a:
+                    continue                 # no gradient on any rank: stays None (the optimizer skips it, as the reference's does)
                 if p.grad is None:
                     p.grad = v.clone()
                 else:
@@ -231,7 +236,8 @@ class DataParallelTrainStep:
             # device path: gradients stay in the flat (all-reduced) buffer; norms in one launch, global clip + per-tensor clip +
             # BertAdam in one more.  The skip decision reads the reduced norm, identically on every rank.
             self.reducer.reduce(copy_back=False, sink=self.sink)
-            tab = self.optimizer._fused_table(grads=dict(zip(self.reducer.params, self.reducer.views)))
+            act = self.reducer.active          # the same on every rank (same graph); a gradient-free parameter is not touched (no decay)
+            tab = self.optimizer._fused_table(grads={p: v for p, v, a in zip(self.reducer.params, self.reducer.views, act) if a})
             if tab is not None:
                 sumsq = self.optimizer.grad_sumsq(tab)
                 gn = float(sumsq.sum().sqrt())
@@ -240,8 +246,9 @@ class DataParallelTrainStep:
                     self.optimizer.step_fused(tab, sumsq, global_max_norm=self.grad_clip)
                 self.optimizer.zero_grad()
                 return gn, skipped
-            for p, v in zip(self.reducer.params, self.reducer.views):
-                p.grad = v.clone() if p.grad is None else p.grad.copy_(v)
+            for p, v, a in zip(self.reducer.params, self.reducer.views, act):
+                if a:
+                    p.grad = v.clone() if p.grad is None else p.grad.copy_(v)
         else:
             self.reducer.reduce(sink=self.sink)
         grad_norm = torch.nn.utils.clip_grad_norm_(self.reducer.params, self.grad_clip)

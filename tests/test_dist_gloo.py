@@ -59,8 +59,10 @@ def _worker(rank, world, port, q):
         m.running_mean.fill_(float(10 * rank + 5))
     sdist.broadcast_parameters(m)
     assert torch.equal(m.weight, torch.ones(3)) and torch.equal(m.running_mean, torch.full((3,), 5.0))
-    red = sdist.FlatGradAllReducer([W, b])
-    flat = red.reduce().clone()
+    unused = torch.ones(3, requires_grad=True)       # a parameter no loss term touches: grad stays None on every rank
+    red = sdist.FlatGradAllReducer([W, b, unused])
+    flat = red.reduce()[:W.numel() + b.numel()].clone()
+    assert red.active == [True, True, False] and unused.grad is None      # BertAdam's `if p.grad is None: continue` still applies
     gn = torch.nn.utils.clip_grad_norm_([W, b], 1.0)
     q.put((rank, idx, loss_global, flat, float(gn), W.grad.clone(), b.grad.clone()))
     dist.barrier()
