@@ -378,7 +378,7 @@ __global__ __launch_bounds__(k4Threads) __attribute__((amdgpu_waves_per_eu(2, 2)
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int k7WSlot = 256 * 128, k7ASlot = 128 * 128, k7ABase = 4 * k7WSlot, k7Lds = 4 * k7WSlot + 2 * k7ASlot;     // 32 KiB, 16 KiB, 160 KiB
 
-template <int GELU, int RIN, int ROUT>
+template <int GELU, int RIN, int ROUT, int INM = 0>
 __global__ __launch_bounds__(k4Threads) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm7_res_ln_kernel(
     const uint16_t* __restrict__ A, int lda, const uint16_t* __restrict__ W, int ldw, const float* __restrict__ bias,
     const float* __restrict__ residual, const float* __restrict__ ln_w, const float* __restrict__ ln_b, float eps, int M, int K,
@@ -476,8 +476,10 @@ __global__ __launch_bounds__(k4Threads) __attribute__((amdgpu_waves_per_eu(2, 2)
 #pragma unroll
         for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(smem + a_sl + a_ad[s2] + i * 2048);
         // staging (see the header): piece q + 3 -> the slot piece q - 1 left at the end of the previous phase; A (t + 1) -> the slot A (t - 1) left
-        if (p == 0 && s2 == 0 && t + 1 < nk) SE7_DMA_A(t + 1);
-        if (q + 3 < npieces) SE7_DMA_W(t + 1, p, s2);         // piece q + 3 = piece p of K-tile t + 1
+        if (!INM) {
+          if (p == 0 && s2 == 0 && t + 1 < nk) SE7_DMA_A(t + 1);
+          if (q + 3 < npieces) SE7_DMA_W(t + 1, p, s2);         // piece q + 3 = piece p of K-tile t + 1
+        }
         if (s2 == 1) {
           // piece q + 1 (and, before a new K-tile, its activation piece) complete: everything issued during pieces q - 1 and q may stay in flight
           const int n = (q + 2 < npieces ? 4 : 0) + (q + 3 < npieces ? 4 : 0) + ((p == 0 || p == 1) && t + 1 < nk ? 2 : 0);
@@ -496,10 +498,18 @@ __global__ __launch_bounds__(k4Threads) __attribute__((amdgpu_waves_per_eu(2, 2)
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i) {
 #pragma unroll
           for (int jj = 0; jj < 4; ++jj)
             acc[i][4 * p + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[jj], af[i], acc[i][4 * p + jj], 0, 0, 0);
+          if (INM) {          // the ring refill between the MFMA groups instead of in the read phase (A/B, whole step: 4.199 -> 4.147 ms;
+                              // one part per group instead of two after the first: 4.17-4.19)
+            __builtin_amdgcn_sched_barrier(0);
+            if (i == 0 && q + 3 < npieces) SE7_DMA_W(t + 1, p, s2);
+            if (i == 1 && p == 0 && s2 == 0 && t + 1 < nk) SE7_DMA_A(t + 1);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
@@ -564,14 +574,26 @@ static int gemm4_launch(const uint16_t* A, int lda, const uint16_t* W, int ldw, 
   }
   // 64-deep K-tiles (gemm7): whole K-tiles, at least two, 32-bit source offsets
   if (use7 && K % 64 == 0 && K >= 128 && (size_t)M * lda < (1u << 31) && (size_t)se::k4N * ldw < (1u << 31)) {
-#define SE7_LAUNCH(GE, RI, RO)                                                                                                            \
-  hipLaunchKernelGGL((se::gemm7_res_ln_kernel<GE, RI, RO>), dim3(ntiles), dim3(se::k4Threads), se::k7Lds, st, A, lda, W, ldw, bias, residual_f32, \
+#define SE7_LAUNCH(GE, RI, RO, IM)                                                                                                        \
+  hipLaunchKernelGGL((se::gemm7_res_ln_kernel<GE, RI, RO, IM>), dim3(ntiles), dim3(se::k4Threads), se::k7Lds, st, A, lda, W, ldw, bias, residual_f32, \
                      ln_w, ln_b, eps, M, K, out_f32, out_bf16, ntiles, res_mod, res_lo, out_lo)
-    if (gelu_no_residual) SE7_LAUNCH(1, 0, 0);
-    else if (rin && rout) SE7_LAUNCH(0, 1, 1);
-    else if (rin) SE7_LAUNCH(0, 1, 0);
-    else if (rout) SE7_LAUNCH(0, 0, 1);
-    else SE7_LAUNCH(0, 0, 0);
+    static int inm7 = -1;
+    if (inm7 < 0) {
+      const char* e = getenv("SE_AMD_GEMM7_INM");        // 0: ring refill issued in the read phase (the first version of this kernel)
+      inm7 = e ? atoi(e) : 1;
+      SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::gemm7_res_ln_kernel<1, 0, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, se::k7Lds));
+      SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::gemm7_res_ln_kernel<0, 0, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, se::k7Lds));
+      SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::gemm7_res_ln_kernel<0, 0, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, se::k7Lds));
+      SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::gemm7_res_ln_kernel<0, 1, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, se::k7Lds));
+      SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::gemm7_res_ln_kernel<0, 1, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, se::k7Lds));
+    }
+#define SE7_PICK(GE, RI, RO) do { if (inm7) SE7_LAUNCH(GE, RI, RO, 1); else SE7_LAUNCH(GE, RI, RO, 0); } while (0)
+    if (gelu_no_residual) SE7_PICK(1, 0, 0);
+    else if (rin && rout) SE7_PICK(0, 1, 1);
+    else if (rin) SE7_PICK(0, 1, 0);
+    else if (rout) SE7_PICK(0, 0, 1);
+    else SE7_PICK(0, 0, 0);
+#undef SE7_PICK
 #undef SE7_LAUNCH
     SE_LAUNCH_CHECK();
     return SE_OK;
