@@ -482,7 +482,8 @@ __global__ __launch_bounds__(k4Threads) __attribute__((amdgpu_waves_per_eu(2, 2)
         }
         if (s2 == 1) {
           // piece q + 1 (and, before a new K-tile, its activation piece) complete: everything issued during pieces q - 1 and q may stay in flight
-          const int n = (q + 2 < npieces ? 4 : 0) + (q + 3 < npieces ? 4 : 0) + ((p == 0 || p == 1) && t + 1 < nk ? 2 : 0);
+          // (INM: this phase's own half of piece q + 3 is issued AFTER this wait, between the MFMA groups: two parts fewer are in flight here)
+          const int n = (q + 2 < npieces ? 4 : 0) + (q + 3 < npieces ? (INM ? 2 : 4) : 0) + ((p == 0 || p == 1) && t + 1 < nk ? 2 : 0);
           switch (n) {
             case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
             case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
