@@ -497,7 +497,7 @@ __global__ __launch_bounds__(k4Threads) __attribute__((amdgpu_waves_per_eu(2, 2)
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
+        if (!INM) __builtin_amdgcn_s_setprio(1);        // with the refill between the MFMA groups the raised priority costs ~1 % of the step (A/B)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -511,7 +511,7 @@ __global__ __launch_bounds__(k4Threads) __attribute__((amdgpu_waves_per_eu(2, 2)
             __builtin_amdgcn_sched_barrier(0);
           }
         }
-        __builtin_amdgcn_s_setprio(0);
+        if (!INM) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
