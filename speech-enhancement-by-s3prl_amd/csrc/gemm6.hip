@@ -385,34 +385,47 @@ __global__ __launch_bounds__(k6Threads) __attribute__((amdgpu_waves_per_eu(2, 2)
 #define SE6_MMA_HALF(mq, nq, s_)                                                                                           \
   _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                        \
     acc[(mq) * 4 + i_][(nq) * 2 + j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j_][s_], af[i_][s_], acc[(mq) * 4 + i_][(nq) * 2 + j_], 0, 0, 0);
-#define SE6P_ISSUE_MID_BEGIN if (INM) { __builtin_amdgcn_sched_barrier(0);
+#undef SE6_SYNC_A
+#undef SE6_SYNC_B
+#define SE6_SYNC_A()                                                                                                       \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                       \
+  __builtin_amdgcn_sched_barrier(0);                                                                                       \
+  __builtin_amdgcn_s_barrier();                                                                                            \
+  __builtin_amdgcn_sched_barrier(0);                                                                                       \
+  if (INM != 2) __builtin_amdgcn_s_setprio(1);
+#define SE6_SYNC_B()                                                                                                       \
+  if (INM != 2) __builtin_amdgcn_s_setprio(0);                                                                             \
+  __builtin_amdgcn_sched_barrier(0);                                                                                       \
+  __builtin_amdgcn_s_barrier();                                                                                            \
+  __builtin_amdgcn_sched_barrier(0);
+#define SE6P_ISSUE_MID_BEGIN if (INM == 1) { __builtin_amdgcn_sched_barrier(0);
 #define SE6P_ISSUE_MID_END __builtin_amdgcn_sched_barrier(0); }
 #define SE6P_TILE(BUF, I1, I2, I3, I4, WAIT)                                                                               \
   {                                                                                                                        \
     SE6_READ_B(BUF, 0)                                                                                                     \
     SE6_READ_A(BUF, 0)                                                                                                     \
-    if (!INM) { I1; }                                                                                                      \
+    if (INM != 1) { I1; }                                                                                                    \
     SE6_SYNC_A()                                                                                                           \
     SE6_MMA_HALF(0, 0, 0)                                                                                                  \
     SE6P_ISSUE_MID_BEGIN I1; SE6P_ISSUE_MID_END                                                                            \
     SE6_MMA_HALF(0, 0, 1)                                                                                                  \
     SE6_SYNC_B()                                                                                                           \
     SE6_READ_B(BUF, 1)                                                                                                     \
-    if (!INM) { I2; }                                                                                                      \
+    if (INM != 1) { I2; }                                                                                                    \
     SE6_SYNC_A()                                                                                                           \
     SE6_MMA_HALF(0, 1, 0)                                                                                                  \
     SE6P_ISSUE_MID_BEGIN I2; SE6P_ISSUE_MID_END                                                                            \
     SE6_MMA_HALF(0, 1, 1)                                                                                                  \
     SE6_SYNC_B()                                                                                                           \
     SE6_READ_A(BUF, 1)                                                                                                     \
-    if (!INM) { I3; }                                                                                                      \
+    if (INM != 1) { I3; }                                                                                                    \
     SE6_SYNC_A()                                                                                                           \
     SE6_MMA_HALF(1, 1, 0)                                                                                                  \
     SE6P_ISSUE_MID_BEGIN I3; SE6P_ISSUE_MID_END                                                                            \
     SE6_MMA_HALF(1, 1, 1)                                                                                                  \
     SE6_SYNC_B()                                                                                                           \
     SE6_READ_B(BUF, 0)                                                                                                     \
-    if (!INM) { I4; }                                                                                                      \
+    if (INM != 1) { I4; }                                                                                                    \
     WAIT;                                                                                                                  \
     SE6_SYNC_A()                                                                                                           \
     SE6_MMA_HALF(1, 0, 0)                                                                                                  \
@@ -421,7 +434,7 @@ __global__ __launch_bounds__(k6Threads) __attribute__((amdgpu_waves_per_eu(2, 2)
     SE6_SYNC_B()                                                                                                           \
   }
 #define SE6P_NOP ((void)0)
-#define SE6P_W6 do { if (INM) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); } while (0)
+#define SE6P_W6 do { if (INM == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); } while (0)
 #define SE6P_W0 asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 
   // bias of every output column, staged once in the LDS beside the ring: the tile loop then contains no compiler-visible VMEM load at all
@@ -460,7 +473,7 @@ __global__ __launch_bounds__(k6Threads) __attribute__((amdgpu_waves_per_eu(2, 2)
 
     // K-tile 0: B_0 (1) is already on its way.  Its wait must not cover the previous tile's stores (issued after B_0 (1)): 6 + 16.
     SE6P_TILE(0, SE6P_NOP, SE6P_DMA(A, a_of[0], k6A0, 0, 2), SE6P_DMA(W, b_of[1], k6B1, 0, 2), SE6P_DMA(A, a_of[1], k6A1, 0, 2),
-              if (stores_pending) { if (INM) asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(22)" ::: "memory"); } else SE6P_W6)
+              if (stores_pending) { if (INM == 1) asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(22)" ::: "memory"); } else SE6P_W6)
     SE6P_TILE(1, SE6P_DMA(W, b_of[0], k6B0, 0, 2), SE6P_DMA(A, a_of[0], k6A0, 1, 3), SE6P_DMA(W, b_of[1], k6B1, 1, 3), SE6P_DMA(A, a_of[1], k6A1, 1, 3), SE6P_W6)
     for (int t = 2; t + 2 < nk; t += 2) {
       SE6P_TILE(0, SE6P_DMA(W, b_of[0], k6B0, 1, t + 1), SE6P_DMA(A, a_of[0], k6A0, 0, t + 2), SE6P_DMA(W, b_of[1], k6B1, 0, t + 2),
@@ -565,12 +578,18 @@ int launch6p(const G6Args& g) {
     if (n_cu < 8) n_cu = 8;
     SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::gemm6p_bf16_kernel<ACT, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, se::k6Lds + 32768));
     SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::gemm6p_bf16_kernel<ACT, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, se::k6Lds + 32768));
+    SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::gemm6p_bf16_kernel<ACT, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, se::k6Lds + 32768));
     attr_set = true;
   }
   static int inm = -1;
-  if (inm < 0) { const char* e = getenv("SE_AMD_GEMM6P_INM"); inm = e ? atoi(e) : 0; }      // 1: LDS-DMA issue between the MFMA groups (A/B)
+  // 0: the first form (DMA issue in the read section, raised wave priority around the MFMA groups); 1: DMA issue between the MFMA groups
+  // (A/B: tie); 2 (default): the first form without the priority change (A/B, whole step: 4.018 -> 4.003 ms)
+  if (inm < 0) { const char* e = getenv("SE_AMD_GEMM6P_INM"); inm = e ? atoi(e) : 2; }
   const int grid = std::min(n_cu, (tiles_m * tiles_n + 7) & ~7);
-  if (inm)
+  if (inm == 2)
+    hipLaunchKernelGGL((se::gemm6p_bf16_kernel<ACT, 2>), dim3(grid), dim3(se::k6Threads), se::k6Lds + g.N * 4, g.st, g.A, g.lda, g.W, g.ldw, g.bias, g.M, g.N,
+                       g.K, g.out_bf16, g.ldc, tiles_m, tiles_n, group_m, late_start);
+  else if (inm)
     hipLaunchKernelGGL((se::gemm6p_bf16_kernel<ACT, 1>), dim3(grid), dim3(se::k6Threads), se::k6Lds + g.N * 4, g.st, g.A, g.lda, g.W, g.ldw, g.bias, g.M, g.N,
                        g.K, g.out_bf16, g.ldc, tiles_m, tiles_n, group_m, late_start);
   else
