@@ -21,6 +21,8 @@ FLAGS = ['-O3', '-std=c++17', '-fPIC', f'--offload-arch={ARCH}', '-fno-gpu-rdc',
          '-Wno-comment', '-I' + os.path.join(HERE, '..', 'include')]
 if os.environ.get('SE_AMD_BUILD_STAMPS') == '1':       # developer build: in-kernel s_memtime stamps (tools/*_stamps.py); never for measurements
     FLAGS.append('-DSE_AMD_STAMPS')
+if os.environ.get('SE_AMD_EXTRA_DEFINES'):              # developer A/B builds, e.g. -DSE_AMD_OLD_CODEC
+    FLAGS.extend(os.environ['SE_AMD_EXTRA_DEFINES'].split())
 # per-file extra flags.  The flash attention forward and the STFT / iSTFT are VALU-issue bound and v_pk_*_f32 (what the SLP vectoriser
 # makes of adjacent fp32 adds / multiplies) costs more issue time there than the two plain instructions it replaces: MHSA 147 -> 139 us,
 # STFT 2.57 -> 2.78 TB/s.  Applied to every file it is a small net loss (GEMM epilogues, element-wise passes), hence per file.

@@ -41,17 +41,35 @@ __device__ __forceinline__ int swz4(int row, int chunk) { return row * 64 + ((ch
 //      reads anyway, round-to-nearest) + int8 lo = round((y - hi) * 2^(15 - E)), E = exponent of hi: 16 mantissa bits (2^-17 relative; the
 //      encoder's error against fp32 is unchanged: 3.177e-3 vs 3.172e-3 relative L2) for 3 B per element instead of 4 + 2.  lo lives in the
 //      accumulator's own layout (one contiguous 256-B block per wave, row tile and column tile): written and read by the same lane.
+// Both directions are written on the bit patterns (this codec runs on all 192 accumulators of a wave at both ends of every row-complete
+// launch: the first, float-select form cost ~24 vector instructions per element pair of directions, ~10 % of a K = 768 launch):
+//   2^(E - 15) = bits(hi) & 0x7f800000 - (15 << 23), clamped at 0 (|hi| < 2^-112: lo is ignored);  2^(15 - E) = (269 << 23) - the same field
+//   round-to-nearest-even + two's-complement byte = low 8 bits of (q + 1.5 * 2^23) after clamping q to [-128, 127]
+#ifdef SE_AMD_OLD_CODEC      // A/B build switch (SE_AMD_EXTRA_DEFINES=-DSE_AMD_OLD_CODEC python build.py --force): the first, float-select form
 __device__ __forceinline__ float dec24(uint32_t hi16, int lo8) {
   const uint32_t eb = (hi16 >> 7) & 0xffu;
-  const float sc = __uint_as_float(eb > 15u ? (eb - 15u) << 23 : 0u);           // 2^(E - 15); 0 below 2^-111
+  const float sc = __uint_as_float(eb > 15u ? (eb - 15u) << 23 : 0u);
   return fmaf((float)lo8, sc, __uint_as_float(hi16 << 16));
 }
 __device__ __forceinline__ uint32_t enc24_lo(float y, uint32_t hi16) {
   const uint32_t eb = (hi16 >> 7) & 0xffu;
-  const float sc = __uint_as_float((eb >= 15u && eb <= 254u) ? (269u - eb) << 23 : 0u);      // 2^(15 - E)
+  const float sc = __uint_as_float((eb >= 15u && eb <= 254u) ? (269u - eb) << 23 : 0u);
   const float q = rintf((y - __uint_as_float(hi16 << 16)) * sc);
   return (uint32_t)(int)fminf(fmaxf(q, -128.f), 127.f) & 0xffu;
 }
+#else
+__device__ __forceinline__ float dec24(uint32_t hi16, int lo8) {
+  const uint32_t hb = hi16 << 16;
+  const uint32_t ef = max(hb & 0x7f800000u, 15u << 23);
+  return fmaf((float)lo8, __uint_as_float(ef - (15u << 23)), __uint_as_float(hb));
+}
+__device__ __forceinline__ uint32_t enc24_lo(float y, uint32_t hi16) {
+  const uint32_t hb = hi16 << 16;
+  const uint32_t ef = max(hb & 0x7f800000u, 15u << 23);
+  const float q = (y - __uint_as_float(hb)) * __uint_as_float(0x86800000u - ef);       // (269 << 23) - E field = 2^(15 - E)
+  return __float_as_uint(__builtin_amdgcn_fmed3f(q, -128.f, 127.f) + 12582912.0f) & 0xffu;
+}
+#endif
 
 // acc[i][t] <- bias (+ residual): fp32 rows, or the 24-bit (bf16 hi row-major + int8 lo tile-major) stream, or a (T, 768) table indexed row % res_mod
 template <int GELU, int RIN>

@@ -57,8 +57,8 @@ out = {
     'other_kernels': bench.get('roofline_other_kernels'),
     'per_kernel_rocprof': {},
 }
-for key, sub, f in (('gemm6p_qkv', 'gemm6p_bf16_kernel<0>', flop['qkv']), ('gemm6p_ffn1_gelu', 'gemm6p_bf16_kernel<3>', flop['ffn1']),
-                    ('mhsa_fwd_prescaled', 'mhsa_fwd_kernel<3, 0, 1>', flop['mhsa'])):
+for key, sub, f in (('gemm6p_qkv', 'gemm6p_bf16_kernel<0', flop['qkv']), ('gemm6p_ffn1_gelu', 'gemm6p_bf16_kernel<3', flop['ffn1']),
+                    ('mhsa_fwd_prescaled', 'mhsa_fwd_kernel<3, 0, 1', flop['mhsa'])):
     us = avg_us(sub)
     if us:
         out['per_kernel_rocprof'][key] = {'avg_us': round(us, 1), 'TFLOPs': round(f / us / 1e6, 1), 'frac_of_2500': round(f / us / 1e6 / 2500.0, 3)}
