@@ -173,15 +173,17 @@ __device__ __forceinline__ void ln_epilogue4(f32x4 (&acc)[4][12], char* smem, in
     const size_t o = (size_t)min(gm, M - 1) * k4N + col0;
     const size_t orow8 = (size_t)min(gm, M - 1) * k4N + wc * 192 + 4 * (cq & ~1);      // first of this lane's 8 consecutive bf16 columns
     uint2 pk_prev = make_uint2(0u, 0u);
+    const float nmr = -mean[i] * rstd[i];
 #pragma unroll
     for (int t = 0; t < 12; ++t) {
       if ((t & 3) == 0) __builtin_amdgcn_sched_barrier(0);
       const float4 lw = *reinterpret_cast<const float4*>(colv + col0 + 16 * t);
       const float4 lb = *reinterpret_cast<const float4*>(colv + k4N + col0 + 16 * t);
-      const float y0 = lw.x * ((acc[i][t][0] - mean[i]) * rstd[i]) + lb.x;
-      const float y1 = lw.y * ((acc[i][t][1] - mean[i]) * rstd[i]) + lb.y;
-      const float y2 = lw.z * ((acc[i][t][2] - mean[i]) * rstd[i]) + lb.z;
-      const float y3 = lw.w * ((acc[i][t][3] - mean[i]) * rstd[i]) + lb.w;
+      // xhat = acc * rstd - mean * rstd as ONE fma (the per-row product is formed once), then lw * xhat + lb: two instructions per element
+      const float y0 = fmaf(lw.x, fmaf(acc[i][t][0], rstd[i], nmr), lb.x);
+      const float y1 = fmaf(lw.y, fmaf(acc[i][t][1], rstd[i], nmr), lb.y);
+      const float y2 = fmaf(lw.z, fmaf(acc[i][t][2], rstd[i], nmr), lb.z);
+      const float y3 = fmaf(lw.w, fmaf(acc[i][t][3], rstd[i], nmr), lb.w);
       if (!ROUT && ok && out_f32) *reinterpret_cast<float4*>(out_f32 + o + 16 * t) = make_float4(y0, y1, y2, y3);
       if (out_bf16) {
         // 16-B bf16 stores (as gemm3.hip): lanes l, l ^ 16 trade 4-column pieces of the MFMA tile pair (t - 1, t), so a lane owns 8
