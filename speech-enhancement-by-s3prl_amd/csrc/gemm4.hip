@@ -70,6 +70,25 @@ __device__ __forceinline__ uint32_t enc24_lo(float y, uint32_t hi16) {
   return __float_as_uint(__builtin_amdgcn_fmed3f(q, -128.f, 127.f) + 12582912.0f) & 0xffu;
 }
 #endif
+// the four lo bytes of (y0..y3) given their packed bf16 pairs (pk.x = hi(y0) | hi(y1) << 16, pk.y = hi(y2) | hi(y3) << 16), as one dword.
+// Fast form: the byte is the low byte of the magic-add result, so no masks; three v_perm_b32 gather the four low bytes.
+__device__ __forceinline__ uint32_t enc24_lo4(float y0, float y1, float y2, float y3, uint2 pk) {
+#ifdef SE_AMD_OLD_CODEC
+  return enc24_lo(y0, pk.x & 0xffffu) | (enc24_lo(y1, pk.x >> 16) << 8) | (enc24_lo(y2, pk.y & 0xffffu) << 16) | (enc24_lo(y3, pk.y >> 16) << 24);
+#else
+  const uint32_t hb[4] = {pk.x << 16, pk.x & 0xffff0000u, pk.y << 16, pk.y & 0xffff0000u};
+  const float y[4] = {y0, y1, y2, y3};
+  uint32_t m[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const uint32_t ef = max(hb[r] & 0x7f800000u, 15u << 23);
+    const float q = (y[r] - __uint_as_float(hb[r])) * __uint_as_float(0x86800000u - ef);
+    m[r] = __float_as_uint(__builtin_amdgcn_fmed3f(q, -128.f, 127.f) + 12582912.0f);
+  }
+  const uint32_t t01 = __builtin_amdgcn_perm(m[1], m[0], 0x0c0c0400u), t23 = __builtin_amdgcn_perm(m[3], m[2], 0x0c0c0400u);
+  return __builtin_amdgcn_perm(t23, t01, 0x05040100u);
+#endif
+}
 
 // acc[i][t] <- bias (+ residual): fp32 rows, or the 24-bit (bf16 hi row-major + int8 lo tile-major) stream, or a (T, 768) table indexed row % res_mod
 template <int GELU, int RIN>
@@ -191,7 +210,7 @@ __device__ __forceinline__ void ln_epilogue4(f32x4 (&acc)[4][12], char* smem, in
         const uint2 pk = make_uint2(pack_bf16x2(y0, y1), pack_bf16x2(y2, y3));
         if (ROUT)      // tile-major lo bytes: rows past M are written too (the buffer covers whole tiles) and never read as real rows
           *reinterpret_cast<uint32_t*>(out_lo + ((((size_t)id * 8 + wave) * 4 + i) * 12 + t) * 256 + lane * 4) =
-              enc24_lo(y0, pk.x & 0xffffu) | (enc24_lo(y1, pk.x >> 16) << 8) | (enc24_lo(y2, pk.y & 0xffffu) << 16) | (enc24_lo(y3, pk.y >> 16) << 24);
+              enc24_lo4(y0, y1, y2, y3, pk);
         if (t & 1) {
           const uint2 keep = godd ? pk : pk_prev, send = godd ? pk_prev : pk;
           uint2 recv;
