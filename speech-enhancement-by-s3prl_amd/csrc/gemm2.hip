@@ -15,6 +15,14 @@
 #include "bf16.h"
 #include "prof.h"
 
+// The raised wave priority around the MFMA clusters (s_setprio 1 ... 0) is OFF: A/B on one box, fine-tune step 19.73 -> 19.52 ms without it
+// (the same finding as for the row-complete and the persistent kernels).  SE_AMD_EXTRA_DEFINES=-DSE_AMD_SETPRIO python build.py --force brings it back.
+#ifdef SE_AMD_SETPRIO
+#define SE_SETPRIO(x) __builtin_amdgcn_s_setprio(x)
+#else
+#define SE_SETPRIO(x) ((void)0)
+#endif
+
 namespace se {
 
 constexpr int k2BN = 128, k2BK = 64;
@@ -200,12 +208,12 @@ __global__ __launch_bounds__(128 * WR) __attribute__((amdgpu_waves_per_eu(2, 2))
         const int st2 = (st + 2 >= k2Stages) ? st + 2 - k2Stages : st + 2;
         SE2_ISSUE(t + 2, st2);
       }
-      __builtin_amdgcn_s_setprio(1);
+      SE_SETPRIO(1);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
+      SE_SETPRIO(0);
       __builtin_amdgcn_sched_barrier(0);
       stamp(st_buf, st_i, st_on);          // [2] MFMA(k0) issued
       __builtin_amdgcn_s_barrier();
@@ -226,12 +234,12 @@ __global__ __launch_bounds__(128 * WR) __attribute__((amdgpu_waves_per_eu(2, 2))
       __builtin_amdgcn_s_barrier();
       stamp(st_buf, st_i, st_on);          // [6] past B0'
       __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_setprio(1);
+      SE_SETPRIO(1);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
+      SE_SETPRIO(0);
       __builtin_amdgcn_sched_barrier(0);
       stamp(st_buf, st_i, st_on);          // [7] MFMA(k1) issued
       __builtin_amdgcn_s_barrier();
