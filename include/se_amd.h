@@ -196,7 +196,7 @@ typedef struct se_encoder_config {
   float ln_eps;      /* 1e-12 */
   int spec_out;      /* 0 = no spec head; else output dim of the head (201) */
   int fused_ln_min_rows; /* rows (B*T) from which the out-proj / FFN2 projections use the row-complete GEMM + LayerNorm kernel;
-                            0 = default (24576: one launch then makes ~a full round of workgroups).  Callers that keep two half
+                            0 = default (16000: from about half a round of workgroups on the row-complete kernels win, re-measured in round 2).  Callers that keep two half
                             batches in flight on two streams set it lower: two half-size launches share the chip out of phase. */
 } se_encoder_config;
 

@@ -600,10 +600,11 @@ extern "C" int se_encoder_fwd_bf16(const se_encoder* enc, const float* feats, co
     fuse_env = e ? atoi(e) : 1;
   }
   // the row-complete GEMM + LayerNorm kernel owns 128 x 768 outputs per workgroup: M / 128 workgroups.  It needs ~a full round of the
-  // 256 CUs to pay off (B = 32: 251 workgroups); below ~24 k rows the unfused GEMM + LayerNorm pair is faster (B = 16: 3.19 vs 3.31 ms,
-  // B = 1: 8 workgroups, 0.85 vs 1.70 ms).  SE_AMD_FUSED_LN = 2 forces it.  Between its launches the residual stream travels as
+  // 256 CUs to pay off (B = 32: 251 workgroups).  Threshold re-measured with the round-2 kernels (ms per pass, unfused / row-complete):
+  // B = 12: 2.28 / 2.42, B = 16: 2.66 / 2.61, B = 20: 3.10 / 2.87, B = 24: 3.94 / 3.28 -- the round-1 threshold of 24 576 rows left B = 17..24 on
+  // the slower side; it is now 16 000 rows (B = 1: 8 workgroups, 0.85 vs 1.70 ms).  SE_AMD_FUSED_LN = 2 forces it.  Between its launches the residual stream travels as
   // bf16 + int8 (24 bits, gemm4.hip) instead of fp32 + bf16: 196 instead of 295 MB per K = 768 launch.
-  const bool fused = fuse_env && H == 768 && I % 32 == 0 && I >= 128 && (fuse_env == 2 || M >= (enc->cfg.fused_ln_min_rows > 0 ? enc->cfg.fused_ln_min_rows : 24576));
+  const bool fused = fuse_env && H == 768 && I % 32 == 0 && I >= 128 && (fuse_env == 2 || M >= (enc->cfg.fused_ln_min_rows > 0 ? enc->cfg.fused_ln_min_rows : 16000));
   if (fused) {      // gemm8's pair flags + error word start every pass at zero (each launch also leaves them zero)
     const size_t fo = se::gemm8_scratch_bytes() - (128 * 2 * 4 + 256);
     if ((rc = se::zero_async(w.g8 + fo, 128 * 2 * 4 + 256, st))) return rc;
@@ -681,7 +682,7 @@ extern "C" int se_spechead_fwd_bf16(const se_encoder* enc, const float* hidden, 
     const char* e = getenv("SE_AMD_FUSED_LN");
     fuse_env = e ? atoi(e) : 1;
   }
-  if (fuse_env && H == 768 && (fuse_env == 2 || M >= (enc->cfg.fused_ln_min_rows > 0 ? enc->cfg.fused_ln_min_rows : 24576))) {
+  if (fuse_env && H == 768 && (fuse_env == 2 || M >= (enc->cfg.fused_ln_min_rows > 0 ? enc->cfg.fused_ln_min_rows : 16000))) {
     if ((rc = se::launch_gemm_gelu_ln(w.x_bf, H, enc->sh_dense_w, H, enc->sh_dense_b, enc->sh_ln_w, enc->sh_ln_b, enc->cfg.ln_eps, M, H, H, nullptr,
                                       w.ctx, st))) return rc;
   } else {

@@ -77,7 +77,7 @@ def test_encoder_full_size_one_utterance(gpu):
 
 def test_row_complete_kernels_at_full_width(gpu):
     """The row-complete GEMM + LayerNorm kernel (encoder input stage with the positional table as residual, attention-output and
-    FFN-output projections, spec-head dense -> gelu -> LayerNorm) is only selected from ~24 k rows on; here it is forced at two
+    FFN-output projections, spec-head dense -> gelu -> LayerNorm) is only selected from 16 000 rows on; here it is forced at two
     ragged utterances (fused_ln_min_rows = 1) and must agree with the GEMM + LayerNorm pair and with the oracle."""
     from speech_enhancement_by_s3prl_amd import pipeline
     cfg = pipeline.make_config(layers=2)                    # hidden 768: the width the kernel is built for
