@@ -218,14 +218,16 @@ extern "C" int se_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, int l
     // serving-size batches (M = B*T <= 8 utterances of 10 s): a 1 001-row GEMM makes 4 row tiles of 256 -- 36 workgroups for the QKV
     // projection on 256 CUs.  128 x 128 tiles at two workgroups per CU fill the chip 4x better: 0.85 vs 1.85 ms per utterance pass
     // at B = 1, 1.81 vs 2.61 ms at B = 8 (tools/small_batch_sweep.sh); from B = 16 on the large tiles win again.
-    static int use5 = -1, use6 = 0, small_m = 8192;
+    // Round 2, with the 64-deep kernels: the crossover moved down to ~4 000 rows (ms per pass, small / large tiles: B = 4 1.14 / 1.14,
+    // B = 5 1.30 / 1.22, B = 6 1.51 / 1.37, B = 8 1.69 / 1.57), so the threshold is 4 096 rows (was 8 192).
+    static int use5 = -1, use6 = 0, small_m = 4096;
     if (use5 < 0) {
       const char* e5 = getenv("SE_AMD_GEMM5");       // developer switch: 1 = the one-wave-per-SIMD 256 x 256 kernel (gemm5.hip) for the bf16-output wide GEMMs
       use5 = e5 ? atoi(e5) : 0;
       const char* e6 = getenv("SE_AMD_GEMM6");       // 1 = the 64-deep eight-phase 256 x 256 kernel (gemm6.hip) for the wide GEMMs
       use6 = e6 ? atoi(e6) : 1;                      // default since round 2: +5-8 % over gemm3 on every wide shape (profiles/README.md)
       const char* sm = getenv("SE_AMD_GEMM_SMALL_M");   // row count up to which the 128 x 128 kernel is used (kernel benchmarks set 0)
-      small_m = sm ? atoi(sm) : 8192;
+      small_m = sm ? atoi(sm) : 4096;
     }
     if (M <= small_m) return se_gemm2_launch(A, lda, W, ldw, bias, residual_f32, M, N, K, act, out_bf16, out_f32, ldc, vec_ok, 4, stream);
     if (use6 && N >= 1536) {
