@@ -186,6 +186,7 @@ def main():
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-host-fed', action='store_true', help='skip the PCIe-inclusive side measurement')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend of the ranks ('nccl' = RCCL over xGMI)")
+    ap.add_argument('--one-device', action='store_true', help='rehearsal: every rank uses cuda:0 (several ranks on a one-GPU box, e.g. --gpus 2 --backend gloo)')
     ap.add_argument('--launch-check', action='store_true', help='rank plumbing only (no kernels): used by the CPU test of the launcher')
     args = ap.parse_args()
 
@@ -204,6 +205,8 @@ def main():
     if not torch.cuda.is_available():
         print('bench.py needs an MI355X: the hot path has no CPU fallback', file=sys.stderr)
         sys.exit(2)
+    if args.one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     # RCCL prints a version banner on stdout at communicator creation; the contract is ONE JSON line on stdout, so
@@ -312,7 +315,8 @@ def main():
                                      'forward (train mode, dropout 0.1), masked log-L1, backward, flat-buffer gradient all-reduce, clip 1.0, BertAdam')
         out['config']['parallelism'] = f'dp{world} (replicated parameters, one gradient all-reduce per step)'
 
-    if rank == 0 and not args.no_roofline:
+    collective_step = distributed and args.workload in ('finetune', 'lstm')      # the training steps all-reduce: every rank has to take part
+    if not args.no_roofline and (rank == 0 or collective_step):
         # roofline leg: the same K steps with HIP events recorded (in-library, on the launch stream) around every
         # kernel of the dominant families.  Dominant kernel = the bf16 MFMA GEMM (QKV / out-proj / FFN / head).
         lib.se_prof_reset()
@@ -321,6 +325,7 @@ def main():
             step(wavs, lengths, max_len)
         torch.cuda.synchronize()
         lib.se_prof_enable(0)
+    if rank == 0 and not args.no_roofline:
         fam = {}
         for kind, name in ((0, 'gemm_bf16'), (1, 'mhsa_fwd'), (2, 'stft'), (3, 'istft'), (6, 'mhsa_bwd')):
             ms, work, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_longlong()
