@@ -218,11 +218,18 @@ class _EncoderTrainFn(torch.autograd.Function):
         ws = torch.empty(nws, device=dev, dtype=torch.uint8)
         cb = None
         if sink is not None:
+            errors = []
+
             def _done(layer, _user):      # exactly the parameters whose gradients the launches enqueued so far have produced
-                sink.bucket_done([vs[layer] for vs in per.values()] if layer >= 0 else list(head.values()))
+                try:                      # (ctypes swallows exceptions raised inside a callback: keep the first one and re-raise after the C call)
+                    sink.bucket_done([vs[layer] for vs in per.values()] if layer >= 0 else list(head.values()))
+                except BaseException as e:    # noqa: BLE001
+                    errors.append(e)
             cb = _lib.LAYER_DONE_CB(_done)
         _lib.check(lib.se_encoder_bwd_cb_bf16(h, _lib.ptr(ctx.lengths), B, T, _lib.ptr(d_hidden), _lib.ptr(saved), saved.numel(), gs,
                                               _lib.ptr(ws), nws, ctx.dropout[0], ctx.dropout[1], cb, None, _lib.stream()), 'se_encoder_bwd_bf16')
+        if sink is not None and errors:
+            raise errors[0]
         ctx.buf = None
         grads = [ghead[k] for k in ('in_w', 'in_b', 'in_ln_w', 'in_ln_b')]
         for k in _TRUNK_FIELDS:
