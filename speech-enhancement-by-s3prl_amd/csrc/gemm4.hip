@@ -41,11 +41,15 @@ __device__ __forceinline__ int swz4(int row, int chunk) { return row * 64 + ((ch
 //      reads anyway, round-to-nearest) + int8 lo = round((y - hi) * 2^(15 - E)), E = exponent of hi: 16 mantissa bits (2^-17 relative; the
 //      encoder's error against fp32 is unchanged: 3.177e-3 vs 3.172e-3 relative L2) for 3 B per element instead of 4 + 2.  lo lives in the
 //      accumulator's own layout (one contiguous 256-B block per wave, row tile and column tile): written and read by the same lane.
-// Both directions are written on the bit patterns (this codec runs on all 192 accumulators of a wave at both ends of every row-complete
-// launch: the first, float-select form cost ~24 vector instructions per element pair of directions, ~10 % of a K = 768 launch):
-//   2^(E - 15) = bits(hi) & 0x7f800000 - (15 << 23), clamped at 0 (|hi| < 2^-112: lo is ignored);  2^(15 - E) = (269 << 23) - the same field
-//   round-to-nearest-even + two's-complement byte = low 8 bits of (q + 1.5 * 2^23) after clamping q to [-128, 127]
-#ifdef SE_AMD_OLD_CODEC      // A/B build switch (SE_AMD_EXTRA_DEFINES=-DSE_AMD_OLD_CODEC python build.py --force): the first, float-select form
+// Round 2 (end): the low byte is defined ON THE BIT PATTERN -- lo = round((bits(y) - bits(hi) << 16) / 256), i.e. bits 15..8 of the fp32 pattern
+// as a signed correction to the round-to-nearest bf16 -- instead of through a float scale 2^(15 - E).  Same resolution (1/256 of hi's bf16
+// ulp = 2^8 fp32 ulps; numpy emulation on 2 M values: mean 5.5e-6, max 3.0e-5 relative, the maximum when the byte saturates at +127 for a y
+// exactly half way that rounded down -- as in the first format), but decoding is ONE integer add per element and encoding three:
+//   dec:  bits = (hi << 16) + (lo << 8)                      enc:  lo = min(((bits(y) - (hi << 16)) + 128) >> 8, 127)
+// (sign-magnitude patterns: y and hi always share the sign, so the integer difference is the signed difference of the magnitudes and the add
+// moves the magnitude the same way).  This codec runs on all 192 accumulators of a wave at both ends of every row-complete launch: the
+// float-select form cost ~24 vector instructions per element over both directions, the bit-field float form ~16, this one ~9.
+#ifdef SE_AMD_OLD_CODEC      // A/B build switch (SE_AMD_EXTRA_DEFINES=-DSE_AMD_OLD_CODEC python build.py --force): the first, float-scale format
 __device__ __forceinline__ float dec24(uint32_t hi16, int lo8) {
   const uint32_t eb = (hi16 >> 7) & 0xffu;
   const float sc = __uint_as_float(eb > 15u ? (eb - 15u) << 23 : 0u);
@@ -57,25 +61,16 @@ __device__ __forceinline__ uint32_t enc24_lo(float y, uint32_t hi16) {
   const float q = rintf((y - __uint_as_float(hi16 << 16)) * sc);
   return (uint32_t)(int)fminf(fmaxf(q, -128.f), 127.f) & 0xffu;
 }
-#else
+__device__ __forceinline__ uint32_t enc24_lo4(float y0, float y1, float y2, float y3, uint2 pk) {
+  return enc24_lo(y0, pk.x & 0xffffu) | (enc24_lo(y1, pk.x >> 16) << 8) | (enc24_lo(y2, pk.y & 0xffffu) << 16) | (enc24_lo(y3, pk.y >> 16) << 24);
+}
+#elif defined(SE_AMD_FLOAT_CODEC)      // A/B: the float-scale format computed on the exponent field (the intermediate version of round 2)
 __device__ __forceinline__ float dec24(uint32_t hi16, int lo8) {
   const uint32_t hb = hi16 << 16;
   const uint32_t ef = max(hb & 0x7f800000u, 15u << 23);
   return fmaf((float)lo8, __uint_as_float(ef - (15u << 23)), __uint_as_float(hb));
 }
-__device__ __forceinline__ uint32_t enc24_lo(float y, uint32_t hi16) {
-  const uint32_t hb = hi16 << 16;
-  const uint32_t ef = max(hb & 0x7f800000u, 15u << 23);
-  const float q = (y - __uint_as_float(hb)) * __uint_as_float(0x86800000u - ef);       // (269 << 23) - E field = 2^(15 - E)
-  return __float_as_uint(__builtin_amdgcn_fmed3f(q, -128.f, 127.f) + 12582912.0f) & 0xffu;
-}
-#endif
-// the four lo bytes of (y0..y3) given their packed bf16 pairs (pk.x = hi(y0) | hi(y1) << 16, pk.y = hi(y2) | hi(y3) << 16), as one dword.
-// Fast form: the byte is the low byte of the magic-add result, so no masks; three v_perm_b32 gather the four low bytes.
 __device__ __forceinline__ uint32_t enc24_lo4(float y0, float y1, float y2, float y3, uint2 pk) {
-#ifdef SE_AMD_OLD_CODEC
-  return enc24_lo(y0, pk.x & 0xffffu) | (enc24_lo(y1, pk.x >> 16) << 8) | (enc24_lo(y2, pk.y & 0xffffu) << 16) | (enc24_lo(y3, pk.y >> 16) << 24);
-#else
   const uint32_t hb[4] = {pk.x << 16, pk.x & 0xffff0000u, pk.y << 16, pk.y & 0xffff0000u};
   const float y[4] = {y0, y1, y2, y3};
   uint32_t m[4];
@@ -87,8 +82,20 @@ __device__ __forceinline__ uint32_t enc24_lo4(float y0, float y1, float y2, floa
   }
   const uint32_t t01 = __builtin_amdgcn_perm(m[1], m[0], 0x0c0c0400u), t23 = __builtin_amdgcn_perm(m[3], m[2], 0x0c0c0400u);
   return __builtin_amdgcn_perm(t23, t01, 0x05040100u);
-#endif
 }
+#else
+__device__ __forceinline__ float dec24(uint32_t hi16, int lo8) { return __uint_as_float((hi16 << 16) + (uint32_t)(lo8 << 8)); }
+// the four lo bytes of (y0..y3) given their packed bf16 pairs (pk.x = hi(y0) | hi(y1) << 16, pk.y = hi(y2) | hi(y3) << 16), as one dword
+__device__ __forceinline__ uint32_t enc24_lo4(float y0, float y1, float y2, float y3, uint2 pk) {
+  const uint32_t hb[4] = {pk.x << 16, pk.x & 0xffff0000u, pk.y << 16, pk.y & 0xffff0000u};
+  const float y[4] = {y0, y1, y2, y3};
+  uint32_t m[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) m[r] = (uint32_t)min(((int)(__float_as_uint(y[r]) - hb[r]) + 128) >> 8, 127);
+  const uint32_t t01 = __builtin_amdgcn_perm(m[1], m[0], 0x0c0c0400u), t23 = __builtin_amdgcn_perm(m[3], m[2], 0x0c0c0400u);
+  return __builtin_amdgcn_perm(t23, t01, 0x05040100u);
+}
+#endif
 
 // acc[i][t] <- bias (+ residual): fp32 rows, or the 24-bit (bf16 hi row-major + int8 lo tile-major) stream, or a (T, 768) table indexed row % res_mod
 template <int GELU, int RIN>
@@ -483,6 +490,13 @@ __global__ __launch_bounds__(k4Threads) __attribute__((amdgpu_waves_per_eu(2, 2)
   const int col0 = wc * 192 + 4 * cq;
   f32x4 acc[4][12];
   acc_init4<GELU, RIN>(acc, bias, residual, res_lo, M, m0, id, wave, wr, lane, col0, res_mod);
+  // every accumulator is COMPLETE here (opaque uses): with the integer codec the compiler otherwise left residual loads pending into the K loop
+  // and protected the hand-issued LDS-DMA operands with s_waitcnt vmcnt(1) / vmcnt(0) INSIDE it -- which drains the DMA ring every K-tile
+  // (K = 3072: 214 instead of 170 us per launch)
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int t = 0; t < 12; ++t) asm volatile("" : "+v"(acc[i][t]));
 
   // fragment addresses: lane -> row (lane & 15) of a 16-row tile, logical chunk 4 s + (lane >> 4); tiles 16 rows apart share the swizzle term
   const int frow = lane & 15, fch = lane >> 4;

@@ -40,16 +40,10 @@ constexpr int k8SpinLimit = 1 << 22;
 
 typedef __attribute__((address_space(3))) void* lds8_ptr_t;
 
-__device__ __forceinline__ float dec24_8(uint32_t hi16, int lo8) {          // gemm4.hip: dec24
-  const uint32_t eb = (hi16 >> 7) & 0xffu;
-  const float sc = __uint_as_float(eb > 15u ? (eb - 15u) << 23 : 0u);
-  return fmaf((float)lo8, sc, __uint_as_float(hi16 << 16));
-}
-__device__ __forceinline__ uint32_t enc24_lo8(float y, uint32_t hi16) {      // gemm4.hip: enc24_lo
-  const uint32_t eb = (hi16 >> 7) & 0xffu;
-  const float sc = __uint_as_float((eb >= 15u && eb <= 254u) ? (269u - eb) << 23 : 0u);
-  const float q = rintf((y - __uint_as_float(hi16 << 16)) * sc);
-  return (uint32_t)(int)fminf(fmaxf(q, -128.f), 127.f) & 0xffu;
+// the 24-bit codec of gemm4.hip (dec24 / enc24_lo4: low byte = bits 15..8 of the fp32 pattern as a signed correction to the RNE bf16)
+__device__ __forceinline__ float dec24_8(uint32_t hi16, int lo8) { return __uint_as_float((hi16 << 16) + (uint32_t)(lo8 << 8)); }
+__device__ __forceinline__ uint32_t enc24_lo8(float y, uint32_t hi16) {
+  return (uint32_t)min(((int)(__float_as_uint(y) - (hi16 << 16)) + 128) >> 8, 127) & 0xffu;
 }
 // byte offset of the 4 low bytes of (row, 4 columns starting at col4, col4 % 4 == 0) in gemm4's tile-major layout:
 // [128-row block][wave = 2 (64-row half) x 4 (192-column group)][16-row tile][16-column tile][lane = 16 (col quad) + row][4 B]
