@@ -169,89 +169,208 @@ def launch_check(args):
         print(json.dumps({'metric': 'launch-check', 'n_gpus': world, 'world_observed': world, 'backend': args.backend}), flush=True)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=32, help='utterances per GPU per step (configs[1]: 32)')
-    ap.add_argument('--layers', type=int, default=6, help='encoder depth (6 = config/pretrain_sample.yaml; 3 = "base")')
-    ap.add_argument('--workload', choices=('enhance', 'finetune', 'lstm'), default='enhance',
-                    help="enhance = configs[1] (the headline metric); finetune = configs[3]'s Mockingjay training step "
-                         '(fwd + L1 + bwd + gradient all-reduce + clip + BertAdam); lstm = the same step for the 3 x BiLSTM-256 head of '
-                         'pseudo_noise.yaml:50-53 on raw features (run_active.sh); both reported as side measurements')
-    ap.add_argument('--streams', type=int, default=1, help='process the batch as this many sub-batches on separate HIP streams (enhance workload)')
-    ap.add_argument('--graph', action='store_true', help='replay the enhance pass as one hipGraph launch (serving-size batches are launch-bound)')
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-roofline', action='store_true')
-    ap.add_argument('--no-host-fed', action='store_true', help='skip the PCIe-inclusive side measurement')
-    ap.add_argument('--backend', default='nccl', help="torch.distributed backend of the ranks ('nccl' = RCCL over xGMI)")
-    ap.add_argument('--one-device', action='store_true', help='rehearsal: every rank uses cuda:0 (several ranks on a one-GPU box, e.g. --gpus 2 --backend gloo)')
-    ap.add_argument('--launch-check', action='store_true', help='rank plumbing only (no kernels): used by the CPU test of the launcher')
-    args = ap.parse_args()
+def cpu_baseline_head(batch, head_feat, seconds_budget=20.0):
+    """The oracle's restatement of the head pass (configs[3] / configs[0]) timed on this box's host cores, bounded sample."""
+    from oracle import decode as odec, heads as oheads, objective as oobj, preprocessor as opre
+    from speech_enhancement_by_s3prl_amd import synth
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))
+    torch.set_num_threads(cores)
+    geom = opre.Geometry()
+    feat = HEAD_FEATS[head_feat]
+    feat_list = [dict(feat, channel=0), dict(feat, channel=0), opre.get_feat_config('linear', 0), opre.get_feat_config('phase', 0),
+                 opre.get_feat_config('linear', 1), opre.get_feat_config('phase', 1)]
+    lengths, wavs = synth.fast_batch(batch, 160000, seed=1)
+    wavs = wavs[:, :2].contiguous()
+    D = 120 if head_feat == 'mel120' else 201
+    g = torch.Generator().manual_seed(0)
+    W, b = torch.randn(201, D, generator=g) * 0.05, torch.randn(201, generator=g) * 0.05
 
-    if args.gpus > 1 and 'RANK' not in os.environ:
-        launch_ranks(args.gpus, sys.argv[1:])            # never returns; nothing above touched the GPU
-    if args.launch_check:
-        return launch_check(args)
+    def one():
+        with torch.no_grad():
+            f = opre.forward(wavs, feat_list, geom)
+            pred, _ = oheads.linear_residual(f[1], f[2], W, b)
+            wav = odec.decode_wav(pred, f[3], lengths, geom, wavs[:, 1])
+            loss = oobj.sisdr_objective(pred, f[4], odec.get_length_masks(lengths // 160 + 1))
+        return wav, loss
 
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    distributed = world > 1 or 'RANK' in os.environ      # under torchrun always go through RCCL (also at N = 1)
-    if world != args.gpus:
-        print(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}', file=sys.stderr)
-        sys.exit(2)
-    if not torch.cuda.is_available():
-        print('bench.py needs an MI355X: the hot path has no CPU fallback', file=sys.stderr)
-        sys.exit(2)
-    if args.one_device:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
-    # RCCL prints a version banner on stdout at communicator creation; the contract is ONE JSON line on stdout, so
-    # everything before the final print goes to stderr at the file-descriptor level.
-    sys.stdout.flush()
-    saved_stdout_fd = os.dup(1)
-    os.dup2(2, 1)
-    if distributed:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', '29500')
-        dist.init_process_group(args.backend, device_id=dev)
-        dist.barrier()                      # creates the communicator now (not inside the timed region)
-        ones = torch.ones(1, device=dev, dtype=torch.float64)
-        dist.all_reduce(ones)               # the world size the collective itself sees
-        world_observed = int(ones.item())
-        if world_observed != args.gpus:
-            print(f'bench.py: --gpus {args.gpus} but the all-reduce counted {world_observed} ranks', file=sys.stderr)
+    t0 = time.perf_counter()
+    one()
+    warm = time.perf_counter() - t0
+    for _ in range(2):
+        one()
+    iters = max(3, min(10, int(seconds_budget / max(warm, 1e-3)) - 3))
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        one()
+    dt = (time.perf_counter() - t0) / iters
+    return {'value': batch / dt, 'unit': 'utt/s', 'cores': cores, 'kind': 'port',
+            'sample': f'3 warm-ups + {iters} timed x batch of {batch} synthetic 10 s two-channel utterances, same pass (fp32 torch CPU oracle: torch.stft, '
+                      f'features, LinearResidual, torch.istft, dB-norm, SISDR), {dt:.2f} s per batch'}
+
+
+def extras_leg(args, w, dev, out):
+    """extra keys of the line, never `value` (rank 0, after the process group is gone)"""
+    from speech_enhancement_by_s3prl_amd import synth
+
+    def rate(step, batch, steps, warm=2):
+        lengths, wavs = synth.fast_batch(batch, 160000, seed=2000, device=dev)
+        if args.workload == 'head':
+            wavs = wavs[:, :2].contiguous()
+        for _ in range(warm):
+            step(wavs, lengths, w['max_len'])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(wavs, lengths, w['max_len'])
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        return {'value': batch / dt, 'unit': 'utt/s', 'ms_per_step': 1000.0 * dt, 'batch': batch}
+
+    if args.workload == 'enhance' and args.streams == 1 and not args.graph:
+        # the mode that meets north_star's 1e-4 on enhanced magnitudes (tests/test_gpu_encoder_fp32.py): exact-fp32 encoder + spec head
+        up = w['upstream']
+        up.set_precision('fp32')
+        try:
+            r = rate(w['step'], 8, 3, warm=1)
+        finally:
+            up.set_precision('bf16')
+        r['note'] = ("TRANSFORMER.set_precision('fp32'): fp32 operands / products / sums on v_mfma_f32_32x32x2_f32 (1/16 of the bf16 matrix rate), the rate at "
+                     'which the stated 1e-4 tolerance holds; not the headline value')
+        out['fp32_parity_mode'] = r
+    if args.workload == 'head' and not args.graph:
+        r = rate(w['step'], 12, 50, warm=5)
+        r['note'] = 'vcb.yaml:3 eval_batch_size = 12: launch-latency regime (one pass is ~10 launches of a few microseconds of work each)'
+        out['batch_12'] = r
+
+
+class Ranks:
+    """The process group's lifetime.  Everything that may run a collective happens between __init__ and teardown(), in the SAME
+    order on every rank (no `if rank == 0` around a step); the rank-0-only side legs (host-fed rate, CPU baseline, printing) run
+    after teardown(), when no process group exists any more -- a rank cannot wait in a collective for a peer that is busy elsewhere."""
+
+    def __init__(self, args):
+        self.rank = int(os.environ.get('RANK', '0'))
+        self.local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+        self.world = int(os.environ.get('WORLD_SIZE', '1'))
+        self.distributed = self.world > 1 or 'RANK' in os.environ      # under torchrun always go through RCCL (also at N = 1)
+        self.backend = args.backend
+        if self.world != args.gpus:
+            print(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={self.world}', file=sys.stderr)
             sys.exit(2)
-    else:
-        world_observed = 1
+        self.stub = args.stub_step
+        if self.stub:
+            self.dev = torch.device('cpu')
+        else:
+            if not torch.cuda.is_available():
+                print('bench.py needs an MI355X: the hot path has no CPU fallback', file=sys.stderr)
+                sys.exit(2)
+            if args.one_device:
+                self.local_rank = 0
+            torch.cuda.set_device(self.local_rank)
+            self.dev = torch.device('cuda', self.local_rank)
+        self.world_observed = 1
+        if self.distributed:
+            import torch.distributed as dist
+            self.dist = dist
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('MASTER_PORT', '29500')
+            if self.stub:
+                dist.init_process_group(args.backend)
+            else:
+                dist.init_process_group(args.backend, device_id=self.dev)
+            dist.barrier()                      # creates the communicator now (not inside the timed region)
+            ones = torch.ones(1, device=self.dev, dtype=torch.float64)
+            dist.all_reduce(ones)               # the world size the collective itself sees
+            self.world_observed = int(ones.item())
+            if self.world_observed != args.gpus:
+                print(f'bench.py: --gpus {args.gpus} but the all-reduce counted {self.world_observed} ranks', file=sys.stderr)
+                sys.exit(2)
 
+    def sync(self):
+        if self.dev.type == 'cuda':
+            torch.cuda.synchronize()
+        if self.distributed:
+            self.dist.barrier()
+            if self.dev.type == 'cuda':
+                torch.cuda.synchronize()
+
+    def local_sync(self):
+        if self.dev.type == 'cuda':
+            torch.cuda.synchronize()
+
+    def max_over_ranks(self, x):
+        if not self.distributed:
+            return x
+        t = torch.tensor([x], device=self.dev, dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return t.item()
+
+    def teardown(self):
+        """The LAST collective of the job, reached by every rank after the same sequence of collectives."""
+        if self.distributed:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+            self.distributed = False
+
+
+HEAD_FEATS = {
+    # SURVEY 8d's restatement of configs[3] ("same as config 1 but on GPU"): pseudo_noise.yaml's baseline features, 120 dims
+    'mel120': {'feat_type': 'mel', 'log': True, 'delta': 2, 'cmvn': False},
+    # vcb.yaml:10-14 literally: the linear power spectrogram itself is the head's input, 201 dims
+    'linear201': {'feat_type': 'linear', 'log': False, 'delta': 0, 'cmvn': False},
+}
+
+
+def build_workload(args, ranks):
+    """-> dict(step=callable(wavs, lengths, max_len) -> (wav_pred, loss, aux), wavs, lengths, max_len, collective, lib, describe)"""
     from speech_enhancement_by_s3prl_amd import _lib, pipeline, synth
+    dev, rank = ranks.dev, ranks.rank
     lib = _lib.load()
     cfg = pipeline.make_config(layers=args.layers)
-    ckpt = pipeline.synthetic_checkpoint(cfg, seed=0)
-    upstream = pipeline.build_upstream(ckpt, dev)
-    pre = pipeline.build_preprocessor(cfg, dev)
-    step = pipeline.UpstreamEnhanceStep(pre, upstream, streams=args.streams)
-    if args.workload == 'finetune':
+    w = {'lib': lib, 'collective': False, 'max_len': 160000, 'dtype': 'bf16'}
+    lengths, wavs = synth.fast_batch(args.batch, 160000, seed=1000 + rank, device=dev)   # resident in HBM before timing
+    if args.workload == 'head':
+        from speech_enhancement_by_s3prl_amd.heads import LinearResidual
+        from speech_enhancement_by_s3prl_amd.objective import SISDR
+        feat = HEAD_FEATS[args.head_feat]
+        pre = pipeline.build_preprocessor(cfg, dev, channel_inp=0, channel_tar=1, downstream_feat=feat)
+        torch.manual_seed(0)
+        D = 120 if args.head_feat == 'mel120' else 201
+        head = LinearResidual(input_size=D, output_size=201, cmvn=True).to(dev)
+        hs = pipeline.HeadEnhanceStep(pre, head, criterion=SISDR())
+        wavs = wavs[:, :2].contiguous()          # NoisyCleanDataset batches are (B, 2, T) = (noisy, clean): dataset.py:245, vcb.yaml:5-7
+
+        def step(wavs, lengths, max_len):
+            wav_pred, predicted, lin_tar, loss = hs(wavs, lengths, max_len=max_len)
+            return wav_pred, loss, predicted
+        w.update(step=step, pre=pre, dtype='f32')
+    elif args.workload == 'enhance':
+        ckpt = pipeline.synthetic_checkpoint(cfg, seed=0)
+        upstream = pipeline.build_upstream(ckpt, dev)
+        pre = pipeline.build_preprocessor(cfg, dev)
+        w.update(step=pipeline.UpstreamEnhanceStep(pre, upstream, streams=args.streams), pre=pre, upstream=upstream)
+    elif args.workload == 'finetune':
         import warnings
         warnings.simplefilter('ignore')
         from speech_enhancement_by_s3prl_amd.solver import get_optimizer
-        del upstream
+        ckpt = pipeline.synthetic_checkpoint(cfg, seed=0)
+        pre = pipeline.build_preprocessor(cfg, dev)
         model = pipeline.build_mockingjay(ckpt, dev)
         opt = get_optimizer(list(model.named_parameters()), lr=4e-5, warmup_proportion=0.07, training_steps=100000)
-        ft = pipeline.MockingjayFinetuneStep(pre, model, opt)
+        ft = pipeline.MockingjayFinetuneStep(pre, model, opt)        # broadcasts the parameters: a collective, on every rank
 
         def step(wavs, lengths, max_len):          # same call shape as the enhance step
             loss, gn, skipped = ft(wavs, lengths)
             return loss.reshape(1), loss, None
-    if args.workload == 'lstm':
+        w.update(step=step, pre=pre, collective=True)
+    elif args.workload == 'lstm':
         from speech_enhancement_by_s3prl_amd.lstm import LSTM
         from speech_enhancement_by_s3prl_amd.solver import get_optimizer
-        del upstream
+        pre = pipeline.build_preprocessor(cfg, dev)
         head = LSTM(input_size=120, output_size=201, hidden_size=256, num_layers=3, bidirectional=True).to(dev)
         opt = get_optimizer(list(head.named_parameters()), lr=4e-5, warmup_proportion=0.07, training_steps=100000)
         ht = pipeline.HeadFinetuneStep(pre, head, opt)
@@ -259,114 +378,136 @@ def main():
         def step(wavs, lengths, max_len):
             loss, gn, skipped = ht(wavs, lengths)
             return loss.reshape(1), loss, None
-    lengths, wavs = synth.fast_batch(args.batch, 160000, seed=1000 + rank, device=dev)   # resident in HBM before timing
-    max_len = 160000
-    if args.graph and args.workload == 'enhance':
-        eager = step
-        graphed = pipeline.GraphedStep(eager, wavs, lengths, max_len)
+        w.update(step=step, pre=pre, collective=True)
+    w.update(wavs=wavs, lengths=lengths)
+    if args.graph and args.workload in ('enhance', 'head'):
+        graphed = pipeline.GraphedStep(w['step'], wavs, lengths, w['max_len'])
+        w['step'] = lambda wavs, lengths, max_len: graphed(wavs, lengths)
+    return w
 
-        def step(wavs, lengths, max_len):
-            return graphed(wavs, lengths)
 
-    def sync_all():
-        torch.cuda.synchronize()
-        if distributed:
-            dist.barrier()
-            torch.cuda.synchronize()
+def build_stub_workload(args, ranks):
+    """--stub-step: the SAME control flow and the SAME collective sequence per step as the real workloads, on CPU tensors over gloo, with
+    the HIP kernels replaced by a few torch lines: what tests/test_dist_gloo.py runs so that the driver's 8-GPU job is never the first
+    execution of this file's N > 1 path.  The training stubs go through the product's own dist.py classes (global-mean criterion sums,
+    BucketedGradSink's async per-layer all-reduces, FlatGradAllReducer's tail reduce + wait, clip, step)."""
+    from speech_enhancement_by_s3prl_amd import dist as sdist
+    g = torch.Generator().manual_seed(7 + ranks.rank)
+    B, F, D, N = args.batch, 16, 12, 9
+    feats = torch.randn(B, F, D, generator=g)
+    tar = torch.rand(B, F, N, generator=g) + 0.1
+    lens = torch.randint(1, F + 1, (B,), generator=g)
+    w = {'lib': None, 'collective': args.workload in ('finetune', 'lstm'), 'max_len': F, 'wavs': feats, 'lengths': lens, 'dtype': 'f32'}
+    if not w['collective']:
+        lin = torch.nn.Linear(D, N)
 
-    for _ in range(args.warmup):
-        step(wavs, lengths, max_len)
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        wav_pred, loss, _ = step(wavs, lengths, max_len)
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if distributed:
-        dist.barrier()
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
-    assert torch.isfinite(wav_pred).all() and torch.isfinite(loss)
+        def step(feats, lens, max_len):
+            with torch.no_grad():
+                out = lin(feats)
+            return out, out.abs().mean(), None
+        w['step'] = step
+        return w
+    torch.manual_seed(0)
+    layers = torch.nn.ModuleList([torch.nn.Linear(D, D) for _ in range(3)] + [torch.nn.Linear(D, N)])
+    sdist.broadcast_parameters(layers)
+    params = list(layers.parameters())
+    red = sdist.FlatGradAllReducer(params)
+    sink = sdist.BucketedGradSink(red)
+    opt = torch.optim.SGD(params, lr=1e-3)
 
-    total_utts = args.batch * world * args.steps
-    out = {
-        'metric': {'enhance': 'enhanced 10s utts/sec', 'finetune': 'fine-tuned 10s utts/sec (Mockingjay training step)',
-                   'lstm': 'trained 10s utts/sec (LSTM head training step)'}[args.workload], 'value': total_utts / elapsed, 'unit': 'utt/s', 'n_gpus': world_observed,
-        'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1000.0 * elapsed / args.steps,
-        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
-        'config': {'workload': 'configs[1]: TERA/Mockingjay upstream (6x768x12x3072, pretrain_sample.yaml) + '
-                               'TransformerSpecPredictionHead, evaluate()-style pass, 10 s @ 16 kHz',
-                   'batch_per_gpu': args.batch, 'global_batch': args.batch * world, 'layers': args.layers,
-                   'frames': 1001, 'parallelism': f'dp{world} (utterance-sharded inference, no data-path collective)',
-                   'weights': 'seeded random, real sizes',
-                   'ranks': f'{world_observed} ranks counted by all-reduce over {args.backend}' if distributed else 'single process, no process group'},
-    }
-    if args.graph and args.workload == 'enhance':
-        out['config']['launch'] = 'one hipGraph replay per step'
-    if args.streams > 1 and args.workload == 'enhance':
-        out['config']['streams'] = f'{args.streams} sub-batches of the batch in flight on separate HIP streams'
-    if args.workload == 'lstm':
-        out['config']['workload'] = ('config 5 style: 3 x BiLSTM-256 + Linear(512->201) head (pseudo_noise.yaml:50-53, 4.0 M params) on mel/log/delta-2 '
-                                     'features: STFT/features, forward, masked log-L1, backward (BPTT), gradient all-reduce, clip 1.0, BertAdam')
-        out['config']['parallelism'] = f'dp{world} (replicated parameters, one gradient all-reduce per step)'
-    if args.workload == 'finetune':
-        out['config']['workload'] = ('configs[3]: Mockingjay fine-tune step (6x768x12x3072 encoder + spec head, 43 M params): STFT/features, '
-                                     'forward (train mode, dropout 0.1), masked log-L1, backward, flat-buffer gradient all-reduce, clip 1.0, BertAdam')
-        out['config']['parallelism'] = f'dp{world} (replicated parameters, one gradient all-reduce per step)'
+    def step(feats, lens, max_len):
+        x = feats
+        for l in layers[:-1]:
+            x = torch.tanh(l(x))
+        logp = layers[-1](x)
+        mask = (torch.arange(F)[None] < lens[:, None]).float()[..., None]
+        s = ((logp - tar.log()).abs() * mask).sum()
+        sums = sdist.all_reduce_sums(torch.stack([s.detach().double(), (mask.sum() * N).double()]))      # (sum, count) BEFORE dividing
+        loss = s / sums[1].float()
+        opt.zero_grad()
+        loss.backward()
+        sink.begin()
+        for l in reversed(layers[:-1]):          # the encoder backward's per-layer callback, last layer first
+            for p in l.parameters():
+                sink.view(p).copy_(p.grad)
+            sink.bucket_done(list(l.parameters()))
+        flat = red.reduce(copy_back=True, sink=sink)     # the rest (the head) + wait for the bucket handles
+        gn = float(torch.nn.utils.clip_grad_norm_(params, 1.0))
+        if not (gn != gn or gn == float('inf')):
+            opt.step()
+        return flat[:1], (sums[0] / sums[1]).float(), None
+    w['step'] = step
+    return w
 
-    collective_step = distributed and args.workload in ('finetune', 'lstm')      # the training steps all-reduce: every rank has to take part
-    if not args.no_roofline and (rank == 0 or collective_step):
-        # roofline leg: the same K steps with HIP events recorded (in-library, on the launch stream) around every
-        # kernel of the dominant families.  Dominant kernel = the bf16 MFMA GEMM (QKV / out-proj / FFN / head).
-        lib.se_prof_reset()
-        lib.se_prof_enable(1)
-        for _ in range(args.steps):
-            step(wavs, lengths, max_len)
-        torch.cuda.synchronize()
-        lib.se_prof_enable(0)
-    if rank == 0 and not args.no_roofline:
-        fam = {}
-        for kind, name in ((0, 'gemm_bf16'), (1, 'mhsa_fwd'), (2, 'stft'), (3, 'istft'), (6, 'mhsa_bwd')):
-            ms, work, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_longlong()
-            lib.se_prof_read(kind, ctypes.byref(ms), ctypes.byref(work), ctypes.byref(n))
-            fam[name] = (ms.value, work.value, n.value)
-        g_ms, g_flop, g_n = fam['gemm_bf16']
-        achieved = g_flop / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
-        # the committed PMC passes are of the default command: report them only when this run is that command
-        pmc_matches = (args.workload == 'enhance' and args.batch == 32 and args.layers == 6 and args.streams == 1 and not args.graph)
-        traffic = pmc_traffic(GEMM_KERNELS) if pmc_matches else None
-        out['roofline'] = {'bound': 'mfma', 'kernel': 'gemm_bf16_kernel', 'achieved': achieved, 'peak': MFMA_BF16_PEAK_TFLOPS,
-                           'unit': 'TFLOP/s', 'frac': achieved / MFMA_BF16_PEAK_TFLOPS, 'traffic': traffic,
-                           'traffic_unit': 'HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, committed PMC passes: profiles/' + os.path.basename(PMC_FILE) + ')',
-                           'launches': g_n, 'avg_launch_ms': g_ms / max(g_n, 1),
-                           'algorithmic_flop_per_launch': g_flop / max(g_n, 1)}
-        others = {}
-        m_ms, m_flop, m_n = fam['mhsa_fwd']
-        if m_ms > 0:
-            a = m_flop / (m_ms * 1e-3) / 1e12
-            others['mhsa_fwd_kernel'] = {'bound': 'mfma', 'achieved': a, 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                                         'frac': a / MFMA_BF16_PEAK_TFLOPS, 'avg_launch_ms': m_ms / m_n, 'share_of_step_ms': m_ms / args.steps}
-        b_ms, b_flop, b_n = fam['mhsa_bwd']
-        if b_ms > 0:
-            a = b_flop / (b_ms * 1e-3) / 1e12
-            others['mhsa_bwd_kernels'] = {'bound': 'mfma', 'achieved': a, 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                                          'frac': a / MFMA_BF16_PEAK_TFLOPS, 'avg_launch_ms': b_ms / b_n, 'share_of_step_ms': b_ms / args.steps}
-        for name in ('stft', 'istft'):
-            ms, byts, n = fam[name]
-            if ms > 0:
-                a = byts / (ms * 1e-3) / 1e9
-                others[name + '_kernel'] = {'bound': 'hbm', 'achieved': a, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': a / HBM_PEAK_GBS,
-                                            'avg_launch_ms': ms / n, 'share_of_step_ms': ms / args.steps}
-        others['gemm_share_of_step_ms'] = g_ms / args.steps
+
+def roofline_report(args, lib, out):
+    """reads the in-library HIP-event timings of the roofline leg (recorded on the launch stream around every kernel of the dominant families)"""
+    fam = {}
+    for kind, name in ((0, 'gemm_bf16'), (1, 'mhsa_fwd'), (2, 'stft'), (3, 'istft'), (5, 'head'), (6, 'mhsa_bwd')):
+        ms, work, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_longlong()
+        lib.se_prof_read(kind, ctypes.byref(ms), ctypes.byref(work), ctypes.byref(n))
+        fam[name] = (ms.value, work.value, n.value)
+    others = {}
+
+    def hbm_entry(name):
+        ms, byts, n = fam[name]
+        if ms <= 0:
+            return None
+        a = byts / (ms * 1e-3) / 1e9
+        return {'bound': 'hbm', 'achieved': a, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': a / HBM_PEAK_GBS, 'avg_launch_ms': ms / n,
+                'launches': n, 'algorithmic_bytes_per_launch': byts / n, 'share_of_step_ms': ms / args.steps}
+
+    def mfma_entry(name):
+        ms, flop, n = fam[name]
+        if ms <= 0:
+            return None
+        a = flop / (ms * 1e-3) / 1e12
+        return {'bound': 'mfma', 'achieved': a, 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': a / MFMA_BF16_PEAK_TFLOPS,
+                'avg_launch_ms': ms / n, 'share_of_step_ms': ms / args.steps}
+
+    if args.workload == 'head':
+        # HBM-bound pass: the dominant kernel is the two-channel STFT launch
+        e = hbm_entry('stft') or {}
+        out['roofline'] = dict(e, kernel='stft_kernel', traffic=None,
+                               traffic_unit='HBM bytes per launch from PMC passes (none committed for this workload yet)')
+        for name in ('istft', 'head'):
+            e = hbm_entry(name)
+            if e:
+                others[name + '_kernel'] = e
         out['roofline_other_kernels'] = others
+        return
+    g_ms, g_flop, g_n = fam['gemm_bf16']
+    achieved = g_flop / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
+    # the committed PMC passes are of the default command: report them only when this run is that command
+    pmc_matches = (args.workload == 'enhance' and args.batch == 32 and args.layers == 6 and args.streams == 1 and not args.graph)
+    traffic = pmc_traffic(GEMM_KERNELS) if pmc_matches else None
+    out['roofline'] = {'bound': 'mfma', 'kernel': 'gemm_bf16_kernel', 'achieved': achieved, 'peak': MFMA_BF16_PEAK_TFLOPS,
+                       'unit': 'TFLOP/s', 'frac': achieved / MFMA_BF16_PEAK_TFLOPS, 'traffic': traffic,
+                       'traffic_unit': 'HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, committed PMC passes: profiles/' + os.path.basename(PMC_FILE) +
+                                       '); counts L2 misses incl. Infinity-Cache hits: ~1.45x the algorithmic bytes of these launches',
+                       'launches': g_n, 'avg_launch_ms': g_ms / max(g_n, 1),
+                       'algorithmic_flop_per_launch': g_flop / max(g_n, 1)}
+    for name, key in (('mhsa_fwd', 'mhsa_fwd_kernel'), ('mhsa_bwd', 'mhsa_bwd_kernels')):
+        e = mfma_entry(name)
+        if e:
+            others[key] = e
+    for name in ('stft', 'istft'):
+        e = hbm_entry(name)
+        if e:
+            others[name + '_kernel'] = e
+    others['gemm_share_of_step_ms'] = g_ms / args.steps
+    out['roofline_other_kernels'] = others
 
-    if rank == 0 and args.workload == 'enhance' and not args.graph and not args.no_host_fed:
-        # PCIe-inclusive side measurement (never `value`): the same K steps with every batch arriving from pinned HOST memory through the
-        # double-buffered feeder (feeder.py; the reference copies synchronously on the compute stream, runner.py:431-432, 556-557)
-        from speech_enhancement_by_s3prl_amd.feeder import HostBatchFeeder
-        host_l, host_w = lengths.cpu().pin_memory(), wavs.cpu().pin_memory()
-        feeder = HostBatchFeeder([(host_l, host_w)] * args.warmup, dev)
+
+def host_fed_leg(args, w, dev):
+    """PCIe-inclusive side measurement (never `value`): the same K steps with every batch arriving from pinned HOST memory through the
+    double-buffered feeder (feeder.py; the reference copies synchronously on the compute stream, runner.py:431-432, 556-557)"""
+    from speech_enhancement_by_s3prl_amd.feeder import HostBatchFeeder
+    step, max_len = w['step'], w['max_len']
+    host_l, host_w = w['lengths'].cpu().pin_memory(), w['wavs'].cpu().pin_memory()
+
+    def timed(channels):
+        feeder = HostBatchFeeder([(host_l, host_w)] * args.warmup, dev, channels=channels)
         for dl, dw in feeder:
             step(dw, dl, max_len)
         torch.cuda.synchronize()
@@ -375,38 +516,180 @@ def main():
         for dl, dw in feeder:
             step(dw, dl, max_len)
         torch.cuda.synchronize()
-        el = time.perf_counter() - t0
-        out['host_fed'] = {'value': args.batch * args.steps / el, 'unit': 'utt/s', 'ms_per_step': 1000.0 * el / args.steps,
-                           'bytes_per_step': host_w.numel() * 4 + host_l.numel() * 8,
-                           'note': 'rank 0 only; batches DMA-ed from pinned host memory on a copy stream, double buffered (PCIe-inclusive; not the headline value)'}
+        return time.perf_counter() - t0
+
+    el = timed(None)
+    rec = {'value': args.batch * args.steps / el, 'unit': 'utt/s', 'ms_per_step': 1000.0 * el / args.steps,
+           'bytes_per_step': host_w.numel() * 4 + host_l.numel() * 8,
+           'note': 'rank 0 only, after the process group is gone; batches DMA-ed from pinned host memory on a copy stream, double buffered '
+                   '(PCIe-inclusive; not the headline value)'}
+    if host_w.shape[1] > 2:
         # the same with only the channels the pass reads (0 = noisy, 1 = clean; runner.py:558-561) crossing PCIe
-        feeder = HostBatchFeeder([(host_l, host_w)] * args.warmup, dev, channels=2)
-        for dl, dw in feeder:
-            step(dw, dl, max_len)
-        torch.cuda.synchronize()
-        feeder.batches = [(host_l, host_w)] * args.steps
-        t0 = time.perf_counter()
-        for dl, dw in feeder:
-            step(dw, dl, max_len)
-        torch.cuda.synchronize()
-        el = time.perf_counter() - t0
-        out['host_fed']['two_channels'] = {'value': args.batch * args.steps / el, 'ms_per_step': 1000.0 * el / args.steps,
-                                           'bytes_per_step': host_w.numel() * 4 * 2 // host_w.shape[1] + host_l.numel() * 8}
+        el = timed(2)
+        rec['two_channels'] = {'value': args.batch * args.steps / el, 'ms_per_step': 1000.0 * el / args.steps,
+                               'bytes_per_step': host_w.numel() * 4 * 2 // host_w.shape[1] + host_l.numel() * 8}
+    return rec
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == 'enhance':
-        try:
-            out['cpu_baseline'] = cpu_baseline(batch=4, layers=args.layers, seconds_budget=28.0)
-        except Exception as e:      # the baseline is a reported extra; never lose the GPU line
-            out['cpu_baseline'] = {'value': None, 'unit': 'utt/s', 'cores': os.cpu_count(), 'kind': 'port', 'sample': f'failed: {e}'}
 
-    if distributed:
-        dist.barrier()
-        dist.destroy_process_group()
+def head_pass_bytes(head_feat):
+    """algorithmic HBM bytes per utterance of the head pass: the sum over its kernels, and the fully fused bound"""
+    T, F, K = 160000, 1001, 201
+    D = 120 if head_feat == 'mel120' else 201
+    stft = 2 * (4 * T + 2 * 4 * F * K)                       # both channels, power + phase each (SURVEY 8d: 2 249 608 B per utterance-channel)
+    feats = (4 * F * 40 + 4 * F * D * 3) if head_feat == 'mel120' else 0
+    head = 4 * F * (D + 2 * K + K)                           # features + noisy power in, predicted + offset out
+    istft = 2 * 4 * F * K + 4 * T + 4 * T                    # + the reference wav read by the level normalisation
+    crit = 2 * 4 * F * K                                     # SISDR criterion reads predicted + clean power
+    return {'sum_of_kernels': stft + feats + head + istft + crit, 'fused_bound': 2 * 4 * T,
+            'parts': {'stft_2ch': stft, 'features': feats, 'head': head, 'istft_dbnorm': istft, 'criterion': crit}}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=None, help='utterances per GPU per step (default: 32 = configs[1]; head workload: 256)')
+    ap.add_argument('--layers', type=int, default=6, help='encoder depth (6 = config/pretrain_sample.yaml; 3 = "base")')
+    ap.add_argument('--workload', choices=('enhance', 'finetune', 'lstm', 'head'), default='enhance',
+                    help="enhance = configs[1] (the headline metric); head = configs[3] / configs[0] (vcb.yaml / pseudo_noise.yaml inference: "
+                         "STFT -> LinearResidual mask -> iSTFT on (B, 2, T) noisy/clean batches, fp32, HBM-bound); finetune = configs[2]'s Mockingjay "
+                         'training step (fwd + L1 + bwd + gradient all-reduce + clip + BertAdam); lstm = the same step for the 3 x BiLSTM-256 head of '
+                         'pseudo_noise.yaml:50-53 on raw features (run_active.sh); all but enhance are side measurements')
+    ap.add_argument('--head-feat', choices=tuple(HEAD_FEATS), default='mel120', help='head workload: the mask head\'s input features')
+    ap.add_argument('--streams', type=int, default=1, help='process the batch as this many sub-batches on separate HIP streams (enhance workload)')
+    ap.add_argument('--graph', action='store_true', help='replay the pass as one hipGraph launch (serving-size batches are launch-bound)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-host-fed', action='store_true', help='skip the PCIe-inclusive side measurement')
+    ap.add_argument('--no-extras', action='store_true', help='skip the extra keys of the default line (fp32 parity-mode rate, head batch-12 rate)')
+    ap.add_argument('--backend', default='nccl', help="torch.distributed backend of the ranks ('nccl' = RCCL over xGMI)")
+    ap.add_argument('--one-device', action='store_true', help='rehearsal: every rank uses cuda:0 (several ranks on a one-GPU box, e.g. --gpus 2 --backend gloo)')
+    ap.add_argument('--launch-check', action='store_true', help='rank plumbing only (no kernels): used by the CPU test of the launcher')
+    ap.add_argument('--stub-step', action='store_true', help='CPU rehearsal of the whole control flow: the step is a torch stub with the same collective '
+                                                             'sequence (tests/test_dist_gloo.py); prints a line marked "stub"')
+    args = ap.parse_args()
+    if args.batch is None:
+        args.batch = 256 if args.workload == 'head' else (4 if args.stub_step else 32)
+
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        launch_ranks(args.gpus, sys.argv[1:])            # never returns; nothing above touched the GPU
+    if args.launch_check:
+        return launch_check(args)
+
+    # RCCL prints a version banner on stdout at communicator creation; the contract is ONE JSON line on stdout, so
+    # everything before the final print goes to stderr at the file-descriptor level.
+    sys.stdout.flush()
+    saved_stdout_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    # ---------------- phase A: every rank, identical sequence of collectives ----------------
+    ranks = Ranks(args)
+    rank, world, dev = ranks.rank, ranks.world, ranks.dev
+    w = build_stub_workload(args, ranks) if args.stub_step else build_workload(args, ranks)
+    step, lib, wavs, lengths, max_len = w['step'], w['lib'], w['wavs'], w['lengths'], w['max_len']
+
+    for _ in range(args.warmup):
+        step(wavs, lengths, max_len)
+    ranks.sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        wav_pred, loss, _ = step(wavs, lengths, max_len)
+    ranks.local_sync()
+    elapsed = time.perf_counter() - t0
+    if ranks.distributed:
+        ranks.dist.barrier()
+    elapsed = ranks.max_over_ranks(elapsed)
+    assert torch.isfinite(wav_pred).all() and torch.isfinite(loss)
+
+    do_roofline = not args.no_roofline and lib is not None
+    if not args.no_roofline:
+        # roofline leg: the same K steps with HIP events recorded (in-library, on the launch stream) around every kernel of the dominant
+        # families.  EVERY rank runs it (the training steps all-reduce; and no rank-conditional code may sit between two collectives).
+        if lib is not None:
+            lib.se_prof_reset()
+            lib.se_prof_enable(1)
+        for _ in range(args.steps):
+            step(wavs, lengths, max_len)
+        ranks.local_sync()
+        if lib is not None:
+            lib.se_prof_enable(0)
+    world_observed, was_distributed = ranks.world_observed, ranks.distributed
+    ranks.teardown()                                         # last collective; from here on no rank can wait for another
+
+    # ---------------- phase B: rank 0 only, collective-free by construction (the process group no longer exists) ----------------
+    if rank != 0:
+        return
+    import torch.distributed as _d
+    assert not (_d.is_available() and _d.is_initialized()), 'side legs must not run inside a process group'
+
+    total_utts = args.batch * world * args.steps
+    metric = {'enhance': 'enhanced 10s utts/sec', 'head': 'enhanced 10s utts/sec', 'finetune': 'fine-tuned 10s utts/sec (Mockingjay training step)',
+              'lstm': 'trained 10s utts/sec (LSTM head training step)'}[args.workload]
+    out = {
+        'metric': metric, 'value': total_utts / elapsed, 'unit': 'utt/s', 'n_gpus': world_observed,
+        'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1000.0 * elapsed / args.steps,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': w['dtype'], 'data': 'synthetic',
+        'config': {'workload': 'configs[1]: TERA/Mockingjay upstream (6x768x12x3072, pretrain_sample.yaml) + '
+                               'TransformerSpecPredictionHead, evaluate()-style pass, 10 s @ 16 kHz',
+                   'batch_per_gpu': args.batch, 'global_batch': args.batch * world, 'layers': args.layers,
+                   'frames': 1001, 'parallelism': f'dp{world} (utterance-sharded inference, no data-path collective)',
+                   'weights': 'seeded random, real sizes',
+                   'ranks': f'{world_observed} ranks counted by all-reduce over {args.backend}' if was_distributed else 'single process, no process group'},
+    }
+    if args.stub_step:
+        out['stub'] = 'control-flow rehearsal on CPU (torch stub step, same collective sequence); not a measurement'
+    if args.graph and args.workload in ('enhance', 'head'):
+        out['config']['launch'] = 'one hipGraph replay per step'
+    if args.streams > 1 and args.workload == 'enhance':
+        out['config']['streams'] = f'{args.streams} sub-batches of the batch in flight on separate HIP streams'
+    if args.workload == 'lstm':
+        out['config']['workload'] = ('config 5 style: 3 x BiLSTM-256 + Linear(512->201) head (pseudo_noise.yaml:50-53, 4.0 M params) on mel/log/delta-2 '
+                                     'features: STFT/features, forward, masked log-L1, backward (BPTT), gradient all-reduce, clip 1.0, BertAdam')
+        out['config']['parallelism'] = f'dp{world} (replicated parameters, one gradient all-reduce per step)'
+    if args.workload == 'finetune':
+        out['config']['workload'] = ('configs[2]: Mockingjay fine-tune step (6x768x12x3072 encoder + spec head, 43 M params): STFT/features, '
+                                     'forward (train mode, dropout 0.1), masked log-L1, backward, per-layer bucketed gradient all-reduce, clip 1.0, BertAdam')
+        out['config']['parallelism'] = f'dp{world} (replicated parameters, bucketed gradient all-reduce overlapped with the backward)'
+    if args.workload == 'head':
+        del out['config']['layers'], out['config']['weights']
+        out['config']['workload'] = ('configs[3] / configs[0]: vcb.yaml / pseudo_noise.yaml inference-only enhancement, evaluate()-style pass on (B, 2, T) '
+                                     'noisy/clean batches (NoisyCleanDataset): STFT of both channels -> ' +
+                                     ('mel/log/delta-2 features (120) -> ' if args.head_feat == 'mel120' else 'linear power features (201, vcb.yaml:10-14) -> ') +
+                                     'LinearResidual(cmvn, sigmoid) mask (.) noisy power -> iSTFT (noisy phase) -> level normalisation to the clean wav; '
+                                     'SISDR criterion; exact fp32 throughout')
+        if not args.stub_step:
+            hb = head_pass_bytes(args.head_feat)
+            per_s = out['value']
+            out['pass_hbm'] = {'algorithmic_bytes_per_utt_sum_of_kernels': hb['sum_of_kernels'], 'parts': hb['parts'],
+                               'achieved_GBs_sum_of_kernels': per_s * hb['sum_of_kernels'] / 1e9,
+                               'frac_sum_of_kernels': per_s * hb['sum_of_kernels'] / 1e9 / HBM_PEAK_GBS,
+                               'fused_bound_bytes_per_utt': hb['fused_bound'],
+                               'achieved_GBs_vs_fused_bound': per_s * hb['fused_bound'] / 1e9,
+                               'frac_vs_fused_bound': per_s * hb['fused_bound'] / 1e9 / HBM_PEAK_GBS,
+                               'note': 'whole-pass view (SURVEY 8d): utterances/s x algorithmic bytes per utterance / 8 TB/s; `roofline` is the dominant kernel'}
+
+    if do_roofline:
+        roofline_report(args, lib, out)
+
+    if not args.stub_step:
+        if args.workload in ('enhance', 'head') and not args.graph and not args.no_host_fed:
+            out['host_fed'] = host_fed_leg(args, w, dev)
+        if not args.no_extras:
+            extras_leg(args, w, dev, out)
+        if world == 1 and not args.no_cpu_baseline and args.workload in ('enhance', 'head'):
+            try:
+                if args.workload == 'enhance':
+                    out['cpu_baseline'] = cpu_baseline(batch=4, layers=args.layers, seconds_budget=28.0)
+                else:
+                    out['cpu_baseline'] = cpu_baseline_head(batch=16, head_feat=args.head_feat, seconds_budget=20.0)
+            except Exception as e:      # the baseline is a reported extra; never lose the GPU line
+                out['cpu_baseline'] = {'value': None, 'unit': 'utt/s', 'cores': os.cpu_count(), 'kind': 'port', 'sample': f'failed: {e}'}
+
     sys.stdout.flush()
     os.dup2(saved_stdout_fd, 1)
     os.close(saved_stdout_fd)
-    if rank == 0:
-        print(json.dumps(out), flush=True)
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == '__main__':

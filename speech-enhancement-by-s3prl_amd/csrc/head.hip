@@ -10,6 +10,7 @@
 // Bound: HBM (4*F*(D + 2N) bytes per utterance, +4*F*N when `offset` is stored); the f32 MFMA rate
 // (157 TF) puts the GEMM itself at about the same time, so the kernel is balanced, not MFMA-bound.
 #include "common.h"
+#include "prof.h"
 
 namespace se {
 
@@ -143,6 +144,8 @@ extern "C" size_t se_head_workspace_bytes(int B, int F, int D, int N) {
 template <int NT>
 static int launch_head(const float* feats, const float* W, const float* bias, const float* linears, const float* stats,
                        int rows, int F, int D, int N, int act, float* predicted, float* offset, hipStream_t st) {
+  // algorithmic bytes: features + noisy power in, predicted + offset out
+  se::ProfScope prof(se::kProfHead, 4.0 * rows * ((double)D + (linears ? N : 0) + (predicted ? N : 0) + (offset ? N : 0)), st);
   hipLaunchKernelGGL((se::head_kernel<NT>), dim3((rows + se::kHM - 1) / se::kHM), dim3(256), 0, st, feats, W, bias, linears,
                      stats, rows, F, D, N, act, predicted, offset);
   SE_LAUNCH_CHECK();

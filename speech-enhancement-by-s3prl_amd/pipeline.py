@@ -164,11 +164,12 @@ class UpstreamEnhanceStep:
 
 
 class HeadEnhanceStep:
-    """evaluate()-style pass for a feature-input head (LinearResidual / Linear), config 1 / 4:
-    wavs -> features -> mask head -> mask (.) noisy power -> decode_wav."""
+    """evaluate()-style pass for a feature-input head (LinearResidual / Linear), config 1 / 4 (runner.py:556-575):
+    wavs (B, C >= 2, T) -> features -> mask head -> mask (.) noisy power -> decode_wav [-> criterion].
+    Returns (wav_pred, predicted, linear_tar, loss); loss is None without a criterion."""
 
-    def __init__(self, preprocessor, head):
-        self.pre, self.head = preprocessor, head
+    def __init__(self, preprocessor, head, criterion=None):
+        self.pre, self.head, self.criterion = preprocessor, head, criterion
 
     @torch.no_grad()
     def __call__(self, wavs, lengths, max_len=None):
@@ -176,7 +177,11 @@ class HeadEnhanceStep:
         predicted, res = self.head(features=feats_down, linears=lin_inp)
         wav_tar = wavs[:, self.pre.channel_tar, :]
         wav_pred = decode.decode_wav(self.pre, predicted, ph_inp, lengths, wav_tar, max_len=max_len)
-        return wav_pred, predicted, lin_tar
+        loss = None
+        if self.criterion is not None:
+            stft_lengths = lengths // self.pre._win_args['hop_length'] + 1
+            loss, _ = self.criterion(predicted=predicted, linear_inp=lin_inp, linear_tar=lin_tar, stft_lengths=stft_lengths, **res)
+        return wav_pred, predicted, lin_tar, loss
 
 
 class MockingjayFinetuneStep:

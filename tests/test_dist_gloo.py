@@ -117,3 +117,49 @@ def test_bench_launcher_starts_the_ranks_itself():
     assert len(lines) == 1, lines                                           # ONE JSON line on stdout
     rec = json.loads(lines[0])
     assert rec['n_gpus'] == 2 and rec['world_observed'] == 2
+
+
+def _run_bench(argv, timeout=300):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    return subprocess.run([sys.executable, os.path.join(root, 'bench.py')] + argv, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                          text=True, timeout=timeout)
+
+
+@pytest.mark.parametrize('workload', ['finetune', 'enhance'])
+def test_bench_control_flow_two_ranks_stubbed(workload):
+    """The WHOLE control flow of bench.py at N = 2 over gloo with the step stubbed (`--stub-step`: same collective sequence per step --
+    (sum, count) all-reduce, per-layer async bucket all-reduces, tail reduce + wait -- through the product's own dist.py classes): warm-up,
+    timed loop, max-over-ranks, the roofline leg on EVERY rank, teardown, then rank 0's side legs with no process group left.  Round 2's
+    2-rank fine-tune rehearsal deadlocked because rank 0 alone re-ran all-reducing steps; this is the test that would have caught it
+    (a hang here fails by timeout)."""
+    import json
+    out = _run_bench(['--gpus', '2', '--workload', workload, '--stub-step', '--backend', 'gloo', '--steps', '3', '--warmup', '1'], timeout=240)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 2 and rec['steps'] == 3 and 'stub' in rec and rec['value'] > 0
+    assert rec['config']['global_batch'] == 2 * rec['config']['batch_per_gpu']
+
+
+def test_bench_phase_b_is_collective_free():
+    """static check of the invariant the fix rests on: in bench.main() nothing between Ranks() and ranks.teardown() is conditional on the
+    rank, and everything rank-0-only sits after teardown()."""
+    import ast
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, 'bench.py')).read()
+    tree = ast.parse(src)
+    main = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == 'main')
+    start = next(i for i, n in enumerate(main.body) if isinstance(n, ast.Assign) and 'Ranks(args)' in ast.get_source_segment(src, n))
+    end = next(i for i, n in enumerate(main.body) if isinstance(n, ast.Expr) and 'ranks.teardown()' in ast.get_source_segment(src, n))
+    assert start < end
+    for node in main.body[start:end]:
+        for sub in ast.walk(node):
+            if isinstance(sub, (ast.If, ast.IfExp, ast.While)):
+                cond = ast.get_source_segment(src, sub.test)
+                assert 'rank' not in cond.replace('ranks.', '').replace('do_roofline', ''), f'rank-conditional code inside the collective phase: {cond}'
+    tail = '\n'.join(ast.get_source_segment(src, n) for n in main.body[end + 1:])
+    assert 'if rank != 0' in tail and 'host_fed_leg' in tail and 'cpu_baseline' in tail
