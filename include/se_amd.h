@@ -93,6 +93,19 @@ int se_stft2_f32(const se_plan* plan, const float* wavs, int B, int C, int T, in
                  float* mel_a, int channel_b, float* power_b, float* phase_b, float* complx_b, float* mel_b, void* stream);
 
 /*
+ * se_stft_tphase_f32 -- rows A1 + A2 (+ A3) in the form every consumer INSIDE the path uses (runner.py:433,558 -> model -> runner.py:267):
+ * the noisy channel's phase is only ever fed back into OnlinePreprocessor.istft, so the transform writes it as one 32-bit word per bin from
+ * which (cos, sin) follow without transcendental functions -- t = tan(half the angle of (|re|, im)) = im / (|X| + |re|) in [-1, 1] as fp32,
+ * bit 0 of the pattern = (re < 0); X == 0 -> 0 (the reference's atan2(0, 0) = 0) -- and `phase` = atan2 stays an on-demand output of
+ * se_stft_f32.  One launch for one or two channels (channel_b < 0: one); every sample is loaded once.
+ *   power_*   (B, F, K) fp32 time-major  re^2+im^2                 (may be NULL)
+ *   tphase_*  (B, F, K) 32-bit words, time-major                   (may be NULL)
+ *   mel_*     (B, n_mels, F) fp32 feature-major raw mel power      (may be NULL)
+ */
+int se_stft_tphase_f32(const se_plan* plan, const float* wavs, int B, int C, int T, int channel_a, float* power_a, unsigned* tphase_a, float* mel_a,
+                       int channel_b, float* power_b, unsigned* tphase_b, float* mel_b, void* stream);
+
+/*
  * se_features_f32 -- row A4: OnlinePreprocessor.forward's select_feat: log(x+eps), `delta` stacked
  * compute_deltas passes (5-tap, replicate), CMVN over time (unbiased std, +eps), transposed to
  * time-major.
@@ -117,6 +130,14 @@ int se_features_f32(const float* raw, int raw_time_major, int B, int D, int F,
 int se_istft_f32(const se_plan* plan, const float* power, const float* phase, int B, int F,
                  float linear_power, float* wav_out, int wav_stride,
                  const int64_t* lengths, float* sumsq_out, void* stream);
+
+/*
+ * se_istft_tphase_f32 -- row A6 on (enhanced power, encoded phase of the noisy channel as se_stft_tphase_f32 writes it):
+ * X' = sqrt(power) * (+-(1 - t^2), 2 t) / (1 + t^2), then as se_istft_f32 (linear_power = 2).  log_input != 0: `power` holds log_predicted
+ * of a log-target head (model.py:108-124, predicted = exp(log_predicted)).  Outputs, zero fill and sumsq_out as se_istft_f32.
+ */
+int se_istft_tphase_f32(const se_plan* plan, const float* power, const unsigned* tphase, int B, int F, int log_input,
+                        float* wav_out, int wav_stride, const int64_t* lengths, float* sumsq_out, void* stream);
 
 /*
  * se_masked_sumsq_f32 -- utils.py:26-29 numerator: sums[b] = sum_{n < lengths[b]} x[b,n]^2  (sums zeroed inside).

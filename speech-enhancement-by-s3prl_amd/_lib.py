@@ -59,6 +59,8 @@ SIGNATURES = {
     'se_num_frames': (c_int, [_P, c_int]),
     'se_stft_f32': (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
     'se_stft2_f32': (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P]),
+    'se_stft_tphase_f32': (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P, _P, _P, _P]),
+    'se_istft_tphase_f32': (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, c_int, _P, _P, _P]),
     'se_features_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int]),
     'se_features_f32': (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P, _P, c_size_t, _P]),
     'se_istft_f32': (c_int, [_P, _P, _P, c_int, c_int, c_float, _P, c_int, _P, _P, _P]),

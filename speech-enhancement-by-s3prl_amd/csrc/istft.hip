@@ -16,6 +16,7 @@
 // All tables (twiddles, window) live in LDS and every global load of a thread is issued up front, so the output loop
 // holds stores only (a load there would drain the stores every iteration: one in-order vmcnt on gfx950).
 // LDS 52.8 KB -> 3 workgroups per CU.  Bound: vector issue (the HBM floor, 2 249 608 B per utterance, is ~9 us at B = 32).
+#include <stdlib.h>
 #include "plan.h"
 #include "prof.h"
 #include "fft200.h"
@@ -30,7 +31,8 @@ constexpr int kIPairs = 101;             // bin pairs (k, 200 - k) per frame
 constexpr int kIPairIters = (kIFR * kIPairs + kIThreads - 1) / kIThreads;   // 12
 constexpr float kIScale = 1.0f / 400.0f; // 1/200 (inverse transform) x 1/2 (E, O of the fold are kept doubled)
 
-template <int SQRT>
+// ENC = 1: `phase` holds the encoded words of se_stft_tphase_f32 (stft.hip: encode_phase): (cos, sin) = (+-(1 - t^2), 2 t) / (1 + t^2)
+template <int SQRT, int ENC>
 __global__ __launch_bounds__(kIThreads) void istft_kernel(
     const float* __restrict__ power, const float* __restrict__ phase, int F, float inv_lp,
     const float* __restrict__ window, const float2* __restrict__ tw400g, const float2* __restrict__ tw200g,
@@ -78,13 +80,23 @@ __global__ __launch_bounds__(kIThreads) void istft_kernel(
       const int fl = it / kIPairs, k = it - fl * kIPairs;
       const float m0 = SQRT ? __builtin_amdgcn_sqrtf(p0[r]) : powf(p0[r], inv_lp);
       const float m1 = SQRT ? __builtin_amdgcn_sqrtf(p1[r]) : powf(p1[r], inv_lp);
-      // sin / cos through the hardware units (argument in revolutions, reduced to [-0.5, 0.5])
-      float r0 = h0[r] * 0.15915494309189535f, r1 = h1[r] * 0.15915494309189535f;
-      r0 -= rintf(r0);
-      r1 -= rintf(r1);
       const bool k0 = (k == 0);
-      const float2 xk = make_float2(m0 * __builtin_amdgcn_cosf(r0), k0 ? 0.f : m0 * __builtin_amdgcn_sinf(r0));
-      const float2 xn = make_float2(m1 * __builtin_amdgcn_cosf(r1), k0 ? 0.f : m1 * __builtin_amdgcn_sinf(r1));
+      float2 xk, xn;
+      if (ENC) {
+        // bit 0 of the word (the sign of cos) stays in t: 6e-8 relative
+        const float t0 = h0[r], t1 = h1[r];
+        const float s0 = t0 * t0, s1 = t1 * t1;
+        const float g0 = m0 * __builtin_amdgcn_rcpf(1.0f + s0), g1 = m1 * __builtin_amdgcn_rcpf(1.0f + s1);
+        xk = make_float2(__uint_as_float(__float_as_uint((1.0f - s0) * g0) ^ (__float_as_uint(t0) << 31)), k0 ? 0.f : (t0 + t0) * g0);
+        xn = make_float2(__uint_as_float(__float_as_uint((1.0f - s1) * g1) ^ (__float_as_uint(t1) << 31)), k0 ? 0.f : (t1 + t1) * g1);
+      } else {
+        // sin / cos through the hardware units (argument in revolutions, reduced to [-0.5, 0.5])
+        float r0 = h0[r] * 0.15915494309189535f, r1 = h1[r] * 0.15915494309189535f;
+        r0 -= rintf(r0);
+        r1 -= rintf(r1);
+        xk = make_float2(m0 * __builtin_amdgcn_cosf(r0), k0 ? 0.f : m0 * __builtin_amdgcn_sinf(r0));
+        xn = make_float2(m1 * __builtin_amdgcn_cosf(r1), k0 ? 0.f : m1 * __builtin_amdgcn_sinf(r1));
+      }
       // doubled E, D (the 1/2 rides in the window scale); k = 100 pairs the bin with itself and both writes agree
       const float2 E = make_float2(xk.x + xn.x, xk.y - xn.y);
       const float2 D = make_float2(xk.x - xn.x, xk.y + xn.y);
@@ -256,11 +268,34 @@ extern "C" int se_istft_f32(const se_plan* plan, const float* power, const float
   dim3 grid((n_out + se::kISpan - 1) / se::kISpan, B);
   se::ProfScope prof(se::kProfIstft, (double)B * (8.0 * F * se::kBins + 4.0 * n_out), st);
   if (linear_power == 2.0f)
-    hipLaunchKernelGGL(se::istft_kernel<1>, grid, dim3(se::kIThreads), 0, st, power, phase, F, 0.5f, plan->d_window, plan->d_tw400, plan->d_tw200,
+    hipLaunchKernelGGL((se::istft_kernel<1, 0>), grid, dim3(se::kIThreads), 0, st, power, phase, F, 0.5f, plan->d_window, plan->d_tw400, plan->d_tw200,
                        wav_out, wav_stride, lengths, sumsq_out);
   else
-    hipLaunchKernelGGL(se::istft_kernel<0>, grid, dim3(se::kIThreads), 0, st, power, phase, F, 1.0f / linear_power, plan->d_window, plan->d_tw400,
+    hipLaunchKernelGGL((se::istft_kernel<0, 0>), grid, dim3(se::kIThreads), 0, st, power, phase, F, 1.0f / linear_power, plan->d_window, plan->d_tw400,
                        plan->d_tw200, wav_out, wav_stride, lengths, sumsq_out);
+  SE_LAUNCH_CHECK();
+  return SE_OK;
+}
+
+// the experimental persistent kernel of istft2.hip (SE_AMD_STFT2=1; measured equal or slower)
+extern "C" int se_istft2p_tphase_f32(const se_plan* plan, const float* power, const unsigned* tphase, int B, int F, int log_input,
+                                     float* wav_out, int wav_stride, const int64_t* lengths, float* sumsq_out, void* stream);
+
+extern "C" int se_istft_tphase_f32(const se_plan* plan, const float* power, const unsigned* tphase, int B, int F, int log_input,
+                                   float* wav_out, int wav_stride, const int64_t* lengths, float* sumsq_out, void* stream) {
+  SE_REQUIRE(plan && power && tphase && wav_out, "se_istft_tphase_f32: null argument");
+  SE_REQUIRE(B > 0 && B <= 65535 && F >= 2, "se_istft_tphase_f32: bad B=%d F=%d", B, F);
+  const int n_out = se::kHop * (F - 1);
+  SE_REQUIRE(wav_stride >= n_out, "se_istft_tphase_f32: wav_stride=%d < %d output samples", wav_stride, n_out);
+  SE_REQUIRE(sumsq_out == nullptr || lengths != nullptr, "se_istft_tphase_f32: sumsq_out needs lengths");
+  static const bool use2 = getenv("SE_AMD_STFT2") != nullptr;
+  if (use2 || log_input) return se_istft2p_tphase_f32(plan, power, tphase, B, F, log_input, wav_out, wav_stride, lengths, sumsq_out, stream);
+  hipStream_t st = se::as_stream(stream);
+  if (sumsq_out) { const int zrc_ = se::zero_async(sumsq_out, sizeof(float) * B, st); if (zrc_) return zrc_; }
+  dim3 grid((n_out + se::kISpan - 1) / se::kISpan, B);
+  se::ProfScope prof(se::kProfIstft, (double)B * (8.0 * F * se::kBins + 4.0 * n_out), st);
+  hipLaunchKernelGGL((se::istft_kernel<1, 1>), grid, dim3(se::kIThreads), 0, st, power, reinterpret_cast<const float*>(tphase), F, 0.5f, plan->d_window,
+                     plan->d_tw400, plan->d_tw200, wav_out, wav_stride, lengths, sumsq_out);
   SE_LAUNCH_CHECK();
   return SE_OK;
 }

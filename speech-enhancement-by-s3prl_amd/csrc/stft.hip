@@ -59,9 +59,20 @@ __device__ __forceinline__ float fast_atan2(float y, float x) {
   return copysignf(r, y);
 }
 
+// phase of X = (x, y), q = x^2 + y^2, as ONE word from which (cos, sin) follow rationally: t = y / (|X| + |x|) (= tan of half the angle of
+// (|x|, y), in [-1, 1]) as fp32 with bit 0 = (x < 0):  cos = +-(1 - t^2) / (1 + t^2), sin = 2 t / (1 + t^2)  (istft.hip decodes it).
+// ~8 instructions instead of ~22 for atan2, and no sin / cos on the consuming side.  X == 0 -> 0 -> (1, 0), the reference's atan2(0, 0) = 0.
+__device__ __forceinline__ float encode_phase(float x, float y, float q) {
+  const float m = q * __builtin_amdgcn_rsqf(q);             // |X|  (NaN for q == 0: handled by the select below)
+  const float d = m + fabsf(x);
+  const float t = (q > 0.f) ? y * __builtin_amdgcn_rcpf(d) : 0.f;
+  return __uint_as_float((__float_as_uint(t) & ~1u) | (__float_as_uint(x) >> 31));
+}
+
 // blockIdx.z selects one of up to two (channel, output set) jobs of the same launch: the reference transforms the noisy AND the clean channel
 // of every batch (runner.py:433,558); as two launches each was 1.4 rounds of the 768 resident workgroups at B = 32, together 2.8
-struct StftOut { float* power; float* phase; float* complx; float* mel; int channel; int vec_ok; };
+// enc != 0: the `phase` plane receives the encoded phase words of se_stft_tphase_f32 (encode_phase) instead of atan2
+struct StftOut { float* power; float* phase; float* complx; float* mel; int channel; int vec_ok; int enc; };
 
 __global__ __launch_bounds__(kThreads) void stft_kernel(
     const float* __restrict__ wavs, int C, int T, int F,
@@ -213,8 +224,13 @@ __global__ __launch_bounds__(kThreads) void stft_kernel(
         r1[r] = make_float2(X1.x * X1.x + X1.y * X1.y, 0.f);
         r2[r] = make_float2(X2.x * X2.x + X2.y * X2.y, 0.f);
         if (phase) {        // a job without a phase plane (the clean channel of the training batch: magnitude target only) skips 2 x ~22 instructions per pair
-          r1[r].y = fast_atan2(X1.y, X1.x);
-          r2[r].y = fast_atan2(X2.y, X2.x);
+          if (job.enc) {
+            r1[r].y = encode_phase(X1.x, X1.y, r1[r].x);
+            r2[r].y = encode_phase(X2.x, X2.y, r2[r].x);
+          } else {
+            r1[r].y = fast_atan2(X1.y, X1.x);
+            r2[r].y = fast_atan2(X2.y, X2.x);
+          }
         }
       }
       k += kThreads - 2 * 101;                              // 256 = 2 * 101 + 54
@@ -336,7 +352,7 @@ extern "C" int se_stft_f32(const se_plan* plan, const float* wavs, int B, int C,
     dbgbuf = reinterpret_cast<unsigned long long*>(complx);
     complx = nullptr;
   }
-  const se::StftOut job{power, phase, complx, mel, channel, (((uintptr_t)power | (uintptr_t)phase) % 16) == 0};
+  const se::StftOut job{power, phase, complx, mel, channel, (((uintptr_t)power | (uintptr_t)phase) % 16) == 0, 0};
   return stft_launch(plan, wavs, B, C, T, &job, 1, dbgbuf, stream);
 }
 
@@ -346,7 +362,27 @@ extern "C" int se_stft2_f32(const se_plan* plan, const float* wavs, int B, int C
   SE_REQUIRE(B > 0 && C > 0 && channel_a >= 0 && channel_a < C && channel_b >= 0 && channel_b < C, "se_stft2_f32: bad B=%d C=%d channels=%d,%d", B, C, channel_a, channel_b);
   SE_REQUIRE(T > se::kHalf, "se_stft2_f32: T=%d must exceed n_fft/2=%d (reflect padding)", T, se::kHalf);
   SE_REQUIRE(B <= 65535, "se_stft2_f32: B=%d exceeds grid.y limit", B);
-  const se::StftOut jobs[2] = {{power_a, phase_a, complx_a, mel_a, channel_a, (((uintptr_t)power_a | (uintptr_t)phase_a) % 16) == 0},
-                               {power_b, phase_b, complx_b, mel_b, channel_b, (((uintptr_t)power_b | (uintptr_t)phase_b) % 16) == 0}};
+  const se::StftOut jobs[2] = {{power_a, phase_a, complx_a, mel_a, channel_a, (((uintptr_t)power_a | (uintptr_t)phase_a) % 16) == 0, 0},
+                               {power_b, phase_b, complx_b, mel_b, channel_b, (((uintptr_t)power_b | (uintptr_t)phase_b) % 16) == 0, 0}};
   return stft_launch(plan, wavs, B, C, T, jobs, 2, nullptr, stream);
+}
+
+// the experimental persistent kernels of stft2.hip (SE_AMD_STFT2=1; measured equal or slower)
+extern "C" int se_stft2p_tphase_f32(const se_plan* plan, const float* wavs, int B, int C, int T, int channel_a, float* power_a, unsigned* tphase_a, float* mel_a,
+                                    int channel_b, float* power_b, unsigned* tphase_b, float* mel_b, void* stream);
+
+extern "C" int se_stft_tphase_f32(const se_plan* plan, const float* wavs, int B, int C, int T, int channel_a, float* power_a, unsigned* tphase_a, float* mel_a,
+                                  int channel_b, float* power_b, unsigned* tphase_b, float* mel_b, void* stream) {
+  SE_REQUIRE(plan && wavs, "se_stft_tphase_f32: null plan / wavs");
+  const int njobs = channel_b >= 0 ? 2 : 1;
+  SE_REQUIRE(B > 0 && C > 0 && channel_a >= 0 && channel_a < C && channel_b < C, "se_stft_tphase_f32: bad B=%d C=%d channels=%d,%d", B, C, channel_a, channel_b);
+  SE_REQUIRE(T > se::kHalf, "se_stft_tphase_f32: T=%d must exceed n_fft/2=%d (reflect padding)", T, se::kHalf);
+  SE_REQUIRE(B <= 65535, "se_stft_tphase_f32: B=%d exceeds grid.y limit", B);
+  static const bool use2 = getenv("SE_AMD_STFT2") != nullptr;
+  if (use2) return se_stft2p_tphase_f32(plan, wavs, B, C, T, channel_a, power_a, tphase_a, mel_a, channel_b, power_b, tphase_b, mel_b, stream);
+  float* pa = reinterpret_cast<float*>(tphase_a);
+  float* pb = reinterpret_cast<float*>(tphase_b);
+  const se::StftOut jobs[2] = {{power_a, pa, nullptr, mel_a, channel_a, (((uintptr_t)power_a | (uintptr_t)pa) % 16) == 0, 1},
+                               {power_b, pb, nullptr, mel_b, njobs > 1 ? channel_b : channel_a, (((uintptr_t)power_b | (uintptr_t)pb) % 16) == 0, 1}};
+  return stft_launch(plan, wavs, B, C, T, jobs, njobs, nullptr, stream);
 }

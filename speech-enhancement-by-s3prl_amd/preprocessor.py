@@ -26,6 +26,41 @@ from . import _lib
 N_SAMPLED_PSEUDO_WAV = 2
 
 
+class LazyPhase(torch.Tensor):
+    """The `phase` feature of the boundary (run_downstream.py:150-157: `get_feat_config('phase', channel)`), produced ON DEMAND.
+
+    Every consumer of the noisy phase inside the reference's pipelines is `preprocessor.istft(linears, phases)` (runner.py:267), and nothing
+    ever reads the clean channel's phase (runner.py:433,558 unpack it and drop it).  So the hot path neither computes atan2 in the STFT nor
+    sin / cos in the iSTFT: the STFT kernel writes the phase as one word per bin from which (cos, sin) follow rationally (`_tphase`, int32
+    (..., F, K): fp32 t = tan(half angle) with the sign of cos in bit 0, stft2.hip), `istft` recognises this object and runs
+    se_istft_tphase_f32 on it.  Any OTHER use -- arithmetic, indexing, .cpu(), printing, torch.save -- goes through __torch_dispatch__,
+    which first materialises the real (…, F, K) fp32 phase with the atan2 kernel (se_stft_f32 on the retained waveform: bit-identical to
+    what the eager path returns) and then runs the requested op on it.  Shape / dtype / device are the real tensor's."""
+
+    @staticmethod
+    def __new__(cls, shape, device, materialize, tphase=None):
+        r = torch.Tensor._make_wrapper_subclass(cls, tuple(shape), dtype=torch.float32, device=device, requires_grad=False)
+        r._materialize_fn, r._tphase, r._value = materialize, tphase, None
+        return r
+
+    def materialize(self):
+        if self._value is None:
+            self._value = self._materialize_fn()
+            self._materialize_fn = None
+        return self._value
+
+    @classmethod
+    def __torch_dispatch__(cls, func, types, args=(), kwargs=None):
+        from torch.utils._pytree import tree_map
+
+        def unwrap(t):
+            return t.materialize() if isinstance(t, LazyPhase) else t
+        return func(*tree_map(unwrap, args), **tree_map(unwrap, kwargs or {}))
+
+    def __reduce_ex__(self, protocol):          # pickling / torch.save / deepcopy: as the plain tensor
+        return self.materialize().__reduce_ex__(protocol)
+
+
 class OnlinePreprocessor(nn.Module):
     _FEAT_TYPES = ('complx', 'linear', 'phase', 'mel', 'mfcc')
 
@@ -194,6 +229,56 @@ class OnlinePreprocessor(nn.Module):
                                     cb, g(ob, 'linear'), g(ob, 'phase'), g(ob, 'complx'), g(ob, 'mel'), _lib.stream()), 'se_stft2_f32')
         return {ca: oa, cb: ob}
 
+    # ---- the encoded-phase form of the STFT (stft2.hip): what the hot path runs ------------------------------------------------------
+    lazy_phase = True          # False: always return eager atan2 phase planes (the round-2 behaviour)
+
+    def _tphase_path_ok(self, need, wavs3, home):
+        """phase planes can be LazyPhase objects when the caller lives on the device (host-resident callers get plain tensors), at most two
+        channels are transformed and nobody asked for `complx`."""
+        if not self.lazy_phase or home != wavs3.device or not need or len(need) > 2:
+            return False
+        if not any('phase' in k for k in need.values()):
+            return False
+        return all(k <= {'linear', 'phase', 'mel'} for k in need.values())
+
+    def _stft_tphase(self, wavs3, need, lead):
+        """One se_stft_tphase_f32 launch for the (one or two) channels of `need`.  The encoded phase plane is kept for the INPUT channel only
+        (`channel_inp`, set by run_downstream.py:161 / pipeline.build_preprocessor; default: the lowest channel that asks for a phase):
+        it is what istft() consumes; every other channel's phase is never read by the reference and costs nothing until somebody does."""
+        lib = _lib.load()
+        B, C, T = wavs3.shape
+        F = T // self._win_args['hop_length'] + 1
+        K = self._n_freq
+        dev = wavs3.device
+        with_phase = sorted(ch for ch, k in need.items() if 'phase' in k)
+        ch_inp = getattr(self, 'channel_inp', None)
+        if ch_inp not in with_phase:
+            ch_inp = with_phase[0]
+        chans = sorted(need)
+        outs = {}
+        for ch in chans:
+            o = {}
+            if 'linear' in need[ch]:
+                o['linear'] = torch.empty(B, F, K, device=dev, dtype=torch.float32)
+            if 'mel' in need[ch]:
+                o['mel'] = torch.empty(B, self._n_mels, F, device=dev, dtype=torch.float32)
+            if ch == ch_inp and 'phase' in need[ch]:
+                o['_tphase'] = torch.empty(B, F, K, device=dev, dtype=torch.int32)
+            outs[ch] = o
+        g = lambda o, k: _lib.ptr(o.get(k))       # noqa: E731
+        a = chans[0]
+        b = chans[1] if len(chans) > 1 else -1
+        ob = outs[b] if b >= 0 else {}
+        _lib.check(lib.se_stft_tphase_f32(self._plan(dev), _lib.ptr(wavs3), B, C, T, a, g(outs[a], 'linear'), g(outs[a], '_tphase'), g(outs[a], 'mel'),
+                                          b, g(ob, 'linear'), g(ob, '_tphase'), g(ob, 'mel'), _lib.stream()), 'se_stft_tphase_f32')
+        for ch in chans:
+            if 'phase' in need[ch]:
+                def materialize(ch=ch):
+                    return self._stft_channel(wavs3, ch, {'phase'})['phase'].reshape(*lead, F, K)
+                ph = outs[ch].get('_tphase')
+                outs[ch]['phase'] = LazyPhase((*lead, F, K), dev, materialize, None if ph is None else ph.reshape(*lead, F, K))
+        return outs
+
     def _select(self, raw, raw_time_major, log, delta, cmvn):
         """se_features_f32: raw (B, D, F) feature-major or (B, F, D) time-major -> (B, F, D*(1+delta))."""
         lib = _lib.load()
@@ -230,7 +315,10 @@ class OnlinePreprocessor(nn.Module):
                 mfcc_channels.add(int(a.get('channel', 0)))
                 continue
             need.setdefault(int(a.get('channel', 0)), set()).add(ft)
-        if len(need) == 2:       # the reference's standard list (noisy + clean channel): both transforms in ONE launch
+        lazy = self._tphase_path_ok(need, wavs3, home)
+        if lazy:
+            planes = self._stft_tphase(wavs3, need, lead)
+        elif len(need) == 2:       # the reference's standard list (noisy + clean channel): both transforms in ONE launch
             planes = self._stft_two_channels(wavs3, need)
         else:
             planes = {ch: self._stft_channel(wavs3, ch, kinds) for ch, kinds in need.items()}
@@ -242,6 +330,9 @@ class OnlinePreprocessor(nn.Module):
             ft, ch = a['feat_type'], int(a.get('channel', 0))
             log, delta, cmvn = bool(a.get('log', False)), int(a.get('delta', 0)), bool(a.get('cmvn', False))
             raw = planes[ch][ft]                 # mel: (B, D, F) feature-major; everything else time-major
+            if type(raw) is LazyPhase:
+                feats.append(raw)                # (*lead, F, K) already; materialises itself on any use but istft()
+                continue
             if ft == 'mel':
                 feat = self._select(raw, False, log, delta, cmvn)
             elif log or delta or cmvn:
@@ -262,6 +353,9 @@ class OnlinePreprocessor(nn.Module):
     def istft_with_sumsq(self, linears, phases, linear_power=2, lengths=None, out_len=None):
         """se_istft_f32; with `lengths` also returns the masked sum of squares (fused, for the dB normalisation)."""
         linears, home = self._stage(linears)
+        if (type(phases) is LazyPhase and phases._tphase is not None and phases._value is None and float(linear_power) == 2.0 and
+                phases._tphase.device == linears.device and home == linears.device):
+            return self._istft_tphase(linears, phases._tphase, lengths, out_len)
         phases = phases.to(linears.device)
         lib = _lib.load()
         lead = linears.shape[:-2]
@@ -279,6 +373,26 @@ class OnlinePreprocessor(nn.Module):
         _lib.check(lib.se_istft_f32(self._plan(lin.device), _lib.ptr(lin), _lib.ptr(ph), B, F, float(linear_power),
                                     _lib.ptr(wav), stride, _lib.ptr(lengths), _lib.ptr(sumsq), _lib.stream()), 'se_istft_f32')
         return wav.reshape(*lead, stride).to(home), (None if sumsq is None else sumsq.to(home))
+
+    def _istft_tphase(self, linears, tphase, lengths, out_len, log_input=False):
+        """se_istft_tphase_f32: X' = sqrt(linears) * (cos, sin)(tphase) -> waveform (+ the masked square sum when `lengths` is given)."""
+        lib = _lib.load()
+        lead = linears.shape[:-2]
+        F, K = linears.shape[-2:]
+        lin = linears.contiguous().float().reshape(-1, F, K)
+        ph = tphase.reshape(-1, F, K)
+        assert ph.shape[0] == lin.shape[0] and ph.is_contiguous()
+        B = lin.shape[0]
+        n_out = self._win_args['hop_length'] * (F - 1)
+        stride = n_out if out_len is None else max(int(out_len), n_out)
+        wav = torch.empty(B, stride, device=lin.device, dtype=torch.float32)
+        sumsq = None
+        if lengths is not None:
+            lengths = lengths.to(device=lin.device, dtype=torch.int64).contiguous()
+            sumsq = torch.empty(B, device=lin.device, dtype=torch.float32)
+        _lib.check(lib.se_istft_tphase_f32(self._plan(lin.device), _lib.ptr(lin), _lib.ptr(ph), B, F, int(bool(log_input)), _lib.ptr(wav), stride,
+                                           _lib.ptr(lengths), _lib.ptr(sumsq), _lib.stream()), 'se_istft_tphase_f32')
+        return wav.reshape(*lead, stride), sumsq
 
     # ---- attributes used by sampler.hist_scoring (sampler.py:226-228) -----------------------------------
     def _stft(self, wav2d, window=None):

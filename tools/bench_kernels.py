@@ -205,18 +205,50 @@ def bench_mhsa():
     print(f'mhsa prescaled B={B} T={T}: {ms*1e3:8.1f} us  {4.0*B*heads*T*T*64/ms/1e9:8.1f} TF/s   max diff vs the unscaled kernel {d:.2e}', flush=True)
 
 
+def interleaved(variants, rounds=7, iters=20):
+    """cdna_hip_programming.md rule 24: N variants x M rounds interleaved in ONE process; prints min and median per variant"""
+    import statistics
+    times = {k: [] for k in variants}
+    for fn in variants.values():
+        for _ in range(3):
+            fn()
+    torch.cuda.synchronize()
+    for _ in range(rounds):
+        for k, fn in variants.items():
+            times[k].append(timeit(fn, iters=iters, warm=1))
+    return {k: (min(v), statistics.median(v)) for k, v in times.items()}
+
+
 def bench_stft():
+    """STFT / iSTFT stand-alone, old (power + atan2 phase; sqrt / sin / cos) and new (power + unit phasor) forms, one channel and
+    the bench pass's two-channel launch, interleaved.  GB/s = SURVEY 8d's algorithmic bytes (2 249 608 B per utterance-channel) / time."""
     from speech_enhancement_by_s3prl_amd.preprocessor import OnlinePreprocessor
+    from speech_enhancement_by_s3prl_amd import pipeline
     P = OnlinePreprocessor().to(dev)
+    P6 = pipeline.build_preprocessor(pipeline.make_config(), dev)
+    byt = 2249608
     for B in (32, 256):
         wavs = torch.randn(B, 3, 160000, device=dev) * 0.1
         fl = [P.get_feat_config('linear', 0), P.get_feat_config('phase', 0)]
-        ms = timeit(lambda: P(wavs, fl))
-        byts = B * 2249608
-        print(f'stft B={B}: {ms*1e3:8.1f} us  {byts/ms/1e6:8.1f} GB/s', flush=True)
+        need = {0: {'linear', 'phase', 'mel'}, 1: {'linear', 'phase'}}
+        P.lazy_phase = False
         lin, ph = P(wavs, fl)
-        ms = timeit(lambda: P.istft(lin, ph))
-        print(f'istft B={B}: {ms*1e3:8.1f} us  {byts/ms/1e6:8.1f} GB/s', flush=True)
+        P.lazy_phase = True
+        lin2, ph2 = P(wavs, fl)
+
+        def old1():
+            P.lazy_phase = False
+            P(wavs, fl)
+
+        def new1():
+            P.lazy_phase = True
+            P(wavs, fl)
+        res = interleaved({'stft  atan2  1ch': old1, 'stft  phasor 1ch': new1,
+                           'stft  atan2  2ch': lambda: P6._stft_two_channels(wavs, need), 'stft  phasor 2ch': lambda: P6._stft_tphase(wavs, need, (B,)),
+                           'istft atan2': lambda: P.istft(lin, ph), 'istft phasor': lambda: P.istft(lin2, ph2)})
+        for k, (mn, med) in res.items():
+            n = 2 * B if '2ch' in k else B
+            print(f'{k} B={B}: min {mn*1e3:7.1f} us ({n*byt/mn/1e6:7.1f} GB/s)  median {med*1e3:7.1f} us ({n*byt/med/1e6:7.1f} GB/s)', flush=True)
 
 
 def bench_hbm():
