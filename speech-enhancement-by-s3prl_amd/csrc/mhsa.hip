@@ -21,6 +21,12 @@
 #include "mhsa_tile.h"
 #include "dropout.h"
 
+// developer ablation (timing only, results are wrong): build with SE_AMD_EXTRA_DEFINES=-DSE_MHSA_ABL=<mask>: 1 no K/V staging, 2 no barrier,
+// 4 no exponentials, 8 no PV MFMAs, 16 no QK MFMAs, 32 no LDS fragment reads
+#ifndef SE_MHSA_ABL
+#define SE_MHSA_ABL 0
+#endif
+
 namespace se {
 
 // DROP = 1 (training): the attention probabilities are dropped (counter-based mask of dropout.h, site key `dkey`) AFTER the
@@ -33,11 +39,14 @@ namespace se {
 // [2^-60, 2^60) (overflow, inf / nan, or -- first tile -- a row far below the reference) sends the wave to the exact online-softmax tile
 // for this tile and every later one.  fp32 / bf16 keep their relative precision anywhere in that range.  Same box: 133 us speculative
 // against 147 us always-exact (SE_AMD_MHSA_SPEC=0) per B = 32 launch.
-template <int OCC, int DROP, int PRE>
+// DMA = 1: the K / V tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no ds_write, no wait in front of the writes); the
+// destination of a wave instruction is lane-linear (8 rows x 128 B), so the XOR swizzle of kv_off() is applied to the per-lane SOURCE chunk.
+// The compile-time ablation (-DSE_MHSA_ABL) put the register staging at 27 % of the launch.
+template <int OCC, int DROP, int PRE, int DMA = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void mhsa_fwd_kernel(
     const uint16_t* __restrict__ qkv, const int32_t* __restrict__ lengths, int T, int H, uint16_t* __restrict__ ctx,
     float* __restrict__ lse, uint32_t dkey, uint32_t thr16, float dscale) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * 2 * kAK * kHD * 2];   // 2 buffers x (K, V) x 8 KiB = 32 KiB
+  __shared__ __attribute__((aligned(16))) char smem[(DMA == 2 ? 3 : 2) * 2 * kAK * kHD * 2];   // 2 (DMA == 2: 3) slots x (K, V) x 8 KiB = 32 (48) KiB
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hh = lane >> 5;
@@ -97,6 +106,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
     *reinterpret_cast<uint4*>(v_w + so0) = rv0;                         \
     *reinterpret_cast<uint4*>(v_w + so1) = rv1;                         \
   } while (0)
+  // LDS-DMA form: wave w brings rows [16 w, 16 w + 16) of the K and of the V tile, two 1-KiB pieces (8 rows x 128 B) each; lane l of a piece
+  // writes slot l & 7 of row l >> 3, i.e. it must FETCH chunk (l & 7) ^ f(row) (kv_off: slot = chunk ^ f)
+  typedef __attribute__((address_space(1))) const void* glb_a_t;
+  typedef __attribute__((address_space(3))) void* lds_a_t;
+  const int drow = wave * 16 + (lane >> 3);                 // tile row of this lane in piece 0 (piece 1: + 8)
+  const int dch0 = ((lane & 7) ^ (kv_off(drow, 0) >> 4 & 7)) * 8, dch1 = ((lane & 7) ^ (kv_off(drow + 8, 0) >> 4 & 7)) * 8;
+#define SE_A_DMA(kt, buf)                                                                                                  \
+  do {                                                                                                                     \
+    const size_t r0 = (size_t)min((kt) * kAK + drow, T - 1) * ld;                                                          \
+    const size_t r1 = (size_t)min((kt) * kAK + drow + 8, T - 1) * ld;                                                      \
+    char* k_w = smem + (buf) * 16384 + wave * 2048;                                                                        \
+    __builtin_amdgcn_global_load_lds((glb_a_t)(base + H + r0 + dch0), (lds_a_t)(k_w), 16, 0, 0);                           \
+    __builtin_amdgcn_global_load_lds((glb_a_t)(base + H + r1 + dch1), (lds_a_t)(k_w + 1024), 16, 0, 0);                    \
+    __builtin_amdgcn_global_load_lds((glb_a_t)(base + 2 * H + r0 + dch0), (lds_a_t)(k_w + 8192), 16, 0, 0);                \
+    __builtin_amdgcn_global_load_lds((glb_a_t)(base + 2 * H + r1 + dch1), (lds_a_t)(k_w + 8192 + 1024), 16, 0, 0);         \
+  } while (0)
 
   const f32x16 kZero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   f32x16 o0, o1;                      // O^T d-blocks 0 / 1: col = query (lane & 31), row = d
@@ -127,21 +152,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
   // dropout: pair index of (this lane's query row, key) = row_id * ceil(T / 2) + key / 2
   const uint32_t drop_row = ((uint32_t)(b * (H / kHD) + head) * (uint32_t)T + (uint32_t)min(q0 + l31, T - 1)) * (uint32_t)((T + 1) >> 1);
 
-  SE_A_ISSUE(0);
-  SE_A_WRITE(0);
-  __syncthreads();
+  if (DMA == 2) {
+    // three slots, tiles kt + 1 AND kt + 2 in flight: the first toucher of a K / V tile takes an L2 miss (8 query tiles share it: 12.5 % compulsory
+    // misses), and one tile of lookahead does not cover that round trip under load
+    SE_A_DMA(0, 0);
+    if (nkt > 1) {
+      SE_A_DMA(1, 1);
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+  } else if (DMA) {
+    SE_A_DMA(0, 0);
+  } else {
+    SE_A_ISSUE(0);
+    SE_A_WRITE(0);
+  }
+  if (DMA != 2) __syncthreads();
 
 #define SE_A_TILE(CUR)                                                                                                     \
   {                                                                                                                        \
-    if (kt + 1 < nkt) SE_A_ISSUE(kt + 1);                                                                                  \
+    if (DMA == 2) { if (kt + 2 < nkt) SE_A_DMA(kt + 2, (CUR) >= 1 ? (CUR) - 1 : 2); }                                      \
+    else if (DMA == 3) { if (kt + 1 < nkt) SE_A_DMA(kt + 1, (CUR) ^ 1); }                                                  \
+    else if (kt + 1 < nkt && !(SE_MHSA_ABL & 1)) { if (DMA) SE_A_DMA(kt + 1, (CUR) ^ 1); else SE_A_ISSUE(kt + 1); }       \
     const char* t_s = smem + (CUR) * 16384;                                                                                \
     f32x16 s0, s1;                                                                                                         \
     _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                                        \
-      const bf16x8 ka = *reinterpret_cast<const bf16x8*>(t_s + koff[s]);                                                   \
-      const bf16x8 kb_ = *reinterpret_cast<const bf16x8*>(t_s + koff[s] + 4096);                                           \
+      const bf16x8 ka = (SE_MHSA_ABL & 32) ? qf[s] : *reinterpret_cast<const bf16x8*>(t_s + koff[s]);                      \
+      const bf16x8 kb_ = (SE_MHSA_ABL & 32) ? qf[3 - s] : *reinterpret_cast<const bf16x8*>(t_s + koff[s] + 4096);          \
       /* first product of the chain takes the inline constant 0 as C: no 32 v_mov per tile to clear the accumulators */      \
+      if (SE_MHSA_ABL & 16) { if (s == 0) { _Pragma("unroll") for (int r = 0; r < 16; ++r) { s0[r] = __builtin_bit_cast(f32x4, ka)[r & 3] * 1e-30f; s1[r] = __builtin_bit_cast(f32x4, kb_)[r & 3] * 1e-30f; } } } else { \
       s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[s], s == 0 ? kZero16 : s0, 0, 0, 0);                              \
-      s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb_, qf[s], s == 0 ? kZero16 : s1, 0, 0, 0);                             \
+      s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb_, qf[s], s == 0 ? kZero16 : s1, 0, 0, 0); }                           \
     }                                                                                                                      \
     if ((kt + 1) * kAK > len) {                                                                                            \
       const int kbase = kt * kAK + 4 * hh;                                                                                 \
@@ -162,8 +205,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
       float rs0 = 0.f, rs1 = 0.f;                                                                                          \
       _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                                        \
         _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                                    \
-          const float a0 = __builtin_amdgcn_exp2f(s0[8 * s + j]);                                                          \
-          const float a1 = __builtin_amdgcn_exp2f(s1[8 * s + j]);                                                          \
+          const float a0 = (SE_MHSA_ABL & 4) ? s0[8 * s + j] * 0.5f + 1.0f : __builtin_amdgcn_exp2f(s0[8 * s + j]);        \
+          const float a1 = (SE_MHSA_ABL & 4) ? s1[8 * s + j] * 0.5f + 1.0f : __builtin_amdgcn_exp2f(s1[8 * s + j]);        \
           rs0 += a0;                                                                                                       \
           rs1 += a1;                                                                                                       \
           pf[0][s][j] = (__bf16)a0;                                                                                        \
@@ -226,28 +269,50 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
     _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                                                       \
       _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                                      \
         _Pragma("unroll") for (int dblk = 0; dblk < 2; ++dblk) {                                                           \
+          bf16x8 va = qf[2 * kb + s];                                                                                       \
+          if (!(SE_MHSA_ABL & 32)) {                                                                                       \
           const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(                                                      \
               (__attribute__((address_space(3))) bf16x4*)(t_s + voff[dblk][0] + kb * 4096 + s * 2048));                    \
           const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(                                                      \
               (__attribute__((address_space(3))) bf16x4*)(t_s + voff[dblk][1] + kb * 4096 + s * 2048));                    \
-          const bf16x8 va = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};                                      \
+          va = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};                                             \
+          }                                                                                                                \
+          if (SE_MHSA_ABL & 8) { o0[2 * kb + s] += __builtin_bit_cast(f32x4, va)[0] * __builtin_bit_cast(f32x4, pf[kb][s])[dblk]; } else { \
           if (dblk == 0) o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, pf[kb][s], o0, 0, 0, 0);                         \
-          else o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, pf[kb][s], o1, 0, 0, 0);                                   \
+          else o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, pf[kb][s], o1, 0, 0, 0); }                                 \
         }                                                                                                                  \
       }                                                                                                                    \
-    if (kt + 1 < nkt) SE_A_WRITE((CUR) ^ 1);                                                                               \
-    __syncthreads();                                                                                                       \
+    if (!DMA && kt + 1 < nkt && !(SE_MHSA_ABL & 1)) SE_A_WRITE((CUR) ^ 1);                                                 \
+    if (DMA == 2) {                                                                                                        \
+      if (kt + 2 < nkt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  \
+      __builtin_amdgcn_s_barrier();                                                                                        \
+    } else if (!(SE_MHSA_ABL & 2)) __syncthreads();                                                                        \
   }
 
-  // unrolled by two so the double-buffer offset is an immediate
   int kt = 0;
-  for (; kt + 1 < nkt; kt += 2) {
-    SE_A_TILE(0)
-    ++kt;
-    SE_A_TILE(1)
-    --kt;
+  if (DMA == 2) {
+    // ONE tile body with a run-time slot (three unrolled bodies spill at 3 waves per SIMD)
+    int slot = 0;
+    for (; kt < nkt; ++kt) {
+      SE_A_TILE(slot)
+      slot = slot == 2 ? 0 : slot + 1;
+    }
+  } else if (DMA == 3) {
+    int slot = 0;
+    for (; kt < nkt; ++kt) {
+      SE_A_TILE(slot)
+      slot ^= 1;
+    }
+  } else {
+    // unrolled by two so the double-buffer offset is an immediate
+    for (; kt + 1 < nkt; kt += 2) {
+      SE_A_TILE(0)
+      ++kt;
+      SE_A_TILE(1)
+      --kt;
+    }
+    if (kt < nkt) SE_A_TILE(0)
   }
-  if (kt < nkt) SE_A_TILE(0)
 #undef SE_A_TILE
 
   // ---- epilogue: O / l ; lane holds query q0 + l31, d = 32 dblk + (r&3) + 8 (r>>2) + 4 hh
@@ -317,7 +382,18 @@ static int mhsa_prescaled_launch(const uint16_t* qkv, const int32_t* lengths, in
   if (pipe) return se_mhsa_fwd_pipe_launch(qkv, lengths, B, T, heads, ctx, pipe_occ, se::as_stream(stream));
   static int spec = -1;
   if (spec < 0) { const char* e = getenv("SE_AMD_MHSA_SPEC"); spec = e ? atoi(e) : 1; }      // 0: always the exact online-softmax tile (A/B)
-  hipLaunchKernelGGL((se::mhsa_fwd_kernel<3, 0, 1>), grid, dim3(256), 0, se::as_stream(stream), qkv, lengths, T, H, ctx, nullptr, 0u, 0u, spec ? 1.f : -1.f);
+  static int dma = -1;
+  if (dma < 0) { const char* e = getenv("SE_AMD_MHSA_DMA"); dma = e ? atoi(e) : 0; }        // A/B: 1 LDS-DMA 2-slot ring, 2 three slots + two tiles in flight, 3 one-body ring at 4 waves per SIMD, 4 the same at 3 (all measured equal or slower: DESIGN section 6)
+  if (dma == 3)
+    hipLaunchKernelGGL((se::mhsa_fwd_kernel<4, 0, 1, 3>), grid, dim3(256), 0, se::as_stream(stream), qkv, lengths, T, H, ctx, nullptr, 0u, 0u, spec ? 1.f : -1.f);
+  else if (dma == 4)
+    hipLaunchKernelGGL((se::mhsa_fwd_kernel<3, 0, 1, 3>), grid, dim3(256), 0, se::as_stream(stream), qkv, lengths, T, H, ctx, nullptr, 0u, 0u, spec ? 1.f : -1.f);
+  else if (dma == 2)
+    hipLaunchKernelGGL((se::mhsa_fwd_kernel<3, 0, 1, 2>), grid, dim3(256), 0, se::as_stream(stream), qkv, lengths, T, H, ctx, nullptr, 0u, 0u, spec ? 1.f : -1.f);
+  else if (dma)
+    hipLaunchKernelGGL((se::mhsa_fwd_kernel<3, 0, 1, 1>), grid, dim3(256), 0, se::as_stream(stream), qkv, lengths, T, H, ctx, nullptr, 0u, 0u, spec ? 1.f : -1.f);
+  else
+    hipLaunchKernelGGL((se::mhsa_fwd_kernel<3, 0, 1, 0>), grid, dim3(256), 0, se::as_stream(stream), qkv, lengths, T, H, ctx, nullptr, 0u, 0u, spec ? 1.f : -1.f);
   SE_LAUNCH_CHECK();
   return SE_OK;
 }
