@@ -135,9 +135,12 @@ int se_istft_f32(const se_plan* plan, const float* power, const float* phase, in
  * se_istft_tphase_f32 -- row A6 on (enhanced power, encoded phase of the noisy channel as se_stft_tphase_f32 writes it):
  * X' = sqrt(power) * (+-(1 - t^2), 2 t) / (1 + t^2), then as se_istft_f32 (linear_power = 2).  log_input != 0: `power` holds log_predicted
  * of a log-target head (model.py:108-124, predicted = exp(log_predicted)).  Outputs, zero fill and sumsq_out as se_istft_f32.
+ * ref / ref_stride / ref_sumsq_out (optional): the reference waveform of the level normalisation (runner.py:570 passes wav_tar): its masked
+ * square sum over n < min(lengths[b], hop (F-1)) is accumulated by the same launch (what se_masked_sumsq_f32 computes on its own).
  */
 int se_istft_tphase_f32(const se_plan* plan, const float* power, const unsigned* tphase, int B, int F, int log_input,
-                        float* wav_out, int wav_stride, const int64_t* lengths, float* sumsq_out, void* stream);
+                        float* wav_out, int wav_stride, const int64_t* lengths, float* sumsq_out,
+                        const float* ref, int ref_stride, float* ref_sumsq_out, void* stream);
 
 /*
  * se_masked_sumsq_f32 -- utils.py:26-29 numerator: sums[b] = sum_{n < lengths[b]} x[b,n]^2  (sums zeroed inside).
@@ -200,6 +203,11 @@ int se_head_linear_dx_f32(const float* feats, const float* linears, const float*
  */
 int se_l1_masked_f32(const float* log_pred, const float* linear_tar, const int64_t* frame_lengths,
                      int B, int F, int K, float eps, double* sums, float* grad, void* stream);
+/* The same criterion as ONE launch with nothing in front or behind (objective.py:103-117 is one call): `lengths` are frame counts (len_div == 0) or
+ * WAVEFORM lengths with frames = lengths / len_div + 1 (runner.py:455); `scratch3` is a persistent device double[3] that is all zero on entry and
+ * left all zero on exit (the last workgroup to arrive publishes and clears); sums_out double[2] = {sum, count}, loss_out float[1] = sum / count. */
+int se_l1_masked_loss_f32(const float* log_pred, const float* linear_tar, const int64_t* lengths, int len_div, int B, int F, int K, float eps,
+                          double* scratch3, double* sums_out, float* loss_out, float* grad, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Encoder: S3PRL TRANSFORMER (rows B1-B3) + TransformerSpecPredictionHead (row B4), bf16 MFMA.
@@ -253,6 +261,11 @@ int se_encoder_fwd_bf16(const se_encoder* enc, const float* feats, const int32_t
 int se_spechead_fwd_bf16(const se_encoder* enc, const float* hidden, int B, int T, int log_target, int act, float eps,
                          float* predicted, float* log_predicted, float* raw,
                          void* workspace, size_t workspace_bytes, void* stream);
+/* The same with the caller's word that `hidden` is exactly what the last se_encoder_fwd_bf16 on this `workspace` returned (same B, T, untouched since):
+ * that call's final launch left the bf16 copy of the hidden states in the workspace, so the fp32 -> bf16 conversion pass is skipped (x_bf_valid != 0). */
+int se_spechead_fwd2_bf16(const se_encoder* enc, const float* hidden, int B, int T, int log_target, int act, float eps,
+                          float* predicted, float* log_predicted, float* raw,
+                          void* workspace, size_t workspace_bytes, int x_bf_valid, void* stream);
 
 /* frame validity: lengths[b] = #frames whose feature sum != 0 (S3PRL process_input_data). feats (B,T,D). */
 int se_valid_lengths_i32(const float* feats, int B, int T, int D, int32_t* lengths, void* stream);

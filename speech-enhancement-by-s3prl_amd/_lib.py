@@ -60,7 +60,7 @@ SIGNATURES = {
     'se_stft_f32': (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
     'se_stft2_f32': (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P]),
     'se_stft_tphase_f32': (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P, _P, _P, _P]),
-    'se_istft_tphase_f32': (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, c_int, _P, _P, _P]),
+    'se_istft_tphase_f32': (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, c_int, _P, _P, _P, c_int, _P, _P]),
     'se_features_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int]),
     'se_features_f32': (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P, _P, c_size_t, _P]),
     'se_istft_f32': (c_int, [_P, _P, _P, c_int, c_int, c_float, _P, c_int, _P, _P, _P]),
@@ -73,11 +73,13 @@ SIGNATURES = {
     'se_head_dx_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int]),
     'se_head_linear_dx_f32': (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P, _P, c_size_t, _P]),
     'se_l1_masked_f32': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_float, _P, _P, _P]),
+    'se_l1_masked_loss_f32': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P, _P, _P]),
     'se_encoder_create': (c_int, [POINTER(EncoderConfig), POINTER(EncoderWeights), POINTER(_P)]),
     'se_encoder_destroy': (None, [_P]),
     'se_encoder_workspace_bytes': (c_size_t, [_P, c_int, c_int]),
     'se_encoder_fwd_bf16': (c_int, [_P, _P, _P, c_int, c_int, _P, _P, c_size_t, _P]),
     'se_spechead_fwd_bf16': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P, _P, c_size_t, _P]),
+    'se_spechead_fwd2_bf16': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P, _P, c_size_t, c_int, _P]),
     'se_valid_lengths_i32': (c_int, [_P, c_int, c_int, c_int, _P, _P]),
     'se_gemm_bf16': (c_int, [_P, c_int, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, _P, _P, c_int, _P]),
     'se_gemm_res_ln_bf16': (c_int, [_P, c_int, _P, c_int, _P, _P, _P, _P, c_float, c_int, c_int, c_int, _P, _P, _P]),

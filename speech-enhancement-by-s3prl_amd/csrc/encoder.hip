@@ -635,7 +635,7 @@ extern "C" int se_encoder_fwd_bf16(const se_encoder* enc, const float* feats, co
     if ((rc = se_gemm_bf16(w.x_bf, H, y.ff1_w, H, y.ff1_b, nullptr, M, I, H, SE_ACT_GELU, w.h, nullptr, I, stream))) return rc;
     if (fused) {      // the last layer leaves the stream as the fp32 `hidden` the caller asked for
       float* of = (i == L - 1) ? hidden : nullptr;
-      uint16_t* ob = (i == L - 1) ? nullptr : w.x_bf;
+      uint16_t* ob = w.x_bf;      // the last layer writes it too (next to the fp32 `hidden`): the spec head's operand, se_spechead_fwd2_bf16(x_bf_valid = 1)
       uint8_t* ol = (i == L - 1) ? nullptr : w.lo;
       // 256 x 384 tiles with the LayerNorm statistics exchanged between the two column halves (gemm8.hip) where it applies, else 128 x 768
       rc = se::launch_gemm8_res24_ln(w.h, I, y.ff2_w, I, y.ff2_b, w.x_bf, w.lo, y.oln_w, y.oln_b, enc->cfg.ln_eps, M, H, I, of, ob, ol, w.g8, st);
@@ -647,11 +647,11 @@ extern "C" int se_encoder_fwd_bf16(const se_encoder* enc, const float* feats, co
         // serving-size batch: split the K = 3072 reduction four ways (4 x the workgroups), finish in the LayerNorm pass
         if ((rc = se_gemm2_splitk_launch(w.h, I, y.ff2_w, I, M, H, I / kSplitK, kSplitK, w.slabs, stream))) return rc;
         hipLaunchKernelGGL((se::ln_reduce_kernel<3>), dim3((M + 3) / 4), dim3(256), 0, st, w.slabs, kSplitK, Mz * H, y.ff2_b, w.x_f32, y.oln_w, y.oln_b, M,
-                           enc->cfg.ln_eps, xo, (i == L - 1) ? nullptr : w.x_bf);
+                           enc->cfg.ln_eps, xo, w.x_bf);
         SE_LAUNCH_CHECK();
       } else {
         if ((rc = se_gemm_bf16(w.h, I, y.ff2_w, I, y.ff2_b, w.x_f32, M, H, I, SE_ACT_IDENTITY, nullptr, w.tmp, H, stream))) return rc;
-        if ((rc = se::launch_layernorm(w.tmp, nullptr, 1, y.oln_w, y.oln_b, M, H, enc->cfg.ln_eps, xo, (i == L - 1) ? nullptr : w.x_bf, st))) return rc;
+        if ((rc = se::launch_layernorm(w.tmp, nullptr, 1, y.oln_w, y.oln_b, M, H, enc->cfg.ln_eps, xo, w.x_bf, st))) return rc;
       }
     }
   }
@@ -661,6 +661,12 @@ extern "C" int se_encoder_fwd_bf16(const se_encoder* enc, const float* feats, co
 extern "C" int se_spechead_fwd_bf16(const se_encoder* enc, const float* hidden, int B, int T, int log_target, int act, float eps,
                                     float* predicted, float* log_predicted, float* raw,
                                     void* workspace, size_t workspace_bytes, void* stream) {
+  return se_spechead_fwd2_bf16(enc, hidden, B, T, log_target, act, eps, predicted, log_predicted, raw, workspace, workspace_bytes, 0, stream);
+}
+
+extern "C" int se_spechead_fwd2_bf16(const se_encoder* enc, const float* hidden, int B, int T, int log_target, int act, float eps,
+                                     float* predicted, float* log_predicted, float* raw,
+                                     void* workspace, size_t workspace_bytes, int x_bf_valid, void* stream) {
   SE_REQUIRE(enc && hidden && workspace && (predicted || log_predicted || raw), "se_spechead_fwd_bf16: null argument");
   SE_REQUIRE(enc->cfg.spec_out > 0, "se_spechead_fwd_bf16: encoder was created without a spec head");
   SE_REQUIRE(B > 0 && T > 0, "se_spechead_fwd_bf16: bad shape");
@@ -671,7 +677,7 @@ extern "C" int se_spechead_fwd_bf16(const se_encoder* enc, const float* hidden, 
   hipStream_t st = se::as_stream(stream);
   Ws w = carve(enc, Mz, reinterpret_cast<char*>(workspace));
   int rc;
-  {
+  if (!x_bf_valid) {      // else: `hidden` is the output of the last se_encoder_fwd_bf16 on this workspace, whose final launch left its bf16 copy in x_bf
     const int grid = (int)std::min<size_t>((Mz * (H / 4) + 255) / 256, 8192);
     hipLaunchKernelGGL(se::cast_pad_kernel, dim3(grid), dim3(256), 0, st, hidden, Mz, H, H, w.x_bf);
     SE_LAUNCH_CHECK();

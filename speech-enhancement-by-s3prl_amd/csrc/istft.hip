@@ -29,6 +29,7 @@ constexpr int kISpan = kIHB * kHop;      // 4320 samples
 constexpr int kIThreads = 256;
 constexpr int kIPairs = 101;             // bin pairs (k, 200 - k) per frame
 constexpr int kIPairIters = (kIFR * kIPairs + kIThreads - 1) / kIThreads;   // 12
+constexpr int kIRefIters = (kISpan / 4 + kIThreads - 1) / kIThreads;         // 5 output quads per thread
 constexpr float kIScale = 1.0f / 400.0f; // 1/200 (inverse transform) x 1/2 (E, O of the fold are kept doubled)
 
 // ENC = 1: `phase` holds the encoded words of se_stft_tphase_f32 (stft.hip: encode_phase): (cos, sin) = (+-(1 - t^2), 2 t) / (1 + t^2)
@@ -36,12 +37,13 @@ template <int SQRT, int ENC>
 __global__ __launch_bounds__(kIThreads) void istft_kernel(
     const float* __restrict__ power, const float* __restrict__ phase, int F, float inv_lp,
     const float* __restrict__ window, const float2* __restrict__ tw400g, const float2* __restrict__ tw200g,
-    float* __restrict__ wav, int wav_stride, const int64_t* __restrict__ lengths, float* __restrict__ sumsq) {
+    float* __restrict__ wav, int wav_stride, const int64_t* __restrict__ lengths, float* __restrict__ sumsq,
+    const float* __restrict__ ref, int ref_stride, float* __restrict__ ref_sumsq) {
   __shared__ __attribute__((aligned(16))) float2 Y[kIFR * kHalf + 1];   // +1: the dump slot of the k = 0 pair's second write
   __shared__ float2 tw[kHalf];            // (cos, sin)(2 pi k / 400), k < 200: fold twiddles
   __shared__ float2 tw2[kHalf];           // (cos, sin)(2 pi t / 200): pass-A twiddles W200^(j q), j q <= 168
   __shared__ __attribute__((aligned(16))) float win[kNfft];             // window / 400
-  __shared__ float red[kIThreads / 64];
+  __shared__ float red[2][kIThreads / 64];
 
   const int tid = threadIdx.x;
   const int b = blockIdx.y;
@@ -52,12 +54,36 @@ __global__ __launch_bounds__(kIThreads) void istft_kernel(
   const int fhi = min(fbase + kIFR, F);               // exclusive
   const int nfr = fhi - flo;
 
+  float rq[kIRefIters][4];
+  float rtail = 0.f;
+#pragma unroll
+  for (int i = 0; i < kIRefIters; ++i) rq[i][0] = rq[i][1] = rq[i][2] = rq[i][3] = 0.f;
   // ---- tables -> LDS first (their loads lead the queue), then every spectrum load of the thread back to back
   {
     const float2 twv = tw400g[min(tid, kHalf - 1)], tw2v = tw200g[min(tid, kHalf - 1)];
     const float wv0 = window[tid], wv1 = window[min(tid + kIThreads, kNfft - 1)];
     const size_t gbase = ((size_t)b * F + flo) * kBins;
     float p0[kIPairIters], h0[kIPairIters], p1[kIPairIters], h1[kIPairIters];
+    // the reference waveform of the level normalisation (runner.py:570: wav_tar): its masked square sum rides along (D2), loaded up front
+    // with everything else -- a load inside the output loop would drain that loop's stores
+    if (ref) {
+      const float* rrow = ref + (size_t)b * ref_stride;
+      const int rlen = lengths ? (int)min((int64_t)n_out, lengths[b]) : 0;
+#pragma unroll
+      for (int i = 0; i < kIRefIters; ++i) {
+        const int n = o0 + 4 * tid + 4 * kIThreads * i;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rq[i][e] = (4 * tid + 4 * kIThreads * i < kISpan && n + e < rlen) ? rrow[n + e] : 0.f;
+      }
+      // the mask of utils.py:26-46 runs to lengths[b], which may exceed the hop (F - 1) samples the inverse transform returns (T not a multiple of
+      // the hop: the output row is zero-padded there, the reference is not): the row's last workgroup takes that tail (< 160 samples)
+      if (blockIdx.x == gridDim.x - 1 && lengths) {
+        const int rfull = (int)min((int64_t)min(wav_stride, ref_stride), lengths[b]);
+        float t = 0.f;
+        for (int n = n_out + tid; n < rfull; n += kIThreads) { const float v = rrow[n]; t = fmaf(v, v, t); }
+        rtail = t;
+      }
+    }
 #pragma unroll
     for (int r = 0; r < kIPairIters; ++r) {
       const int it = tid + kIThreads * r;
@@ -188,11 +214,20 @@ __global__ __launch_bounds__(kIThreads) void istft_kernel(
     for (int n = n_out + tid; n < wav_stride; n += kIThreads) wav[(size_t)b * wav_stride + n] = 0.f;
 
   if (sumsq) {
+    float sr = rtail;
+    if (ref_sumsq) {
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) ss += __shfl_down(ss, off);
-    if ((tid & 63) == 0) red[tid >> 6] = ss;
+      for (int i = 0; i < kIRefIters; ++i) sr += rq[i][0] * rq[i][0] + rq[i][1] * rq[i][1] + rq[i][2] * rq[i][2] + rq[i][3] * rq[i][3];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      ss += __shfl_down(ss, off);
+      sr += __shfl_down(sr, off);
+    }
+    if ((tid & 63) == 0) { red[0][tid >> 6] = ss; red[1][tid >> 6] = sr; }
     __syncthreads();
-    if (tid == 0) atomicAdd(&sumsq[b], red[0] + red[1] + red[2] + red[3]);
+    if (tid == 0) atomicAdd(&sumsq[b], red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+    if (tid == 64 && ref_sumsq) atomicAdd(&ref_sumsq[b], red[1][0] + red[1][1] + red[1][2] + red[1][3]);
   }
 }
 
@@ -269,10 +304,10 @@ extern "C" int se_istft_f32(const se_plan* plan, const float* power, const float
   se::ProfScope prof(se::kProfIstft, (double)B * (8.0 * F * se::kBins + 4.0 * n_out), st);
   if (linear_power == 2.0f)
     hipLaunchKernelGGL((se::istft_kernel<1, 0>), grid, dim3(se::kIThreads), 0, st, power, phase, F, 0.5f, plan->d_window, plan->d_tw400, plan->d_tw200,
-                       wav_out, wav_stride, lengths, sumsq_out);
+                       wav_out, wav_stride, lengths, sumsq_out, nullptr, 0, nullptr);
   else
     hipLaunchKernelGGL((se::istft_kernel<0, 0>), grid, dim3(se::kIThreads), 0, st, power, phase, F, 1.0f / linear_power, plan->d_window, plan->d_tw400,
-                       plan->d_tw200, wav_out, wav_stride, lengths, sumsq_out);
+                       plan->d_tw200, wav_out, wav_stride, lengths, sumsq_out, nullptr, 0, nullptr);
   SE_LAUNCH_CHECK();
   return SE_OK;
 }
@@ -282,20 +317,34 @@ extern "C" int se_istft2p_tphase_f32(const se_plan* plan, const float* power, co
                                      float* wav_out, int wav_stride, const int64_t* lengths, float* sumsq_out, void* stream);
 
 extern "C" int se_istft_tphase_f32(const se_plan* plan, const float* power, const unsigned* tphase, int B, int F, int log_input,
-                                   float* wav_out, int wav_stride, const int64_t* lengths, float* sumsq_out, void* stream) {
+                                   float* wav_out, int wav_stride, const int64_t* lengths, float* sumsq_out,
+                                   const float* ref, int ref_stride, float* ref_sumsq_out, void* stream) {
   SE_REQUIRE(plan && power && tphase && wav_out, "se_istft_tphase_f32: null argument");
   SE_REQUIRE(B > 0 && B <= 65535 && F >= 2, "se_istft_tphase_f32: bad B=%d F=%d", B, F);
   const int n_out = se::kHop * (F - 1);
   SE_REQUIRE(wav_stride >= n_out, "se_istft_tphase_f32: wav_stride=%d < %d output samples", wav_stride, n_out);
   SE_REQUIRE(sumsq_out == nullptr || lengths != nullptr, "se_istft_tphase_f32: sumsq_out needs lengths");
+  SE_REQUIRE(ref_sumsq_out == nullptr || (ref && sumsq_out && ref_stride >= n_out), "se_istft_tphase_f32: ref_sumsq_out needs ref (row stride >= %d) and sumsq_out", n_out);
   static const bool use2 = getenv("SE_AMD_STFT2") != nullptr;
-  if (use2 || log_input) return se_istft2p_tphase_f32(plan, power, tphase, B, F, log_input, wav_out, wav_stride, lengths, sumsq_out, stream);
   hipStream_t st = se::as_stream(stream);
-  if (sumsq_out) { const int zrc_ = se::zero_async(sumsq_out, sizeof(float) * B, st); if (zrc_) return zrc_; }
+  if (use2 || log_input) {
+    int rc = se_istft2p_tphase_f32(plan, power, tphase, B, F, log_input, wav_out, wav_stride, lengths, sumsq_out, stream);
+    if (rc == SE_OK && ref_sumsq_out) rc = se_masked_sumsq_f32(ref, B, n_out, ref_stride, lengths, ref_sumsq_out, stream);
+    return rc;
+  }
+  if (sumsq_out) {      // one clearing launch for both accumulators when they sit side by side
+    int zrc_;
+    if (ref_sumsq_out == sumsq_out + B) zrc_ = se::zero_async(sumsq_out, sizeof(float) * 2 * B, st);
+    else {
+      zrc_ = se::zero_async(sumsq_out, sizeof(float) * B, st);
+      if (!zrc_ && ref_sumsq_out) zrc_ = se::zero_async(ref_sumsq_out, sizeof(float) * B, st);
+    }
+    if (zrc_) return zrc_;
+  }
   dim3 grid((n_out + se::kISpan - 1) / se::kISpan, B);
   se::ProfScope prof(se::kProfIstft, (double)B * (8.0 * F * se::kBins + 4.0 * n_out), st);
   hipLaunchKernelGGL((se::istft_kernel<1, 1>), grid, dim3(se::kIThreads), 0, st, power, reinterpret_cast<const float*>(tphase), F, 0.5f, plan->d_window,
-                     plan->d_tw400, plan->d_tw200, wav_out, wav_stride, lengths, sumsq_out);
+                     plan->d_tw400, plan->d_tw200, wav_out, wav_stride, lengths, sumsq_out, ref_sumsq_out ? ref : nullptr, ref_stride, ref_sumsq_out);
   SE_LAUNCH_CHECK();
   return SE_OK;
 }

@@ -29,7 +29,7 @@ def masked_sumsq(x, lengths):
     return sums
 
 
-def masked_normalize_decibel(audio, target, lengths, eps=1e-8, audio_sumsq=None, inplace=False):
+def masked_normalize_decibel(audio, target, lengths, eps=1e-8, audio_sumsq=None, inplace=False, ref_sumsq=None):
     """utils.py:31-46 with the mask given as lengths (the reference builds it from lengths, runner.py:269).
     target: number (fixed dB) or reference audio (B, T)."""
     lib = _lib.load()
@@ -40,21 +40,22 @@ def masked_normalize_decibel(audio, target, lengths, eps=1e-8, audio_sumsq=None,
     lengths = lengths.to(device=audio.device, dtype=torch.int64).contiguous()
     if audio_sumsq is None:
         audio_sumsq = masked_sumsq(audio, lengths)
-    ref_sumsq, fixed = None, 0.0
+    fixed = 0.0
     if isinstance(target, (int, float)):
-        fixed = float(target)
+        fixed, ref_sumsq = float(target), None
     elif isinstance(target, torch.Tensor) and target.dim() > 1:
-        ref = target
-        if ref.dtype != torch.float32 or ref.stride(1) != 1:
-            ref = ref.contiguous().float()
-        if ref.shape[1] < T:
-            raise _lib.SEError('reference audio shorter than the audio to normalise')
-        if not ref.is_cuda:
-            raise _lib.SEError('reference audio must live on the GPU (no CPU fallback)')
-        ref_sumsq = torch.empty(B, device=audio.device, dtype=torch.float32)
-        # rows may be strided (wavs[:, channel_tar] of a (B, C, T) batch is read in place, runner.py:561,570)
-        _lib.check(lib.se_masked_sumsq_f32(ref.data_ptr(), B, T, ref.stride(0), _lib.ptr(lengths), _lib.ptr(ref_sumsq),
-                                           _lib.stream()), 'se_masked_sumsq_f32')
+        if ref_sumsq is None:          # else: already summed by the iSTFT launch (preprocessor._istft_tphase)
+            ref = target
+            if ref.dtype != torch.float32 or ref.stride(1) != 1:
+                ref = ref.contiguous().float()
+            if ref.shape[1] < T:
+                raise _lib.SEError('reference audio shorter than the audio to normalise')
+            if not ref.is_cuda:
+                raise _lib.SEError('reference audio must live on the GPU (no CPU fallback)')
+            ref_sumsq = torch.empty(B, device=audio.device, dtype=torch.float32)
+            # rows may be strided (wavs[:, channel_tar] of a (B, C, T) batch is read in place, runner.py:561,570)
+            _lib.check(lib.se_masked_sumsq_f32(ref.data_ptr(), B, T, ref.stride(0), _lib.ptr(lengths), _lib.ptr(ref_sumsq),
+                                               _lib.stream()), 'se_masked_sumsq_f32')
     else:
         raise NotImplementedError('per-utterance dB tensor targets are unused by the reference')
     _lib.check(lib.se_dbnorm_f32(_lib.ptr(audio), B, T, T, _lib.ptr(lengths), _lib.ptr(audio_sumsq), _lib.ptr(ref_sumsq),
@@ -67,5 +68,9 @@ def decode_wav(preprocessor, linear, phase, lengths, target_level=-25, max_len=N
     `max_len` = max(lengths) if known on the host (avoids the sync of runner.py:268)."""
     if max_len is None:
         max_len = int(lengths.max().item())
+    ref = target_level if isinstance(target_level, torch.Tensor) and target_level.dim() == 2 else None
+    if ref is not None:
+        wav, sumsq, ref_sumsq = preprocessor.istft_with_sumsq(linear, phase, lengths=lengths, out_len=max_len, ref=ref)
+        return masked_normalize_decibel(wav, target_level, lengths, audio_sumsq=sumsq, inplace=True, ref_sumsq=ref_sumsq)
     wav, sumsq = preprocessor.istft_with_sumsq(linear, phase, lengths=lengths, out_len=max_len)
     return masked_normalize_decibel(wav, target_level, lengths, audio_sumsq=sumsq, inplace=True)

@@ -10,17 +10,38 @@ import torch.nn as nn
 from . import _lib
 
 
+_L1_SCRATCH = {}      # device -> persistent zeroed double[3] {sum, count, ticket} of se_l1_masked_loss_f32 (self-cleaning)
+
+
+def _l1_scratch(dev):
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(dev).cuda_stream)      # one per stream: calls on two streams may overlap
+    t = _L1_SCRATCH.get(key)
+    if t is None:
+        t = _L1_SCRATCH[key] = torch.zeros(3, device=dev, dtype=torch.float64)
+    return t
+
+
 class _L1Fn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, log_predicted, linear_tar, frame_lengths, eps, reduce_fn):
+    def forward(ctx, log_predicted, linear_tar, lengths, len_div, eps, reduce_fn):
+        """lengths: frame counts (len_div == 0) or waveform lengths (frames = lengths // len_div + 1, runner.py:455)"""
         lib = _lib.load()
         lp = log_predicted.contiguous().float()
         tar = linear_tar.contiguous().float()
         B, F, K = lp.shape
-        lens = frame_lengths.to(device=lp.device, dtype=torch.int64).contiguous()
+        lens = lengths.to(device=lp.device, dtype=torch.int64).contiguous()
         sums = torch.empty(2, device=lp.device, dtype=torch.float64)
         need_grad = log_predicted.requires_grad
         grad = torch.empty_like(lp) if need_grad else None
+        if reduce_fn is None:
+            # one launch: sums, count AND the loss come out of the kernel (last-arriving workgroup), no zeroing launch, no division kernels
+            loss = torch.empty((), device=lp.device, dtype=torch.float32)
+            _lib.check(lib.se_l1_masked_loss_f32(_lib.ptr(lp), _lib.ptr(tar), _lib.ptr(lens), int(len_div), B, F, K, float(eps), _lib.ptr(_l1_scratch(lp.device)),
+                                                 _lib.ptr(sums), _lib.ptr(loss), _lib.ptr(grad), _lib.stream()), 'se_l1_masked_loss_f32')
+            ctx.save_for_backward(grad if grad is not None else torch.empty(0), sums)
+            return loss
+        if len_div:
+            lens = lens // int(len_div) + 1
         _lib.check(lib.se_l1_masked_f32(_lib.ptr(lp), _lib.ptr(tar), _lib.ptr(lens), B, F, K, float(eps), _lib.ptr(sums),
                                         _lib.ptr(grad), _lib.stream()), 'se_l1_masked_f32')
         if reduce_fn is not None:
@@ -31,22 +52,26 @@ class _L1Fn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         sign, sums = ctx.saved_tensors
-        return sign * (g / sums[1].float()), None, None, None, None
+        return sign * (g / sums[1].float()), None, None, None, None, None
 
 
 class L1(nn.Module):
-    """objective.py:103-117.  `stft_length_masks` (B, T') is what the runner passes; the kernel takes the
-    equivalent per-utterance frame counts, so either `stft_lengths` (preferred, no extra pass) or the mask."""
+    """objective.py:103-117.  `stft_length_masks` (B, T') is what the runner passes; the kernel takes the equivalent per-utterance frame
+    counts, so either `stft_lengths` (no extra pass), the mask, or -- cheapest, nothing to compute in front -- the waveform `wav_lengths`
+    with `hop` (frames = wav_lengths // hop + 1, runner.py:455)."""
 
     def __init__(self, eps=1e-10, **kwargs):
         super().__init__()
         self.eps = eps
         self.reduce_fn = None   # set by dist.DataParallelStep for the global masked mean
 
-    def forward(self, log_predicted, linear_tar, stft_length_masks=None, stft_lengths=None, **kwargs):
+    def forward(self, log_predicted, linear_tar, stft_length_masks=None, stft_lengths=None, wav_lengths=None, hop=None, **kwargs):
+        if wav_lengths is not None and hop:
+            loss = _L1Fn.apply(log_predicted, linear_tar, wav_lengths, int(hop), self.eps, self.reduce_fn)
+            return loss, {}
         if stft_lengths is None:
             stft_lengths = stft_length_masks.sum(dim=-1)
-        loss = _L1Fn.apply(log_predicted, linear_tar, stft_lengths, self.eps, self.reduce_fn)
+        loss = _L1Fn.apply(log_predicted, linear_tar, stft_lengths, 0, self.eps, self.reduce_fn)
         return loss, {}
 
 

@@ -123,16 +123,20 @@ class UpstreamEnhanceStep:
         predicted, res = self.up.SpecHead(hidden)
         wav_tar = wavs[:, self.pre.channel_tar, :]
         wav_pred = decode.decode_wav(self.pre, predicted, ph_inp, lengths, wav_tar, max_len=max_len)
-        stft_lengths = lengths // self.pre._win_args['hop_length'] + 1
+        hop = self.pre._win_args['hop_length']
+        if isinstance(self.criterion, L1):       # frame counts derived inside the kernel (runner.py:455): no element-wise launches in front of it
+            lens_kw = {'wav_lengths': lengths, 'hop': hop}
+        else:
+            lens_kw = {'stft_lengths': lengths // hop + 1}
         if want_sums:
             sums = []
             self.criterion.reduce_fn = lambda t: (sums.append(t) or t)
             try:
-                self.criterion(log_predicted=res['log_predicted'], linear_tar=lin_tar, stft_lengths=stft_lengths)
+                self.criterion(log_predicted=res['log_predicted'], linear_tar=lin_tar, **lens_kw)
             finally:
                 self.criterion.reduce_fn = None
             return wav_pred, sums[0], predicted
-        loss, _ = self.criterion(log_predicted=res['log_predicted'], linear_tar=lin_tar, stft_lengths=stft_lengths)
+        loss, _ = self.criterion(log_predicted=res['log_predicted'], linear_tar=lin_tar, **lens_kw)
         return wav_pred, loss, predicted
 
     @torch.no_grad()

@@ -350,12 +350,13 @@ class OnlinePreprocessor(nn.Module):
         wav, _ = self.istft_with_sumsq(linears, phases, linear_power=linear_power)
         return wav
 
-    def istft_with_sumsq(self, linears, phases, linear_power=2, lengths=None, out_len=None):
-        """se_istft_f32; with `lengths` also returns the masked sum of squares (fused, for the dB normalisation)."""
+    def istft_with_sumsq(self, linears, phases, linear_power=2, lengths=None, out_len=None, ref=None):
+        """se_istft_f32; with `lengths` also returns the masked sum of squares (fused, for the dB normalisation).  With `ref` (the reference
+        waveform of that normalisation) returns (wav, sumsq, ref_sumsq or None): the encoded-phase kernel sums it in the same launch."""
         linears, home = self._stage(linears)
         if (type(phases) is LazyPhase and phases._tphase is not None and phases._value is None and float(linear_power) == 2.0 and
                 phases._tphase.device == linears.device and home == linears.device):
-            return self._istft_tphase(linears, phases._tphase, lengths, out_len)
+            return self._istft_tphase(linears, phases._tphase, lengths, out_len, ref=ref)
         phases = phases.to(linears.device)
         lib = _lib.load()
         lead = linears.shape[:-2]
@@ -372,10 +373,13 @@ class OnlinePreprocessor(nn.Module):
             sumsq = torch.empty(B, device=lin.device, dtype=torch.float32)
         _lib.check(lib.se_istft_f32(self._plan(lin.device), _lib.ptr(lin), _lib.ptr(ph), B, F, float(linear_power),
                                     _lib.ptr(wav), stride, _lib.ptr(lengths), _lib.ptr(sumsq), _lib.stream()), 'se_istft_f32')
+        if ref is not None:
+            return wav.reshape(*lead, stride).to(home), (None if sumsq is None else sumsq.to(home)), None
         return wav.reshape(*lead, stride).to(home), (None if sumsq is None else sumsq.to(home))
 
-    def _istft_tphase(self, linears, tphase, lengths, out_len, log_input=False):
-        """se_istft_tphase_f32: X' = sqrt(linears) * (cos, sin)(tphase) -> waveform (+ the masked square sum when `lengths` is given)."""
+    def _istft_tphase(self, linears, tphase, lengths, out_len, log_input=False, ref=None):
+        """se_istft_tphase_f32: X' = sqrt(linears) * (cos, sin)(tphase) -> waveform (+ the masked square sum when `lengths` is given; + the masked
+        square sum of `ref` (B, >= out_len), the reference waveform of the level normalisation, in the same launch).  Returns (wav, sumsq[, ref_sumsq])."""
         lib = _lib.load()
         lead = linears.shape[:-2]
         F, K = linears.shape[-2:]
@@ -386,13 +390,20 @@ class OnlinePreprocessor(nn.Module):
         n_out = self._win_args['hop_length'] * (F - 1)
         stride = n_out if out_len is None else max(int(out_len), n_out)
         wav = torch.empty(B, stride, device=lin.device, dtype=torch.float32)
-        sumsq = None
+        sums = None
+        use_ref = (ref is not None and lengths is not None and ref.dim() == 2 and ref.shape[0] == B and ref.dtype == torch.float32 and ref.is_cuda and
+                   ref.stride(1) == 1 and ref.shape[1] >= stride)
         if lengths is not None:
             lengths = lengths.to(device=lin.device, dtype=torch.int64).contiguous()
-            sumsq = torch.empty(B, device=lin.device, dtype=torch.float32)
+            sums = torch.empty(2 if use_ref else 1, B, device=lin.device, dtype=torch.float32)       # [wav, ref] side by side: one clearing launch
         _lib.check(lib.se_istft_tphase_f32(self._plan(lin.device), _lib.ptr(lin), _lib.ptr(ph), B, F, int(bool(log_input)), _lib.ptr(wav), stride,
-                                           _lib.ptr(lengths), _lib.ptr(sumsq), _lib.stream()), 'se_istft_tphase_f32')
-        return wav.reshape(*lead, stride), sumsq
+                                           _lib.ptr(lengths), None if sums is None else sums[0].data_ptr(),
+                                           ref.data_ptr() if use_ref else None, int(ref.stride(0)) if use_ref else 0,
+                                           sums[1].data_ptr() if use_ref else None, _lib.stream()), 'se_istft_tphase_f32')
+        wav = wav.reshape(*lead, stride)
+        if ref is None:
+            return wav, (None if sums is None else sums[0])
+        return wav, (None if sums is None else sums[0]), (sums[1] if use_ref else None)
 
     # ---- attributes used by sampler.hist_scoring (sampler.py:226-228) -----------------------------------
     def _stft(self, wav2d, window=None):

@@ -476,7 +476,14 @@ class _Engine:
         hidden = torch.empty(B, T, model.config.hidden_size, device=feats.device, dtype=torch.float32)
         _lib.check(lib.se_encoder_fwd_bf16(h, _lib.ptr(feats), _lib.ptr(lengths), B, T, _lib.ptr(hidden), _lib.ptr(ws), n,
                                            _lib.stream()), 'se_encoder_fwd_bf16')
+        # the call's last launch left the bf16 copy of `hidden` in this workspace: the spec head that follows (model.py:164-165) can skip its
+        # conversion pass as long as it is handed exactly this tensor, unmodified, on the same workspace
+        self._last_hidden = (hidden.data_ptr(), hidden._version, B, T, ws.data_ptr())
         return hidden
+
+    def _hidden_is_cached(self, hidden, B, T, ws):
+        lh = getattr(self, '_last_hidden', None)
+        return int(lh is not None and lh == (hidden.data_ptr(), hidden._version, B, T, ws.data_ptr()))
 
     def spechead(self, head, model, hidden, mode='raw', log_target=False, act='ReLU', eps=1e-6):
         if self.precision == 'fp32':
@@ -492,13 +499,14 @@ class _Engine:
         dev = hidden.device
         if mode == 'raw':
             raw = torch.empty(B, T, N, device=dev, dtype=torch.float32)
-            _lib.check(lib.se_spechead_fwd_bf16(h, _lib.ptr(hidden), B, T, 0, 0, float(eps), None, None, _lib.ptr(raw), _lib.ptr(ws), n,
-                                                _lib.stream()), 'se_spechead_fwd_bf16')
+            _lib.check(lib.se_spechead_fwd2_bf16(h, _lib.ptr(hidden), B, T, 0, 0, float(eps), None, None, _lib.ptr(raw), _lib.ptr(ws), n,
+                                                 self._hidden_is_cached(hidden, B, T, ws), _lib.stream()), 'se_spechead_fwd2_bf16')
             return raw
         pred = torch.empty(B, T, N, device=dev, dtype=torch.float32)
         logp = torch.empty(B, T, N, device=dev, dtype=torch.float32)
-        _lib.check(lib.se_spechead_fwd_bf16(h, _lib.ptr(hidden), B, T, int(bool(log_target)), _lib.SE_ACT[act], float(eps),
-                                            _lib.ptr(pred), _lib.ptr(logp), None, _lib.ptr(ws), n, _lib.stream()), 'se_spechead_fwd_bf16')
+        _lib.check(lib.se_spechead_fwd2_bf16(h, _lib.ptr(hidden), B, T, int(bool(log_target)), _lib.SE_ACT[act], float(eps),
+                                             _lib.ptr(pred), _lib.ptr(logp), None, _lib.ptr(ws), n, self._hidden_is_cached(hidden, B, T, ws),
+                                             _lib.stream()), 'se_spechead_fwd2_bf16')
         return pred, logp
 
 

@@ -228,3 +228,25 @@ def test_bench_shape_default_dispatch_vs_oracle(gpu):
     bounded('bench_shape log_predicted', rel_l2(res['log_predicted'], rres['log_predicted']), 8e-3)
     per_utt = ((hidden.cpu() - ref).flatten(1).norm(dim=1) / ref.flatten(1).norm(dim=1)).max().item()
     bounded('bench_shape hidden worst utterance', per_utt, 6e-3)
+
+
+def test_spec_head_reuses_the_encoders_bf16_copy_only_for_the_untouched_tensor(gpu, small):
+    """se_spechead_fwd2_bf16(x_bf_valid): the spec head skips its fp32 -> bf16 pass when it is handed exactly the tensor the last encode returned
+    (model.py:164-165); a modified or different tensor takes the conversion pass and gives ITS result."""
+    from speech_enhancement_by_s3prl_amd import pipeline, synth
+    cfg, ckpt = small
+    up = pipeline.build_upstream(ckpt, gpu)
+    pre = pipeline.build_preprocessor(cfg, gpu)
+    lengths, wavs = synth.synth_batch(2, 16000)
+    feats = pre(wavs.to(gpu))[0]
+    hidden = up(feats)
+    eng = up._engine
+    assert eng._last_hidden[0] == hidden.data_ptr() and eng._last_hidden[1] == hidden._version
+    p_cached, r_cached = up.SpecHead(hidden)
+    p_fresh, r_fresh = up.SpecHead(hidden.clone())             # another tensor: conversion pass
+    assert torch.equal(p_cached, p_fresh) and torch.equal(r_cached['log_predicted'], r_fresh['log_predicted'])
+    hidden2 = up(feats)
+    hidden2.mul_(0.5)                                          # version bump: the cached copy is stale
+    p_mod, _ = up.SpecHead(hidden2)
+    p_ref, _ = up.SpecHead((hidden * 0.5).contiguous())
+    assert torch.equal(p_mod, p_ref) and not torch.equal(p_mod, p_cached)
