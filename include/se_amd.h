@@ -204,8 +204,10 @@ int se_head_linear_dx_f32(const float* feats, const float* linears, const float*
 int se_l1_masked_f32(const float* log_pred, const float* linear_tar, const int64_t* frame_lengths,
                      int B, int F, int K, float eps, double* sums, float* grad, void* stream);
 /* The same criterion as ONE launch with nothing in front or behind (objective.py:103-117 is one call): `lengths` are frame counts (len_div == 0) or
- * WAVEFORM lengths with frames = lengths / len_div + 1 (runner.py:455); `scratch3` is a persistent device double[3] that is all zero on entry and
- * left all zero on exit (the last workgroup to arrive publishes and clears); sums_out double[2] = {sum, count}, loss_out float[1] = sum / count. */
+ * WAVEFORM lengths with frames = lengths / len_div + 1 (runner.py:455); `scratch3` is a persistent device buffer of se_l1_scratch_doubles(B) doubles
+ * whose first word (the arrival ticket) is zero on entry and left zero on exit (the last workgroup to arrive folds the per-workgroup partial sums,
+ * publishes and clears); sums_out double[2] = {sum, count}, loss_out float[1] = sum / count. */
+size_t se_l1_scratch_doubles(int B);
 int se_l1_masked_loss_f32(const float* log_pred, const float* linear_tar, const int64_t* lengths, int len_div, int B, int F, int K, float eps,
                           double* scratch3, double* sums_out, float* loss_out, float* grad, void* stream);
 

@@ -73,6 +73,7 @@ SIGNATURES = {
     'se_head_dx_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int]),
     'se_head_linear_dx_f32': (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P, _P, c_size_t, _P]),
     'se_l1_masked_f32': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_float, _P, _P, _P]),
+    'se_l1_scratch_doubles': (c_size_t, [c_int]),
     'se_l1_masked_loss_f32': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P, _P, _P]),
     'se_encoder_create': (c_int, [POINTER(EncoderConfig), POINTER(EncoderWeights), POINTER(_P)]),
     'se_encoder_destroy': (None, [_P]),

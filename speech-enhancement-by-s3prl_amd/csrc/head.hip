@@ -27,45 +27,64 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 }
 
 // stats[(b*D + d)*2] = mean over time, [..+1] = 1 / (unbiased std + eps)
+// One pass (round 3; the first version read the features twice): per column fp64 sums of x and x^2 -- the products of two fp32 values are exact in
+// fp64 and 1001 of them lose ~1e-13 relative, so the variance equals the two-pass fp32 result to well below fp32 resolution -- four rows in
+// flight per thread, 4 row phases per workgroup.
 __global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__ feats, int F, int D, float eps,
                                                        float* __restrict__ stats) {
-  __shared__ float red[4][64];
+  __shared__ double red[2][4][64];
   const int b = blockIdx.y, d = blockIdx.x * 64 + (threadIdx.x & 63), ph = threadIdx.x >> 6;
   const bool ok = d < D;
   const float* base = feats + (size_t)b * F * D + d;
-  float s = 0.f;
-  if (ok)
-    for (int t = ph; t < F; t += 4) s += base[(size_t)t * D];
-  red[ph][threadIdx.x & 63] = s;
-  __syncthreads();
-  const float mean = (red[0][threadIdx.x & 63] + red[1][threadIdx.x & 63] + red[2][threadIdx.x & 63] + red[3][threadIdx.x & 63]) / (float)F;
-  __syncthreads();
-  float q = 0.f;
-  if (ok)
-    for (int t = ph; t < F; t += 4) {
-      const float c = base[(size_t)t * D] - mean;
-      q = fmaf(c, c, q);
+  double s = 0.0, q = 0.0;
+  if (ok) {
+    int t = ph;
+    for (; t + 12 < F; t += 16) {
+      const float v0 = base[(size_t)t * D], v1 = base[(size_t)(t + 4) * D], v2 = base[(size_t)(t + 8) * D], v3 = base[(size_t)(t + 12) * D];
+      s += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
+      q += ((double)v0 * v0 + (double)v1 * v1) + ((double)v2 * v2 + (double)v3 * v3);
     }
-  red[ph][threadIdx.x & 63] = q;
+    for (; t < F; t += 4) {
+      const float v = base[(size_t)t * D];
+      s += (double)v;
+      q += (double)v * v;
+    }
+  }
+  red[0][ph][threadIdx.x & 63] = s;
+  red[1][ph][threadIdx.x & 63] = q;
   __syncthreads();
   if (ph == 0 && ok) {
-    const float var = (red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]) / (float)(F - 1);
-    stats[((size_t)b * D + d) * 2] = mean;
-    stats[((size_t)b * D + d) * 2 + 1] = 1.0f / (sqrtf(var) + eps);
+    const int c = threadIdx.x;
+    const double S = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
+    const double Q = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
+    const double mean = S / (double)F;
+    const double var = fmax(Q - S * mean, 0.0) / (double)(F - 1);
+    stats[((size_t)b * D + d) * 2] = (float)mean;
+    stats[((size_t)b * D + d) * 2 + 1] = 1.0f / ((float)sqrt(var) + eps);
   }
 }
 
 constexpr int kHM = 128;     // frames per workgroup
-constexpr int kHK = 40;      // K chunk
-constexpr int kHP = kHK + 1; // LDS pitch (odd)
+constexpr int kHK = 40;      // K chunk (ten 16-B pieces per row)
+constexpr int kHP = kHK + 1; // LDS pitch (odd: conflict-free ds_read_b32 operand fetches)
+constexpr int kHHalf = 16;   // rows of a wave's 32 that go out per epilogue pass
 
+// Round 3 rewrite (the first version staged every element with its own index division and 4-B accesses and stored the outputs as 128-B row
+// pieces straight from the accumulator layout: 787 us for 256 utterances, 0.12 of the HBM rate).  Now:
+//   staging  : 16-B global loads (features: CMVN applied on the way; weights), no per-element division; LDS keeps the odd pitch
+//   epilogue : a wave's 32 x N outputs are ONE contiguous span of the row-major (M, N) tensors (N is the whole row), so the activated mask goes
+//              through LDS in that layout, 16 rows at a time, and leaves as aligned 16-B stores with the noisy power read the same way
+//              (predicted = linears * offset): every global access of the kernel is a full 16-B lane access on consecutive addresses.
 template <int NT>
-__global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ feats, const float* __restrict__ W,
-                                                   const float* __restrict__ bias, const float* __restrict__ linears,
-                                                   const float* __restrict__ stats, int rows, int F, int D, int N, int act,
-                                                   float* __restrict__ predicted, float* __restrict__ offset) {
-  __shared__ float As[kHM * kHP];
-  __shared__ float Ws[NT * 32 * kHP];
+__global__ __launch_bounds__(256, 2) void head_kernel(const float* __restrict__ feats, const float* __restrict__ W,
+                                                      const float* __restrict__ bias, const float* __restrict__ linears,
+                                                      const float* __restrict__ stats, int rows, int F, int D, int N, int act,
+                                                      float* __restrict__ predicted, float* __restrict__ offset, int vec_io) {
+  constexpr int kStage = (kHM + NT * 32) * kHP;                     // floats: feature tile + weight chunk
+  constexpr int kEpi = 4 * kHHalf * (NT * 32);                       // floats: per wave 16 rows x (up to NT * 32) outputs
+  __shared__ __attribute__((aligned(16))) float smem[kStage > kEpi ? kStage : kEpi];
+  float* As = smem;
+  float* Ws = smem + kHM * kHP;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int row0 = blockIdx.x * kHM;
 
@@ -76,26 +95,53 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ fea
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
   for (int k0 = 0; k0 < D; k0 += kHK) {
-    const int kc = min(kHK, D - k0);
     __syncthreads();
-    // stage normalised features: item (r, kk)
-    for (int it = tid; it < kHM * kHK; it += 256) {
-      const int r = it / kHK, kk = it - r * kHK;
-      const int row = row0 + r;
-      float v = 0.f;
-      if (row < rows && kk < kc) {
-        v = feats[(size_t)row * D + k0 + kk];
+    // ---- stage the normalised feature tile: item = (row, 16-B piece); 10 pieces per row
+    for (int it = tid; it < kHM * (kHK / 4); it += 256) {
+      const int r = it / (kHK / 4), c = it - r * (kHK / 4);
+      const int row = row0 + r, k = k0 + 4 * c;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < rows && k < D) {
+        const float* src = feats + (size_t)row * D + k;
+        if (k + 3 < D) {
+          v = *reinterpret_cast<const float4*>(src);
+        } else {
+          v.x = src[0];
+          if (k + 1 < D) v.y = src[1];
+          if (k + 2 < D) v.z = src[2];
+        }
         if (stats) {
-          const int b = row / F;
-          const float2 ms = *reinterpret_cast<const float2*>(stats + ((size_t)b * D + k0 + kk) * 2);
-          v = (v - ms.x) * ms.y;
+          const float* sp = stats + ((size_t)(row / F) * D + k) * 2;           // (mean, 1 / (std + eps)) pairs
+          if (k + 3 < D) {
+            const float4 s0 = *reinterpret_cast<const float4*>(sp), s1 = *reinterpret_cast<const float4*>(sp + 4);
+            v = make_float4((v.x - s0.x) * s0.y, (v.y - s0.z) * s0.w, (v.z - s1.x) * s1.y, (v.w - s1.z) * s1.w);
+          } else {
+            v.x = (v.x - sp[0]) * sp[1];
+            if (k + 1 < D) v.y = (v.y - sp[2]) * sp[3];
+            if (k + 2 < D) v.z = (v.z - sp[4]) * sp[5];
+          }
         }
       }
-      As[r * kHP + kk] = v;
+      float* d = As + r * kHP + 4 * c;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     }
-    for (int it = tid; it < NT * 32 * kHK; it += 256) {
-      const int n = it / kHK, kk = it - n * kHK;
-      Ws[n * kHP + kk] = (n < N && kk < kc) ? W[(size_t)n * D + k0 + kk] : 0.f;
+    // ---- stage the weight chunk: item = (output n, 16-B piece)
+    for (int it = tid; it < NT * 32 * (kHK / 4); it += 256) {
+      const int n = it / (kHK / 4), c = it - n * (kHK / 4);
+      const int k = k0 + 4 * c;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (n < N && k < D) {
+        const float* src = W + (size_t)n * D + k;
+        if (k + 3 < D) {
+          v = *reinterpret_cast<const float4*>(src);
+        } else {
+          v.x = src[0];
+          if (k + 1 < D) v.y = src[1];
+          if (k + 2 < D) v.z = src[2];
+        }
+      }
+      float* d = Ws + n * kHP + 4 * c;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     }
     __syncthreads();
     const float* ap = As + (wave * 32 + (lane & 31)) * kHP + (lane >> 5);
@@ -108,21 +154,67 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ fea
     }
   }
 
-  // epilogue: C/D map of 32x32: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+  // ---- epilogue.  C/D map of 32x32: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5): registers 8 h .. 8 h + 7 hold rows 16 h .. 16 h + 15
+  __syncthreads();                                              // every wave is done with the staging tiles
+  float* Es = smem + wave * (kHHalf * NT * 32);                 // this wave's [16][N] slab, rows packed at pitch N: the global layout of the span
+  float bn[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int n = t * 32 + (lane & 31);
-    if (n >= N) continue;
-    const float bn = bias ? bias[n] : 0.f;
+    bn[t] = (bias && n < N) ? bias[n] : 0.f;
+  }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = row0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      if (row >= rows) continue;
-      const float o = apply_act(acc[t][r] + bn, act);
-      const size_t idx = (size_t)row * N + n;
-      if (offset) offset[idx] = o;
-      if (predicted) predicted[idx] = linears ? linears[idx] * o : o;
+  for (int h = 0; h < 2; ++h) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int n = t * 32 + (lane & 31);
+      if (n < N) {
+#pragma unroll
+        for (int r8 = 0; r8 < 8; ++r8) {
+          const int r = 8 * h + r8;
+          const int rl = (r & 3) + 8 * ((r >> 2) & 1) + 4 * (lane >> 5);       // row within the 16-row half
+          Es[rl * N + n] = apply_act(acc[t][r] + bn[t], act);
+        }
+      }
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const int rbase = row0 + wave * 32 + kHHalf * h;                            // a multiple of 16: the span starts 64-B aligned for any N
+    const int nrow = min(kHHalf, rows - rbase);
+    if (nrow > 0) {
+      const int cnt = nrow * N;
+      const size_t g = (size_t)rbase * N;
+      if (vec_io) {
+        const int nvec = cnt >> 2;
+        for (int i = lane; i < nvec; i += 64) {
+          const float4 o = *reinterpret_cast<const float4*>(Es + 4 * i);
+          if (offset) *reinterpret_cast<float4*>(offset + g + 4 * i) = o;
+          if (predicted) {
+            float4 p = o;
+            if (linears) {
+              const float4 l = *reinterpret_cast<const float4*>(linears + g + 4 * i);
+              p = make_float4(o.x * l.x, o.y * l.y, o.z * l.z, o.w * l.w);
+            }
+            *reinterpret_cast<float4*>(predicted + g + 4 * i) = p;
+          }
+        }
+        for (int i = 4 * nvec + lane; i < cnt; i += 64) {
+          const float o = Es[i];
+          if (offset) offset[g + i] = o;
+          if (predicted) predicted[g + i] = linears ? linears[g + i] * o : o;
+        }
+      } else {
+        for (int i = lane; i < cnt; i += 64) {
+          const float o = Es[i];
+          if (offset) offset[g + i] = o;
+          if (predicted) predicted[g + i] = linears ? linears[g + i] * o : o;
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   }
 }
 
@@ -144,10 +236,11 @@ extern "C" size_t se_head_workspace_bytes(int B, int F, int D, int N) {
 template <int NT>
 static int launch_head(const float* feats, const float* W, const float* bias, const float* linears, const float* stats,
                        int rows, int F, int D, int N, int act, float* predicted, float* offset, hipStream_t st) {
+  const int vec_io = ((((uintptr_t)predicted | (uintptr_t)offset | (uintptr_t)linears) % 16) == 0) ? 1 : 0;
   // algorithmic bytes: features + noisy power in, predicted + offset out
   se::ProfScope prof(se::kProfHead, 4.0 * rows * ((double)D + (linears ? N : 0) + (predicted ? N : 0) + (offset ? N : 0)), st);
   hipLaunchKernelGGL((se::head_kernel<NT>), dim3((rows + se::kHM - 1) / se::kHM), dim3(256), 0, st, feats, W, bias, linears,
-                     stats, rows, F, D, N, act, predicted, offset);
+                     stats, rows, F, D, N, act, predicted, offset, vec_io);
   SE_LAUNCH_CHECK();
   return SE_OK;
 }

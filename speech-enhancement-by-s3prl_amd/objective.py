@@ -10,14 +10,15 @@ import torch.nn as nn
 from . import _lib
 
 
-_L1_SCRATCH = {}      # device -> persistent zeroed double[3] {sum, count, ticket} of se_l1_masked_loss_f32 (self-cleaning)
+_L1_SCRATCH = {}      # (device, stream) -> persistent scratch of se_l1_masked_loss_f32: {ticket, -, per-workgroup partial sums}; the ticket is self-cleaning
 
 
-def _l1_scratch(dev):
+def _l1_scratch(dev, B):
     key = (dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(dev).cuda_stream)      # one per stream: calls on two streams may overlap
+    n = int(_lib.load().se_l1_scratch_doubles(int(B)))
     t = _L1_SCRATCH.get(key)
-    if t is None:
-        t = _L1_SCRATCH[key] = torch.zeros(3, device=dev, dtype=torch.float64)
+    if t is None or t.numel() < n:
+        t = _L1_SCRATCH[key] = torch.zeros(max(n, 1024), device=dev, dtype=torch.float64)
     return t
 
 
@@ -36,7 +37,7 @@ class _L1Fn(torch.autograd.Function):
         if reduce_fn is None:
             # one launch: sums, count AND the loss come out of the kernel (last-arriving workgroup), no zeroing launch, no division kernels
             loss = torch.empty((), device=lp.device, dtype=torch.float32)
-            _lib.check(lib.se_l1_masked_loss_f32(_lib.ptr(lp), _lib.ptr(tar), _lib.ptr(lens), int(len_div), B, F, K, float(eps), _lib.ptr(_l1_scratch(lp.device)),
+            _lib.check(lib.se_l1_masked_loss_f32(_lib.ptr(lp), _lib.ptr(tar), _lib.ptr(lens), int(len_div), B, F, K, float(eps), _lib.ptr(_l1_scratch(lp.device, B)),
                                                  _lib.ptr(sums), _lib.ptr(loss), _lib.ptr(grad), _lib.stream()), 'se_l1_masked_loss_f32')
             ctx.save_for_backward(grad if grad is not None else torch.empty(0), sums)
             return loss

@@ -19,6 +19,8 @@ import ctypes
 import warnings
 
 import numpy as np
+import weakref
+
 import torch
 import torch.nn as nn
 
@@ -473,17 +475,23 @@ class _Engine:
         if lengths is None:
             lengths = torch.empty(B, device=feats.device, dtype=torch.int32)
             _lib.check(lib.se_valid_lengths_i32(_lib.ptr(feats), B, T, D, _lib.ptr(lengths), _lib.stream()), 'se_valid_lengths_i32')
-        hidden = torch.empty(B, T, model.config.hidden_size, device=feats.device, dtype=torch.float32)
+        H_ = model.config.hidden_size
+        hidden = torch.empty(B, T, H_, device=feats.device, dtype=torch.float32)
         _lib.check(lib.se_encoder_fwd_bf16(h, _lib.ptr(feats), _lib.ptr(lengths), B, T, _lib.ptr(hidden), _lib.ptr(ws), n,
                                            _lib.stream()), 'se_encoder_fwd_bf16')
         # the call's last launch left the bf16 copy of `hidden` in this workspace: the spec head that follows (model.py:164-165) can skip its
         # conversion pass as long as it is handed exactly this tensor, unmodified, on the same workspace
-        self._last_hidden = (hidden.data_ptr(), hidden._version, B, T, ws.data_ptr())
+        _LAST_ENCODE[(feats.device.index, torch.cuda.current_stream(feats.device).cuda_stream)] = (weakref.ref(hidden), hidden._version, B, T, H_, ws)
         return hidden
 
-    def _hidden_is_cached(self, hidden, B, T, ws):
-        lh = getattr(self, '_last_hidden', None)
-        return int(lh is not None and lh == (hidden.data_ptr(), hidden._version, B, T, ws.data_ptr()))
+    @staticmethod
+    def _cached_workspace(hidden, B, T, H, n):
+        """(workspace, 1) of the encode that produced exactly this `hidden` on this stream (the spec head's engine is another object than the
+        trunk's: the registry is per device and stream), else (None, 0)."""
+        e = _LAST_ENCODE.get((hidden.device.index, torch.cuda.current_stream(hidden.device).cuda_stream))
+        if e is not None and e[0]() is hidden and e[1:5] == (hidden._version, B, T, H) and e[5].numel() >= n:      # the very same tensor object, unmodified
+            return e[5], 1
+        return None, 0
 
     def spechead(self, head, model, hidden, mode='raw', log_target=False, act='ReLU', eps=1e-6):
         if self.precision == 'fp32':
@@ -495,19 +503,25 @@ class _Engine:
         B, T, H = hidden.shape
         h = self._ensure(model, head, hidden.device)
         ws, n = self._workspace(h, B, T, hidden.device)
+        cws, cached = self._cached_workspace(hidden, B, T, H, n)
+        if cached:
+            ws = cws           # the trunk engine's workspace: its last launch left the bf16 copy of `hidden` there
         N = head.output.out_features
         dev = hidden.device
         if mode == 'raw':
             raw = torch.empty(B, T, N, device=dev, dtype=torch.float32)
             _lib.check(lib.se_spechead_fwd2_bf16(h, _lib.ptr(hidden), B, T, 0, 0, float(eps), None, None, _lib.ptr(raw), _lib.ptr(ws), n,
-                                                 self._hidden_is_cached(hidden, B, T, ws), _lib.stream()), 'se_spechead_fwd2_bf16')
+                                                 cached, _lib.stream()), 'se_spechead_fwd2_bf16')
             return raw
         pred = torch.empty(B, T, N, device=dev, dtype=torch.float32)
         logp = torch.empty(B, T, N, device=dev, dtype=torch.float32)
         _lib.check(lib.se_spechead_fwd2_bf16(h, _lib.ptr(hidden), B, T, int(bool(log_target)), _lib.SE_ACT[act], float(eps),
-                                             _lib.ptr(pred), _lib.ptr(logp), None, _lib.ptr(ws), n, self._hidden_is_cached(hidden, B, T, ws),
+                                             _lib.ptr(pred), _lib.ptr(logp), None, _lib.ptr(ws), n, cached,
                                              _lib.stream()), 'se_spechead_fwd2_bf16')
         return pred, logp
+
+
+_LAST_ENCODE = {}      # (device index, stream) -> (weakref to the hidden tensor, its version, B, T, H, workspace) of the last inference encode: see _Engine._cached_workspace
 
 
 def _str2bool(v):

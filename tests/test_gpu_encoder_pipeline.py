@@ -241,7 +241,8 @@ def test_spec_head_reuses_the_encoders_bf16_copy_only_for_the_untouched_tensor(g
     feats = pre(wavs.to(gpu))[0]
     hidden = up(feats)
     eng = up._engine
-    assert eng._last_hidden[0] == hidden.data_ptr() and eng._last_hidden[1] == hidden._version
+    assert eng._cached_workspace(hidden, hidden.shape[0], hidden.shape[1], hidden.shape[2], 1)[1] == 1
+    assert eng._cached_workspace(hidden.clone(), hidden.shape[0], hidden.shape[1], hidden.shape[2], 1)[1] == 0
     p_cached, r_cached = up.SpecHead(hidden)
     p_fresh, r_fresh = up.SpecHead(hidden.clone())             # another tensor: conversion pass
     assert torch.equal(p_cached, p_fresh) and torch.equal(r_cached['log_predicted'], r_fresh['log_predicted'])
