@@ -117,6 +117,13 @@ size_t se_features_workspace_bytes(int B, int D, int F, int delta);
 int se_features_f32(const float* raw, int raw_time_major, int B, int D, int F,
                     int apply_log, int delta, int cmvn, float eps,
                     float* out, void* workspace, size_t workspace_bytes, void* stream);
+/* The same with two side outputs for the encoder that consumes the features next (both optional): the rows as bf16 zero-padded to ld_pad columns
+ * (B*F, ld_pad) -- the operand of se_encoder_fwd2_bf16's input projection -- and valid_count (B) int32 = the number of frames whose feature sum is
+ * not zero (what se_valid_lengths_i32 computes: S3PRL's length rule).  valid_count is cleared inside. */
+int se_features2_f32(const float* raw, int raw_time_major, int B, int D, int F,
+                     int apply_log, int delta, int cmvn, float eps,
+                     float* out, void* workspace, size_t workspace_bytes,
+                     uint16_t* out_bf16_pad, int ld_pad, int32_t* valid_count, void* stream);
 
 /*
  * se_istft_f32 -- row A6: OnlinePreprocessor.istft(linears, phases) (runner.py:267): mag = power^(1/linear_power),
@@ -252,6 +259,10 @@ size_t se_encoder_workspace_bytes(const se_encoder* enc, int B, int T);
  */
 int se_encoder_fwd_bf16(const se_encoder* enc, const float* feats, const int32_t* lengths, int B, int T,
                         float* hidden, void* workspace, size_t workspace_bytes, void* stream);
+/* The same with the input features ALSO available as bf16 rows zero-padded to 128 columns (se_features2_f32's side output): the fp32 -> bf16
+ * conversion pass in front of the input projection is skipped.  feats may then be NULL. */
+int se_encoder_fwd2_bf16(const se_encoder* enc, const float* feats, const uint16_t* feats_bf16_pad, const int32_t* lengths, int B, int T,
+                         float* hidden, void* workspace, size_t workspace_bytes, void* stream);
 
 /*
  * se_spechead_fwd_bf16 -- rows B4 + C3: dense -> gelu -> LayerNorm -> output linear, then SpecHead.forward's

@@ -63,6 +63,7 @@ SIGNATURES = {
     'se_istft_tphase_f32': (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, c_int, _P, _P, _P, c_int, _P, _P]),
     'se_features_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int]),
     'se_features_f32': (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P, _P, c_size_t, _P]),
+    'se_features2_f32': (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P, _P, c_size_t, _P, c_int, _P, _P]),
     'se_istft_f32': (c_int, [_P, _P, _P, c_int, c_int, c_float, _P, c_int, _P, _P, _P]),
     'se_masked_sumsq_f32': (c_int, [_P, c_int, c_int, c_int, _P, _P, _P]),
     'se_dbnorm_f32': (c_int, [_P, c_int, c_int, c_int, _P, _P, _P, c_float, c_float, _P]),
@@ -79,6 +80,7 @@ SIGNATURES = {
     'se_encoder_destroy': (None, [_P]),
     'se_encoder_workspace_bytes': (c_size_t, [_P, c_int, c_int]),
     'se_encoder_fwd_bf16': (c_int, [_P, _P, _P, c_int, c_int, _P, _P, c_size_t, _P]),
+    'se_encoder_fwd2_bf16': (c_int, [_P, _P, _P, _P, c_int, c_int, _P, _P, c_size_t, _P]),
     'se_spechead_fwd_bf16': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P, _P, c_size_t, _P]),
     'se_spechead_fwd2_bf16': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P, _P, c_size_t, c_int, _P]),
     'se_valid_lengths_i32': (c_int, [_P, c_int, c_int, c_int, _P, _P]),

@@ -576,7 +576,13 @@ extern "C" size_t se_encoder_workspace_bytes(const se_encoder* enc, int B, int T
 
 extern "C" int se_encoder_fwd_bf16(const se_encoder* enc, const float* feats, const int32_t* lengths, int B, int T,
                                    float* hidden, void* workspace, size_t workspace_bytes, void* stream) {
-  SE_REQUIRE(enc && feats && hidden && workspace, "se_encoder_fwd_bf16: null argument");
+  return se_encoder_fwd2_bf16(enc, feats, nullptr, lengths, B, T, hidden, workspace, workspace_bytes, stream);
+}
+
+extern "C" int se_encoder_fwd2_bf16(const se_encoder* enc, const float* feats, const uint16_t* feats_bf16_pad, const int32_t* lengths, int B, int T,
+                                    float* hidden, void* workspace, size_t workspace_bytes, void* stream) {
+  SE_REQUIRE(enc && (feats || feats_bf16_pad) && hidden && workspace, "se_encoder_fwd_bf16: null argument");
+  SE_REQUIRE((uintptr_t)feats_bf16_pad % 16 == 0, "se_encoder_fwd2_bf16: the bf16 feature rows must be 16-B aligned");
   SE_REQUIRE(B > 0 && B <= 65535 && T > 0 && T <= se::kMaxPos, "se_encoder_fwd_bf16: bad shape B=%d T=%d (T <= %d)", B, T, se::kMaxPos);
   SE_REQUIRE(workspace_bytes >= se_encoder_workspace_bytes(enc, B, T), "se_encoder_fwd_bf16: workspace too small");
   SE_REQUIRE((uintptr_t)workspace % 256 == 0 && (uintptr_t)hidden % 16 == 0, "se_encoder_fwd_bf16: workspace must be 256-B aligned");
@@ -588,7 +594,9 @@ extern "C" int se_encoder_fwd_bf16(const se_encoder* enc, const float* feats, co
   Ws w = carve(enc, Mz, reinterpret_cast<char*>(workspace));
   int rc;
   // B1: input projection + positional encoding + LayerNorm
-  {
+  if (feats_bf16_pad) {       // the feature kernel already wrote the projection's operand (se_features2_f32: bf16 rows zero-padded to kInPad columns)
+    w.xin = const_cast<uint16_t*>(feats_bf16_pad);
+  } else {
     const int grid = (int)std::min<size_t>((Mz * (se::kInPad / 4) + 255) / 256, 8192);
     hipLaunchKernelGGL(se::cast_pad_kernel, dim3(grid), dim3(256), 0, st, feats, Mz, D, se::kInPad, w.xin);
     SE_LAUNCH_CHECK();
@@ -605,7 +613,9 @@ extern "C" int se_encoder_fwd_bf16(const se_encoder* enc, const float* feats, co
   // the slower side; it is now 16 000 rows (B = 1: 8 workgroups, 0.85 vs 1.70 ms).  SE_AMD_FUSED_LN = 2 forces it.  Between its launches the residual stream travels as
   // bf16 + int8 (24 bits, gemm4.hip) instead of fp32 + bf16: 196 instead of 295 MB per K = 768 launch.
   const bool fused = fuse_env && H == 768 && I % 32 == 0 && I >= 128 && (fuse_env == 2 || M >= (enc->cfg.fused_ln_min_rows > 0 ? enc->cfg.fused_ln_min_rows : 16000));
-  if (fused) {      // gemm8's pair flags + error word start every pass at zero (each launch also leaves them zero)
+  static int use8 = -1;
+  if (use8 < 0) { const char* e8 = getenv("SE_AMD_GEMM8"); use8 = e8 ? atoi(e8) : 0; }
+  if (fused && use8) {      // gemm8's pair flags + error word start every pass at zero (each launch also leaves them zero); the kernel is off by default
     const size_t fo = se::gemm8_scratch_bytes() - (128 * 2 * 4 + 256);
     if ((rc = se::zero_async(w.g8 + fo, 128 * 2 * 4 + 256, st))) return rc;
   }

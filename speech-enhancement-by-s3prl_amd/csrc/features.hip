@@ -21,10 +21,11 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
 
 __global__ __launch_bounds__(256) void feat_rows_kernel(const float* __restrict__ raw, int raw_time_major, int D, int F,
                                                         int apply_log, int delta, int cmvn, float eps,
-                                                        float* __restrict__ derived, float* __restrict__ stats) {
+                                                        float* __restrict__ derived, float* __restrict__ stats, int32_t* __restrict__ valid_count) {
   extern __shared__ __attribute__((aligned(16))) float rows[];   // (1+delta) x F
   __shared__ float red[4];
   const int b = blockIdx.y, d = blockIdx.x, tid = threadIdx.x;
+  if (valid_count && d == 0 && tid == 0) valid_count[b] = 0;      // the emit launch (next on the stream) counts into it: no clearing launch
   const int Dout = D * (1 + delta);
   for (int t = tid; t < F; t += 256) {
     float v = raw_time_major ? raw[((size_t)b * F + t) * D + d] : raw[((size_t)b * D + d) * F + t];
@@ -67,8 +68,12 @@ __global__ __launch_bounds__(256) void feat_rows_kernel(const float* __restrict_
 
 constexpr int kEmitT = 32;
 
+// Side outputs for the encoder that consumes these features next (transformer.py): the rows as bf16, zero-padded to `ld_pad` columns -- exactly the
+// operand of its input projection (the pass se_encoder_fwd_bf16 otherwise runs itself) -- and the number of frames whose feature sum is not zero
+// (S3PRL process_input_data's length rule; se_valid_lengths_i32 otherwise), counted into valid_count[b] (cleared by feat_rows_kernel).
 __global__ __launch_bounds__(256) void feat_emit_kernel(const float* __restrict__ derived, const float* __restrict__ stats,
-                                                        int Dout, int F, int cmvn, float* __restrict__ out) {
+                                                        int Dout, int F, int cmvn, float* __restrict__ out,
+                                                        uint16_t* __restrict__ out_bf16_pad, int ld_pad, int32_t* __restrict__ valid_count) {
   extern __shared__ __attribute__((aligned(16))) float tile[];   // kEmitT x (Dout+1)
   const int b = blockIdx.y, t0 = blockIdx.x * kEmitT, tid = threadIdx.x;
   const int nt = min(kEmitT, F - t0);
@@ -90,6 +95,32 @@ __global__ __launch_bounds__(256) void feat_emit_kernel(const float* __restrict_
     const int tl = it / Dout, dd = it - tl * Dout;
     o[it] = tile[tl * ld + dd];
   }
+  if (out_bf16_pad) {
+    uint16_t* ob = out_bf16_pad + ((size_t)b * F + t0) * ld_pad;
+    const int pairs = ld_pad >> 1;
+    for (int it = tid; it < nt * pairs; it += 256) {
+      const int tl = it / pairs, c = (it - tl * pairs) * 2;
+      const float v0 = c < Dout ? tile[tl * ld + c] : 0.f, v1 = c + 1 < Dout ? tile[tl * ld + c + 1] : 0.f;
+      typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_;
+      const bf16x2_ pk = {(__bf16)v0, (__bf16)v1};
+      *reinterpret_cast<uint32_t*>(ob + (size_t)tl * ld_pad + c) = __builtin_bit_cast(uint32_t, pk);
+    }
+  }
+  if (valid_count) {
+    // 8 threads per frame (kEmitT = 32 frames), shuffle-reduced; one integer atomic per workgroup
+    const int tl = tid >> 3, part = tid & 7;
+    float sum = 0.f;
+    if (tl < nt)
+      for (int dd = part; dd < Dout; dd += 8) sum += tile[tl * ld + dd];
+    sum += __shfl_xor(sum, 1);
+    sum += __shfl_xor(sum, 2);
+    sum += __shfl_xor(sum, 4);
+    const unsigned long long m = __ballot(part == 0 && tl < nt && sum != 0.f);
+    __shared__ int cnts[4];
+    if ((tid & 63) == 0) cnts[tid >> 6] = __popcll(m);
+    __syncthreads();
+    if (tid == 0) atomicAdd(&valid_count[b], cnts[0] + cnts[1] + cnts[2] + cnts[3]);
+  }
 }
 
 }  // namespace se
@@ -102,7 +133,15 @@ extern "C" size_t se_features_workspace_bytes(int B, int D, int F, int delta) {
 extern "C" int se_features_f32(const float* raw, int raw_time_major, int B, int D, int F,
                                int apply_log, int delta, int cmvn, float eps,
                                float* out, void* workspace, size_t workspace_bytes, void* stream) {
+  return se_features2_f32(raw, raw_time_major, B, D, F, apply_log, delta, cmvn, eps, out, workspace, workspace_bytes, nullptr, 0, nullptr, stream);
+}
+
+extern "C" int se_features2_f32(const float* raw, int raw_time_major, int B, int D, int F,
+                                int apply_log, int delta, int cmvn, float eps,
+                                float* out, void* workspace, size_t workspace_bytes,
+                                uint16_t* out_bf16_pad, int ld_pad, int32_t* valid_count, void* stream) {
   SE_REQUIRE(raw && out && workspace, "se_features_f32: null argument");
+  SE_REQUIRE(out_bf16_pad == nullptr || (ld_pad >= D * (1 + delta) && ld_pad % 2 == 0 && (uintptr_t)out_bf16_pad % 4 == 0), "se_features2_f32: bad bf16 side output (ld_pad=%d)", ld_pad);
   SE_REQUIRE(B > 0 && B <= 65535 && D > 0 && D <= 65535 && F >= 2 && delta >= 0 && delta <= 3, "se_features_f32: bad shape B=%d D=%d F=%d delta=%d", B, D, F, delta);
   SE_REQUIRE(workspace_bytes >= se_features_workspace_bytes(B, D, F, delta), "se_features_f32: workspace too small");
   const size_t rows_lds = (size_t)(1 + delta) * F * sizeof(float);
@@ -114,12 +153,12 @@ extern "C" int se_features_f32(const float* raw, int raw_time_major, int B, int 
   float* stats = derived + (size_t)B * Dout * F;
   hipStream_t st = se::as_stream(stream);
   hipLaunchKernelGGL(se::feat_rows_kernel, dim3(D, B), dim3(256), rows_lds, st, raw, raw_time_major, D, F, apply_log, delta,
-                     cmvn, eps, derived, stats);
+                     cmvn, eps, derived, stats, valid_count);
   SE_LAUNCH_CHECK();
   if (tile_lds > 64 * 1024)
     SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::feat_emit_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds));
   hipLaunchKernelGGL(se::feat_emit_kernel, dim3((F + se::kEmitT - 1) / se::kEmitT, B), dim3(256), tile_lds, st, derived, stats,
-                     Dout, F, cmvn, out);
+                     Dout, F, cmvn, out, out_bf16_pad, ld_pad, valid_count);
   SE_LAUNCH_CHECK();
   return SE_OK;
 }

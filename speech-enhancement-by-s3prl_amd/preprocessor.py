@@ -279,19 +279,30 @@ class OnlinePreprocessor(nn.Module):
                 outs[ch]['phase'] = LazyPhase((*lead, F, K), dev, materialize, None if ph is None else ph.reshape(*lead, F, K))
         return outs
 
-    def _select(self, raw, raw_time_major, log, delta, cmvn):
-        """se_features_f32: raw (B, D, F) feature-major or (B, F, D) time-major -> (B, F, D*(1+delta))."""
+    ENCODER_IN_PAD = 128      # csrc/encoder_impl.h kInPad: the encoder's input projection takes bf16 rows zero-padded to this many columns
+
+    def _select(self, raw, raw_time_major, log, delta, cmvn, encoder_side=False):
+        """se_features_f32: raw (B, D, F) feature-major or (B, F, D) time-major -> (B, F, D*(1+delta)).
+        encoder_side: the same launches also write what the upstream encoder needs from these features -- the rows as zero-padded bf16 (the
+        operand of its input projection) and S3PRL's valid-frame counts -- and the pair rides on the returned tensor as `_se_side` (consumed by
+        transformer._Engine.encode when it is handed this very tensor, unmodified: run_downstream.py's feats_for_upstream)."""
         lib = _lib.load()
         if raw_time_major:
             B, F, D = raw.shape
         else:
             B, D, F = raw.shape
-        out = torch.empty(B, F, D * (1 + delta), device=raw.device, dtype=torch.float32)
+        Dout = D * (1 + delta)
+        out = torch.empty(B, F, Dout, device=raw.device, dtype=torch.float32)
         nbytes = lib.se_features_workspace_bytes(B, D, F, delta)
         ws = torch.empty(nbytes, device=raw.device, dtype=torch.uint8)
-        _lib.check(lib.se_features_f32(_lib.ptr(raw), int(raw_time_major), B, D, F, int(bool(log)), int(delta),
-                                       int(bool(cmvn)), float(self.eps), _lib.ptr(out), _lib.ptr(ws), nbytes,
-                                       _lib.stream()), 'se_features_f32')
+        side = encoder_side and Dout <= self.ENCODER_IN_PAD
+        xin = torch.empty(B * F, self.ENCODER_IN_PAD, device=raw.device, dtype=torch.bfloat16) if side else None
+        valid = torch.empty(B, device=raw.device, dtype=torch.int32) if side else None
+        _lib.check(lib.se_features2_f32(_lib.ptr(raw), int(raw_time_major), B, D, F, int(bool(log)), int(delta),
+                                        int(bool(cmvn)), float(self.eps), _lib.ptr(out), _lib.ptr(ws), nbytes,
+                                        _lib.ptr(xin), self.ENCODER_IN_PAD if side else 0, _lib.ptr(valid), _lib.stream()), 'se_features2_f32')
+        if side:
+            out._se_side = (xin, valid)
         return out
 
     def forward(self, wavs=None, feat_list=None):
@@ -333,13 +344,18 @@ class OnlinePreprocessor(nn.Module):
             if type(raw) is LazyPhase:
                 feats.append(raw)                # (*lead, F, K) already; materialises itself on any use but istft()
                 continue
+            first = len(feats) == 0 and home == wavs3.device       # feats_for_upstream (run_downstream.py:150): what the TRANSFORMER is fed
             if ft == 'mel':
-                feat = self._select(raw, False, log, delta, cmvn)
+                feat = self._select(raw, False, log, delta, cmvn, encoder_side=first)
             elif log or delta or cmvn:
-                feat = self._select(raw, True, log, delta, cmvn)
+                feat = self._select(raw, True, log, delta, cmvn, encoder_side=first)
             else:
                 feat = raw
-            feats.append(feat.reshape(*lead, *feat.shape[-2:]).to(home))
+            side = getattr(feat, '_se_side', None)
+            feat = feat.reshape(*lead, *feat.shape[-2:]).to(home)
+            if side is not None:
+                feat._se_side = side + (feat._version,)           # (bf16 rows, valid-frame counts, version the pair belongs to)
+            feats.append(feat)
         return feats
 
     def istft(self, linears=None, phases=None, linear_power=2, complxs=None):

@@ -468,7 +468,16 @@ class _Engine:
         if not feats.is_cuda:
             raise _lib.SEError('TRANSFORMER runs on MI355X only (no CPU fallback): move the module and inputs to the GPU')
         lib = _lib.load()
-        feats = feats.contiguous().float()
+        # the preprocessor's feature kernel may have left the projection's bf16 operand and the valid-frame counts on the tensor (preprocessor._select):
+        # valid for exactly this tensor object in the state it was produced in
+        side = getattr(feats, '_se_side', None)
+        feats_c = feats.contiguous().float()
+        xin = None
+        if side is not None and feats_c is feats and side[2] == feats._version and side[0].shape[0] == feats.shape[0] * feats.shape[1]:
+            xin = side[0]
+            if lengths is None:
+                lengths = side[1]
+        feats = feats_c
         B, T, D = feats.shape
         h = self._ensure(model, head, feats.device)
         ws, n = self._workspace(h, B, T, feats.device)
@@ -477,8 +486,8 @@ class _Engine:
             _lib.check(lib.se_valid_lengths_i32(_lib.ptr(feats), B, T, D, _lib.ptr(lengths), _lib.stream()), 'se_valid_lengths_i32')
         H_ = model.config.hidden_size
         hidden = torch.empty(B, T, H_, device=feats.device, dtype=torch.float32)
-        _lib.check(lib.se_encoder_fwd_bf16(h, _lib.ptr(feats), _lib.ptr(lengths), B, T, _lib.ptr(hidden), _lib.ptr(ws), n,
-                                           _lib.stream()), 'se_encoder_fwd_bf16')
+        _lib.check(lib.se_encoder_fwd2_bf16(h, _lib.ptr(feats), _lib.ptr(xin), _lib.ptr(lengths), B, T, _lib.ptr(hidden), _lib.ptr(ws), n,
+                                            _lib.stream()), 'se_encoder_fwd2_bf16')
         # the call's last launch left the bf16 copy of `hidden` in this workspace: the spec head that follows (model.py:164-165) can skip its
         # conversion pass as long as it is handed exactly this tensor, unmodified, on the same workspace
         _LAST_ENCODE[(feats.device.index, torch.cuda.current_stream(feats.device).cuda_stream)] = (weakref.ref(hidden), hidden._version, B, T, H_, ws)

@@ -251,3 +251,34 @@ def test_spec_head_reuses_the_encoders_bf16_copy_only_for_the_untouched_tensor(g
     p_mod, _ = up.SpecHead(hidden2)
     p_ref, _ = up.SpecHead((hidden * 0.5).contiguous())
     assert torch.equal(p_mod, p_ref) and not torch.equal(p_mod, p_cached)
+
+
+def test_encoder_takes_the_feature_kernels_side_outputs(gpu, small):
+    """preprocessor._select leaves the encoder's bf16 input rows and S3PRL's valid-frame counts on feats_for_upstream (`_se_side`); the encoder
+    uses them only for that very tensor in the state it was produced in, and the result equals the path that converts / counts itself."""
+    from speech_enhancement_by_s3prl_amd import _lib, pipeline, synth
+    cfg, ckpt = small
+    up = pipeline.build_upstream(ckpt, gpu)
+    pre = pipeline.build_preprocessor(cfg, gpu)
+    lengths, wavs = synth.synth_batch(3, 24000, ragged=True)          # zero-padded tails: valid-frame counts below F
+    feats = pre(wavs.to(gpu))[0]
+    xin, valid, ver = feats._se_side
+    assert ver == feats._version and xin.shape == (3 * feats.shape[1], 128) and xin.dtype == torch.bfloat16
+    lib = _lib.load()
+    ref_valid = torch.empty(3, device=gpu, dtype=torch.int32)
+    _lib.check(lib.se_valid_lengths_i32(_lib.ptr(feats), 3, feats.shape[1], feats.shape[2], _lib.ptr(ref_valid), _lib.stream()), 'se_valid_lengths_i32')
+    assert torch.equal(valid, ref_valid)
+    # frames that ARE zero (no CMVN, zero raw rows) are left out of the count, as by se_valid_lengths_i32
+    raw = torch.rand(3, 40, 77, device=gpu)
+    raw[0, :, 50:] = 0
+    raw[2, :, 10:20] = 0
+    f2 = pre._select(raw, False, False, 1, False, encoder_side=True)
+    _lib.check(lib.se_valid_lengths_i32(_lib.ptr(f2), 3, 77, 80, _lib.ptr(ref_valid), _lib.stream()), 'se_valid_lengths_i32')
+    assert torch.equal(f2._se_side[1], ref_valid) and ref_valid.tolist() == [52, 77, 71]      # the delta taps reach two frames into each zero stretch
+    assert torch.equal(xin[:, :80].float(), feats.reshape(-1, 80).bfloat16().float()) and (xin[:, 80:] == 0).all()
+    h_side = up(feats)
+    h_plain = up(feats.clone())                                        # another tensor object: converts and counts itself
+    assert torch.equal(h_side, h_plain)
+    feats.mul_(0.5)                                                    # version bump: the side outputs are stale and must be ignored
+    assert torch.equal(up(feats), up(feats.clone())) and not torch.equal(up(feats), h_side)
+    assert not hasattr(pre(wavs.to(gpu))[1], '_se_side')               # only feats_for_upstream carries them
