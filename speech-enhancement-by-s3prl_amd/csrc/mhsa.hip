@@ -22,7 +22,7 @@
 #include "dropout.h"
 
 // developer ablation (timing only, results are wrong): build with SE_AMD_EXTRA_DEFINES=-DSE_MHSA_ABL=<mask>: 1 no K/V staging, 2 no barrier,
-// 4 no exponentials, 8 no PV MFMAs, 16 no QK MFMAs, 32 no LDS fragment reads
+// 4 no exponentials, 8 no PV MFMAs, 16 no QK MFMAs, 32 no LDS fragment reads, 64 every workgroup stages the K / V of (utterance 0, head 0): all L2 hits
 #ifndef SE_MHSA_ABL
 #define SE_MHSA_ABL 0
 #endif
@@ -84,8 +84,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
 
   // ---- staging: K and V tiles are 64 rows x 128 B; 256 threads x 16 B = 32 rows per pass
   const int srow = tid >> 3, sch = tid & 7;
-  const uint16_t* kp = base + H + sch * 8;
-  const uint16_t* vp = base + 2 * H + sch * 8;
+  const uint16_t* kvbase = (SE_MHSA_ABL & 64) ? qkv : base;
+  const uint16_t* kp = kvbase + H + sch * 8;
+  const uint16_t* vp = kvbase + 2 * H + sch * 8;
   uint4 rk0, rk1, rv0, rv1;
   const int so0 = kv_off(srow, sch), so1 = kv_off(srow + 32, sch);
 #define SE_A_ISSUE(kt)                                                                       \
@@ -337,6 +338,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
 }  // namespace se
 
 int se_mhsa_fwd_pipe_launch(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, int occ, hipStream_t st);   // mhsa_pipe.hip
+int se_mhsa2_fwd_launch(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, int never_speculate, hipStream_t st);   // mhsa2.hip
 
 static int mhsa_fwd_launch(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, float* lse, float dropout_p,
                            uint64_t seed, uint32_t site, void* stream) {
@@ -379,9 +381,10 @@ static int mhsa_prescaled_launch(const uint16_t* qkv, const int32_t* lengths, in
     const char* o = getenv("SE_AMD_MHSA_PIPE_OCC");
     pipe_occ = o ? atoi(o) : 2;
   }
-  if (pipe) return se_mhsa_fwd_pipe_launch(qkv, lengths, B, T, heads, ctx, pipe_occ, se::as_stream(stream));
+  if (pipe == 1) return se_mhsa_fwd_pipe_launch(qkv, lengths, B, T, heads, ctx, pipe_occ, se::as_stream(stream));
   static int spec = -1;
   if (spec < 0) { const char* e = getenv("SE_AMD_MHSA_SPEC"); spec = e ? atoi(e) : 1; }      // 0: always the exact online-softmax tile (A/B)
+  if (pipe == 2) return se_mhsa2_fwd_launch(qkv, lengths, B, T, heads, ctx, spec ? 0 : 1, se::as_stream(stream));      // two query blocks per wave (mhsa2.hip)
   static int dma = -1;
   if (dma < 0) { const char* e = getenv("SE_AMD_MHSA_DMA"); dma = e ? atoi(e) : 0; }        // A/B: 1 LDS-DMA 2-slot ring, 2 three slots + two tiles in flight, 3 one-body ring at 4 waves per SIMD, 4 the same at 3 (all measured equal or slower: DESIGN section 6)
   if (dma == 3)
@@ -407,10 +410,10 @@ extern "C" int se_mhsa_fwd_prescaled_bf16(const uint16_t* qkv, const int32_t* le
   return mhsa_prescaled_launch(qkv, lengths, B, T, heads, ctx, pipe, stream);
 }
 
-// test / measurement surface: variant 0 = this file's kernel, 1 = the software-pipelined experiment of mhsa_pipe.hip
+// test / measurement surface: variant 0 = this file's kernel, 1 = the software-pipelined experiment of mhsa_pipe.hip, 2 = two query blocks per wave (mhsa2.hip)
 extern "C" int se_mhsa_fwd_prescaled_variant_bf16(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, int variant,
                                                   void* stream) {
-  SE_REQUIRE(variant == 0 || variant == 1, "se_mhsa_fwd_prescaled_variant_bf16: variant %d (0 / 1)", variant);
+  SE_REQUIRE(variant >= 0 && variant <= 2, "se_mhsa_fwd_prescaled_variant_bf16: variant %d (0 / 1 / 2)", variant);
   return mhsa_prescaled_launch(qkv, lengths, B, T, heads, ctx, variant, stream);
 }
 
