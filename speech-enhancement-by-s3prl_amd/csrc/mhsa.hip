@@ -339,6 +339,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
 
 int se_mhsa_fwd_pipe_launch(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, int occ, hipStream_t st);   // mhsa_pipe.hip
 int se_mhsa2_fwd_launch(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, int never_speculate, hipStream_t st);   // mhsa2.hip
+int se_mhsa3_fwd_launch(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, int never_speculate, hipStream_t st);   // mhsa3.hip
 
 static int mhsa_fwd_launch(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, float* lse, float dropout_p,
                            uint64_t seed, uint32_t site, void* stream) {
@@ -384,6 +385,7 @@ static int mhsa_prescaled_launch(const uint16_t* qkv, const int32_t* lengths, in
   if (pipe == 1) return se_mhsa_fwd_pipe_launch(qkv, lengths, B, T, heads, ctx, pipe_occ, se::as_stream(stream));
   static int spec = -1;
   if (spec < 0) { const char* e = getenv("SE_AMD_MHSA_SPEC"); spec = e ? atoi(e) : 1; }      // 0: always the exact online-softmax tile (A/B)
+  if (pipe == 3) return se_mhsa3_fwd_launch(qkv, lengths, B, T, heads, ctx, spec ? 0 : 1, se::as_stream(stream));      // interleaved matrix / vector stream, two query blocks per wave (mhsa3.hip)
   if (pipe == 2) return se_mhsa2_fwd_launch(qkv, lengths, B, T, heads, ctx, spec ? 0 : 1, se::as_stream(stream));      // two query blocks per wave (mhsa2.hip)
   static int dma = -1;
   if (dma < 0) { const char* e = getenv("SE_AMD_MHSA_DMA"); dma = e ? atoi(e) : 0; }        // A/B: 1 LDS-DMA 2-slot ring, 2 three slots + two tiles in flight, 3 one-body ring at 4 waves per SIMD, 4 the same at 3 (all measured equal or slower: DESIGN section 6)
@@ -413,7 +415,7 @@ extern "C" int se_mhsa_fwd_prescaled_bf16(const uint16_t* qkv, const int32_t* le
 // test / measurement surface: variant 0 = this file's kernel, 1 = the software-pipelined experiment of mhsa_pipe.hip, 2 = two query blocks per wave (mhsa2.hip)
 extern "C" int se_mhsa_fwd_prescaled_variant_bf16(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, int variant,
                                                   void* stream) {
-  SE_REQUIRE(variant >= 0 && variant <= 2, "se_mhsa_fwd_prescaled_variant_bf16: variant %d (0 / 1 / 2)", variant);
+  SE_REQUIRE(variant >= 0 && variant <= 3, "se_mhsa_fwd_prescaled_variant_bf16: variant %d (0 .. 3)", variant);
   return mhsa_prescaled_launch(qkv, lengths, B, T, heads, ctx, variant, stream);
 }
 
