@@ -22,6 +22,8 @@ __global__ void k(float* out, unsigned long long* cyc, float seed) {
   for (int i = threadIdx.x; i < 4096; i += blockDim.x) reinterpret_cast<float*>(lds)[i] = seed + i;
   __syncthreads();
   float rs = 0.f;
+  typedef float f2t __attribute__((ext_vector_type(2)));
+  f2t rs2 = {0.f, 0.f};
   unsigned pk0 = 0, pk1 = 0;
   float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
   const char* lp = lds + (threadIdx.x & 63) * 16;
@@ -43,6 +45,14 @@ __global__ void k(float* out, unsigned long long* cyc, float seed) {
         const bf16x2 q0 = {(__bf16)a0, (__bf16)a1}, q1 = {(__bf16)a2, (__bf16)a3};                                     \
         pk0 ^= __builtin_bit_cast(unsigned, q0);                                                                       \
         pk1 ^= __builtin_bit_cast(unsigned, q1);                                                                       \
+      } else if (MODE == 5 || MODE == 6) {                                                                             \
+        const float a0 = __builtin_amdgcn_exp2f(MODE == 5 ? RD[4 * j] * 1e-3f : RD[4 * j]), a1 = __builtin_amdgcn_exp2f(MODE == 5 ? RD[4 * j + 1] * 1e-3f : RD[4 * j + 1]); \
+        typedef float f2_ __attribute__((ext_vector_type(2)));                                                          \
+        f2_ pr = {a0, a1};                                                                                             \
+        rs2 += pr;                                                                                                     \
+        const bf16x2 q0 = {(__bf16)a0, (__bf16)a1};                                                                    \
+        pk0 ^= __builtin_bit_cast(unsigned, q0);                                                                       \
+        asm volatile("" : "+v"(rs2));                                                                                  \
       } else if (MODE == 3) {                                                                                          \
         rs += (p0 + p1) + (p2 + p3);                                                                                   \
         const bf16x2 q0 = {(__bf16)p0, (__bf16)p1}, q1 = {(__bf16)p2, (__bf16)p3};                                     \
@@ -63,7 +73,7 @@ __global__ void k(float* out, unsigned long long* cyc, float seed) {
 #undef STEP
   }
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();
-  float s = rs + p0 + p1 + p2 + p3 + __uint_as_float(pk0) + __uint_as_float(pk1);
+  float s = rs + rs2.x + rs2.y + p0 + p1 + p2 + p3 + __uint_as_float(pk0) + __uint_as_float(pk1);
   for (int i = 0; i < 16; ++i) s += acc[i] + accB[i];
   for (int i = 0; i < 8; ++i) s += (float)f0[i];
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
@@ -97,6 +107,8 @@ int main() {
     run<2>("MFMA + vector share", threads, out, cyc);
     run<3>("MFMA + vector share, adds / packs one slot behind their exps", threads, out, cyc);
     run<4>("MFMA (fragment from LDS, read two slots ahead) + vector share", threads, out, cyc);
+    run<5>("MFMA + HALF share: 2 mul + 2 exp2 + 1 packed add + 1 pack", threads, out, cyc);
+    run<6>("MFMA + half share, pre-scaled: 2 exp2 + 1 packed add + 1 pack", threads, out, cyc);
   }
   return 0;
 }
