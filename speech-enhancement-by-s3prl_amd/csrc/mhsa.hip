@@ -42,8 +42,9 @@ namespace se {
 // DMA = 1: the K / V tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no ds_write, no wait in front of the writes); the
 // destination of a wave instruction is lane-linear (8 rows x 128 B), so the XOR swizzle of kv_off() is applied to the per-lane SOURCE chunk.
 // The compile-time ablation (-DSE_MHSA_ABL) put the register staging at 27 % of the launch.
-template <int OCC, int DROP, int PRE, int DMA = 0>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void mhsa_fwd_kernel(
+// NW = waves per workgroup (4, or 8 with the register staging only): 8 waves share one staged K / V tile, so each wave stages half as much per tile
+template <int OCC, int DROP, int PRE, int DMA = 0, int NW = 4>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void mhsa_fwd_kernel(
     const uint16_t* __restrict__ qkv, const int32_t* __restrict__ lengths, int T, int H, uint16_t* __restrict__ ctx,
     float* __restrict__ lse, uint32_t dkey, uint32_t thr16, float dscale) {
   __shared__ __attribute__((aligned(16))) char smem[(DMA == 2 ? 3 : 2) * 2 * kAK * kHD * 2];   // 2 (DMA == 2: 3) slots x (K, V) x 8 KiB = 32 (48) KiB
@@ -67,7 +68,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
       qt = blockIdx.x; head = blockIdx.y; b = blockIdx.z;
     }
   }
-  const int q0 = qt * kAQ + wave * 32;
+  static_assert(NW == 4 || (NW == 8 && DMA == 0), "8-wave workgroups: register staging only");
+  const int q0 = qt * (NW * 32) + wave * 32;
   const int ld = 3 * H;
   const int len = lengths ? min(max(lengths[b], 1), T) : T;
   const int nkt = (len + kAK - 1) / kAK;
@@ -88,24 +90,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
   const uint16_t* kp = kvbase + H + sch * 8;
   const uint16_t* vp = kvbase + 2 * H + sch * 8;
   uint4 rk0, rk1, rv0, rv1;
-  const int so0 = kv_off(srow, sch), so1 = kv_off(srow + 32, sch);
+  const int so0 = kv_off(srow, sch), so1 = kv_off((srow + 32) & 63, sch);      // NW == 8: 512 threads x 16 B = the whole 64-row tile in one pass
 #define SE_A_ISSUE(kt)                                                                       \
   do {                                                                                       \
     const size_t r0 = (size_t)min((kt) * kAK + srow, T - 1) * ld;                            \
     const size_t r1 = (size_t)min((kt) * kAK + srow + 32, T - 1) * ld;                       \
     rk0 = *reinterpret_cast<const uint4*>(kp + r0);                                          \
-    rk1 = *reinterpret_cast<const uint4*>(kp + r1);                                          \
+    if (NW == 4) rk1 = *reinterpret_cast<const uint4*>(kp + r1);                             \
     rv0 = *reinterpret_cast<const uint4*>(vp + r0);                                          \
-    rv1 = *reinterpret_cast<const uint4*>(vp + r1);                                          \
+    if (NW == 4) rv1 = *reinterpret_cast<const uint4*>(vp + r1);                             \
   } while (0)
 #define SE_A_WRITE(buf)                                                 \
   do {                                                                  \
     char* k_w = smem + (buf) * 16384;                                   \
     char* v_w = k_w + 8192;                                             \
     *reinterpret_cast<uint4*>(k_w + so0) = rk0;                         \
-    *reinterpret_cast<uint4*>(k_w + so1) = rk1;                         \
+    if (NW == 4) *reinterpret_cast<uint4*>(k_w + so1) = rk1;            \
     *reinterpret_cast<uint4*>(v_w + so0) = rv0;                         \
-    *reinterpret_cast<uint4*>(v_w + so1) = rv1;                         \
+    if (NW == 4) *reinterpret_cast<uint4*>(v_w + so1) = rv1;            \
   } while (0)
   // LDS-DMA form: wave w brings rows [16 w, 16 w + 16) of the K and of the V tile, two 1-KiB pieces (8 rows x 128 B) each; lane l of a piece
   // writes slot l & 7 of row l >> 3, i.e. it must FETCH chunk (l & 7) ^ f(row) (kv_off: slot = chunk ^ f)
@@ -389,6 +391,8 @@ static int mhsa_prescaled_launch(const uint16_t* qkv, const int32_t* lengths, in
   if (pipe == 2) return se_mhsa2_fwd_launch(qkv, lengths, B, T, heads, ctx, spec ? 0 : 1, se::as_stream(stream));      // two query blocks per wave (mhsa2.hip)
   static int dma = -1;
   if (dma < 0) { const char* e = getenv("SE_AMD_MHSA_DMA"); dma = e ? atoi(e) : 0; }        // A/B: 1 LDS-DMA 2-slot ring, 2 three slots + two tiles in flight, 3 one-body ring at 4 waves per SIMD, 4 the same at 3 (all measured equal or slower: DESIGN section 6)
+  static int nw8 = -1;
+  if (nw8 < 0) { const char* e = getenv("SE_AMD_MHSA_NW"); nw8 = (e && atoi(e) == 8) ? 1 : 0; }      // A/B: 8-wave workgroups (256 queries share a staged tile)
   if (dma == 3)
     hipLaunchKernelGGL((se::mhsa_fwd_kernel<4, 0, 1, 3>), grid, dim3(256), 0, se::as_stream(stream), qkv, lengths, T, H, ctx, nullptr, 0u, 0u, spec ? 1.f : -1.f);
   else if (dma == 4)
@@ -397,7 +401,10 @@ static int mhsa_prescaled_launch(const uint16_t* qkv, const int32_t* lengths, in
     hipLaunchKernelGGL((se::mhsa_fwd_kernel<3, 0, 1, 2>), grid, dim3(256), 0, se::as_stream(stream), qkv, lengths, T, H, ctx, nullptr, 0u, 0u, spec ? 1.f : -1.f);
   else if (dma)
     hipLaunchKernelGGL((se::mhsa_fwd_kernel<3, 0, 1, 1>), grid, dim3(256), 0, se::as_stream(stream), qkv, lengths, T, H, ctx, nullptr, 0u, 0u, spec ? 1.f : -1.f);
-  else
+  else if (nw8) {
+    dim3 grid8((T + 255) / 256, heads, B);
+    hipLaunchKernelGGL((se::mhsa_fwd_kernel<2, 0, 1, 0, 8>), grid8, dim3(512), 0, se::as_stream(stream), qkv, lengths, T, H, ctx, nullptr, 0u, 0u, spec ? 1.f : -1.f);
+  } else
     hipLaunchKernelGGL((se::mhsa_fwd_kernel<3, 0, 1, 0>), grid, dim3(256), 0, se::as_stream(stream), qkv, lengths, T, H, ctx, nullptr, 0u, 0u, spec ? 1.f : -1.f);
   SE_LAUNCH_CHECK();
   return SE_OK;

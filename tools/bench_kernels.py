@@ -205,6 +205,31 @@ def bench_mhsa():
     print(f'mhsa prescaled B={B} T={T}: {ms*1e3:8.1f} us  {4.0*B*heads*T*T*64/ms/1e9:8.1f} TF/s   max diff vs the unscaled kernel {d:.2e}', flush=True)
 
 
+def bench_mhsa_peaked():
+    """what the exact fallback of the speculative softmax costs: the same launch with the scores (log2 domain, std 1.44 at gain 1) multiplied by `gain`;
+    a wave leaves the speculative path for good the first time a 64-key partial row sum leaves [2^-60, 2^60)"""
+    B, T, heads = 32, 1001, 12
+    base = torch.randn(B * T, 3 * 768, device=dev)
+    ctx = torch.empty(B * T, 768, device=dev, dtype=torch.bfloat16)
+    for gain in (1.0, 4.0, 8.0, 12.0, 16.0, 32.0):
+        q = base.clone()
+        q[:, :768] *= gain * 1.4426950408889634 / 8.0
+        q = q.bfloat16()
+
+        def run():
+            L.check(lib.se_mhsa_fwd_prescaled_bf16(L.ptr(q), None, B, T, heads, L.ptr(ctx), L.stream()), 'mhsa')
+        ms = timeit(run)
+        # share of (query row, key tile) partial sums outside the speculation window, from the scores themselves (one head of one utterance)
+        qh = q[:T, :64].float(); kh = q[:T, 768:832].float()
+        sc = qh @ kh.t()
+        pad = (-T) % 64
+        e = torch.exp2(torch.nn.functional.pad(sc, (0, pad), value=-1e30).double()).view(T, -1, 64).sum(-1)
+        bad = (e >= 2.0 ** 60) | ((e < 2.0 ** -60) & (torch.arange(e.shape[1], device=dev) == 0))
+        rows = bad.any(1).float().mean().item()
+        waves = bad.any(1).float().view(-1)[: (T // 32) * 32].view(-1, 32).amax(1).mean().item()
+        print(f'mhsa peaked gain {gain:5.1f} [SE_AMD_MHSA_SPEC={os.environ.get("SE_AMD_MHSA_SPEC")}]: {ms*1e3:8.1f} us   rows that fall back {rows:6.3f}   waves that fall back {waves:6.3f}   finite {bool(torch.isfinite(ctx.float()).all())}', flush=True)
+
+
 def interleaved(variants, rounds=7, iters=20):
     """cdna_hip_programming.md rule 24: N variants x M rounds interleaved in ONE process; prints min and median per variant"""
     import statistics
@@ -286,6 +311,8 @@ if __name__ == '__main__':
         bench_res24()
     if what in ('mhsa', 'all'):
         bench_mhsa()
+    if what in ('mhsa_peaked',):
+        bench_mhsa_peaked()
     if what in ('stft', 'all'):
         bench_stft()
     if what in ('wgrad',):
