@@ -388,6 +388,17 @@ int se_mhsa_fwd_lse_bf16(const uint16_t* qkv, const int32_t* lengths, int B, int
 /* flash MHSA backward: d_ctx (B*T, H) bf16 -> dqkv (B*T, 3H) bf16 = [dQ | dK | dV]; dvec (B, heads, T) fp32 scratch */
 int se_mhsa_bwd_bf16(const uint16_t* qkv, const uint16_t* ctx, const uint16_t* d_ctx, const float* lse, const int32_t* lengths,
                      int B, int T, int heads, uint16_t* dqkv, float* dvec, float dropout_p, uint64_t seed, uint32_t site, void* stream);
+/* The same attention dropout mask (csrc/dropout.h: keep(pair, h) of (seed, site); reference: attention_probs_dropout_prob,
+ * pretrain_sample.yaml:10) evaluated ONCE per layer and step as two bit matrices (csrc/dropmask.hip: mask_r query-major for the forward
+ * and the dQ kernel, mask_c key-major for the dK / dV kernel) instead of being re-hashed inside each of the three attention kernels.
+ * se_mhsa_dropmask_bytes(which = 0: mask_r, 1: mask_c); buffers 16-B aligned. */
+size_t se_mhsa_dropmask_bytes(int B, int T, int heads, int which);
+int se_mhsa_dropmask(int B, int T, int heads, float dropout_p, uint64_t seed, uint32_t site, uint32_t* mask_r, uint32_t* mask_c, void* stream);
+int se_mhsa_fwd_lse_masked_bf16(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, float* lse,
+                                const uint32_t* mask_r, float dropout_p, void* stream);
+int se_mhsa_bwd_masked_bf16(const uint16_t* qkv, const uint16_t* ctx, const uint16_t* d_ctx, const float* lse, const int32_t* lengths,
+                            int B, int T, int heads, uint16_t* dqkv, float* dvec, const uint32_t* mask_r, const uint32_t* mask_c,
+                            float dropout_p, void* stream);
 /* y = gelu(x) and dx = dy * gelu'(x), bf16 arrays of n elements (n % 8 == 0) */
 int se_gelu_bf16(const uint16_t* x, size_t n, uint16_t* y, void* stream);
 int se_gelu_bwd_bf16(const uint16_t* dy, const uint16_t* x, size_t n, uint16_t* dx, void* stream);

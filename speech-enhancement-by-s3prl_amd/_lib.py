@@ -111,6 +111,10 @@ SIGNATURES = {
     'se_spec_epilogue_bwd_f32': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_float, _P, _P, _P]),
     'se_mhsa_fwd_lse_bf16': (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, c_float, ctypes.c_uint64, ctypes.c_uint32, _P]),
     'se_mhsa_bwd_bf16': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, c_float, ctypes.c_uint64, ctypes.c_uint32, _P]),
+    'se_mhsa_dropmask_bytes': (ctypes.c_size_t, [c_int, c_int, c_int, c_int]),
+    'se_mhsa_dropmask': (c_int, [c_int, c_int, c_int, c_float, ctypes.c_uint64, ctypes.c_uint32, _P, _P, _P]),
+    'se_mhsa_fwd_lse_masked_bf16': (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, c_float, _P]),
+    'se_mhsa_bwd_masked_bf16': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, c_float, _P]),
     'se_gelu_bf16': (c_int, [_P, c_size_t, _P, _P]),
     'se_gelu_bwd_bf16': (c_int, [_P, _P, c_size_t, _P, _P]),
     'se_encoder_refresh_bf16': (c_int, [_P, POINTER(EncoderWeights), _P]),

@@ -154,6 +154,18 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OC
 
   // dropout: pair index of (this lane's query row, key) = row_id * ceil(T / 2) + key / 2
   const uint32_t drop_row = ((uint32_t)(b * (H / kHD) + head) * (uint32_t)T + (uint32_t)min(q0 + l31, T - 1)) * (uint32_t)((T + 1) >> 1);
+  // DROP == 2: the mask comes as the query-major bit matrix of dropmask.hip -- per 64-key tile one 8-byte load per lane (fetched one tile ahead),
+  // word .x = the tile's 32 even keys, .y = its odd keys; the kept probabilities are NOT scaled here: 1 / (1 - p) goes into the final 1 / l
+  const uint32_t* mrow = nullptr;
+  uint2 mw_nxt = make_uint2(0u, 0u);
+  if (DROP == 2) {
+    // the matrix address travels in the two hash arguments this mode does not use (dkey = low, thr16 = high word): one kernel signature for all
+    // modes -- two more kernel arguments moved the register allocation of the inference instantiation past its 168-register budget (2 spills)
+    const uint32_t* dmask = reinterpret_cast<const uint32_t*>(((uint64_t)thr16 << 32) | (uint64_t)dkey);
+    const int dmask_w = 4 * ((T + 127) >> 7);
+    mrow = dmask + ((size_t)(b * (H / kHD) + head) * T + min(q0 + l31, T - 1)) * dmask_w;
+    mw_nxt = *reinterpret_cast<const uint2*>(mrow);
+  }
 
   if (DMA == 2) {
     // three slots, tiles kt + 1 AND kt + 2 in flight: the first toucher of a K / V tile takes an L2 miss (8 query tiles share it: 12.5 % compulsory
@@ -174,13 +186,22 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OC
   }
   if (DMA != 2) __syncthreads();
 
+#ifndef SE_MHSA_PRIO
+#define SE_MHSA_PRIO 0          /* bit 0: raised wave priority around the QK^T products, bit 1: around the PV products */
+#endif
+#ifndef SE_MHSA_PRIO_LVL
+#define SE_MHSA_PRIO_LVL 3
+#endif
 #define SE_A_TILE(CUR)                                                                                                     \
   {                                                                                                                        \
     if (DMA == 2) { if (kt + 2 < nkt) SE_A_DMA(kt + 2, (CUR) >= 1 ? (CUR) - 1 : 2); }                                      \
     else if (DMA == 3) { if (kt + 1 < nkt) SE_A_DMA(kt + 1, (CUR) ^ 1); }                                                  \
     else if (kt + 1 < nkt && !(SE_MHSA_ABL & 1)) { if (DMA) SE_A_DMA(kt + 1, (CUR) ^ 1); else SE_A_ISSUE(kt + 1); }       \
+    uint2 mw_cur = mw_nxt;                                                                                                 \
+    if (DROP == 2 && kt + 1 < nkt) mw_nxt = *reinterpret_cast<const uint2*>(mrow + 2 * (kt + 1));                          \
     const char* t_s = smem + (CUR) * 16384;                                                                                \
     f32x16 s0, s1;                                                                                                         \
+    if (SE_MHSA_PRIO & 1) __builtin_amdgcn_s_setprio(SE_MHSA_PRIO_LVL);                                                                    \
     _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                                        \
       const bf16x8 ka = (SE_MHSA_ABL & 32) ? qf[s] : *reinterpret_cast<const bf16x8*>(t_s + koff[s]);                      \
       const bf16x8 kb_ = (SE_MHSA_ABL & 32) ? qf[3 - s] : *reinterpret_cast<const bf16x8*>(t_s + koff[s] + 4096);          \
@@ -189,6 +210,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OC
       s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[s], s == 0 ? kZero16 : s0, 0, 0, 0);                              \
       s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb_, qf[s], s == 0 ? kZero16 : s1, 0, 0, 0); }                           \
     }                                                                                                                      \
+    if (SE_MHSA_PRIO & 1) __builtin_amdgcn_s_setprio(0);                                                                   \
     if ((kt + 1) * kAK > len) {                                                                                            \
       const int kbase = kt * kAK + 4 * hh;                                                                                 \
       _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                                     \
@@ -254,7 +276,16 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OC
     if (__any(alpha != 1.0f)) {                                                                                            \
       _Pragma("unroll") for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }                                   \
     }                                                                                                                      \
-    if (DROP) {                                                                                                            \
+    if (DROP == 2) {                                                                                                       \
+      const uint32_t we_ = mw_cur.x >> (2 * hh), wo_ = mw_cur.y >> (2 * hh);                                               \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                                     \
+        /* key 4 hh + (r & 3) + 8 (r >> 2) (+ 32): pair 2 hh + ((r & 3) >> 1) + 4 (r >> 2) (+ 16), parity r & 1 */         \
+        const int pos = ((r & 3) >> 1) + 4 * (r >> 2);                                                                     \
+        const uint32_t w_ = (r & 1) ? wo_ : we_;                                                                           \
+        s0[r] = __uint_as_float(__float_as_uint(s0[r]) & (uint32_t)((int32_t)(w_ << (31 - pos)) >> 31));                   \
+        s1[r] = __uint_as_float(__float_as_uint(s1[r]) & (uint32_t)((int32_t)(w_ << (15 - pos)) >> 31));                   \
+      }                                                                                                                    \
+    } else if (DROP) {                                                                                                     \
       const uint32_t pb = drop_row + (uint32_t)((kt * kAK + 4 * hh) >> 1);                                                 \
       _Pragma("unroll") for (int r = 0; r < 16; r += 2) {                                                                  \
         const uint32_t off = (uint32_t)(((r & 3) + 8 * (r >> 2)) >> 1);                                                    \
@@ -269,6 +300,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OC
         pf[1][s][j] = (__bf16)s1[8 * s + j];                                                                               \
       }                                                                                                                    \
     }                                                                                                                      \
+    if (SE_MHSA_PRIO & 2) __builtin_amdgcn_s_setprio(SE_MHSA_PRIO_LVL);                                                    \
     _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                                                       \
       _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                                      \
         _Pragma("unroll") for (int dblk = 0; dblk < 2; ++dblk) {                                                           \
@@ -285,6 +317,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OC
           else o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, pf[kb][s], o1, 0, 0, 0); }                                 \
         }                                                                                                                  \
       }                                                                                                                    \
+    if (SE_MHSA_PRIO & 2) __builtin_amdgcn_s_setprio(0);                                                                   \
     if (!DMA && kt + 1 < nkt && !(SE_MHSA_ABL & 1)) SE_A_WRITE((CUR) ^ 1);                                                 \
     if (DMA == 2) {                                                                                                        \
       if (kt + 2 < nkt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  \
@@ -320,7 +353,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OC
 
   // ---- epilogue: O / l ; lane holds query q0 + l31, d = 32 dblk + (r&3) + 8 (r>>2) + 4 hh
   const float l_tot = l_run + __shfl_xor(l_run, 32);
-  const float inv = 1.0f / l_tot;
+  const float inv = (DROP == 2 ? dscale : 1.0f) / l_tot;
   const int q = q0 + l31;
   // training: log2-domain log-sum-exp of the scaled scores, P = exp2(c s - lse) in the backward kernels
   if (lse && q < T && hh == 0) lse[((size_t)b * (H / kHD) + head) * T + q] = fmaf(m_run, c, __builtin_amdgcn_logf(l_tot));
@@ -430,4 +463,23 @@ extern "C" int se_mhsa_fwd_lse_bf16(const uint16_t* qkv, const int32_t* lengths,
                                     float dropout_p, uint64_t seed, uint32_t site, void* stream) {
   SE_REQUIRE(lse, "se_mhsa_fwd_lse_bf16: null lse");
   return mhsa_fwd_launch(qkv, lengths, B, T, heads, ctx, lse, dropout_p, seed, site, stream);
+}
+
+// Training forward with the dropout mask of dropmask.hip (se_mhsa_dropmask: query-major bit matrix `mask_r`) instead of the in-kernel hash: same
+// mask, same result up to the place of the 1 / (1 - p) factor (applied to the fp32 context sums instead of to each probability before its bf16
+// rounding).
+extern "C" int se_mhsa_fwd_lse_masked_bf16(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, float* lse,
+                                           const uint32_t* mask_r, float dropout_p, void* stream) {
+  SE_REQUIRE(qkv && ctx && lse && mask_r, "se_mhsa_fwd_lse_masked_bf16: null argument");
+  SE_REQUIRE(B > 0 && B <= 65535 && T > 0 && heads > 0 && heads <= 65535, "se_mhsa_fwd_lse_masked_bf16: bad shape B=%d T=%d heads=%d", B, T, heads);
+  SE_REQUIRE((uintptr_t)mask_r % 16 == 0, "se_mhsa_fwd_lse_masked_bf16: mask must be 16-B aligned");
+  const se::DropoutCfg d = se::make_dropout(dropout_p, 0);
+  SE_REQUIRE(d.thr16 != 0, "se_mhsa_fwd_lse_masked_bf16: dropout_p must be > 0 (use se_mhsa_fwd_lse_bf16 without dropout)");
+  const int H = heads * se::kHD;
+  dim3 grid((T + se::kAQ - 1) / se::kAQ, heads, B);
+  se::ProfScope prof(se::kProfMhsa, 4.0 * B * (double)heads * T * (double)T * se::kHD, se::as_stream(stream));
+  hipLaunchKernelGGL((se::mhsa_fwd_kernel<2, 2, 0>), grid, dim3(256), 0, se::as_stream(stream), qkv, lengths, T, H, ctx, lse,
+                     (uint32_t)((uintptr_t)mask_r & 0xffffffffu), (uint32_t)((uintptr_t)mask_r >> 32), d.scale);
+  SE_LAUNCH_CHECK();
+  return SE_OK;
 }

@@ -84,6 +84,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
   if (!qvalid) dsum = 0.f;
   if (qvalid && hh == 0) dvec[stat] = dsum;
   const uint32_t drop_row = (uint32_t)stat * (uint32_t)((T + 1) >> 1);      // pair index base of this lane's query row
+  // DROP == 2: the mask as the query-major bit matrix of dropmask.hip (its address in dkey / thr16, as in the forward); one 8-byte load per lane
+  // and tile, fetched one tile ahead; the 1 / (1 - p) of the kept probabilities is a factor of the fma below
+  const uint32_t* mrow = nullptr;
+  uint2 mw_nxt = make_uint2(0u, 0u);
+  if (DROP == 2) {
+    const uint32_t* dmask = reinterpret_cast<const uint32_t*>(((uint64_t)thr16 << 32) | (uint64_t)dkey);
+    mrow = dmask + stat * (size_t)(4 * ((T + 127) >> 7));
+    mw_nxt = *reinterpret_cast<const uint2*>(mrow);
+  }
 
   // ---- staging of the (K, V) tiles: 64 rows x 128 B each; 256 threads x 16 B = 32 rows per pass
   const int srow = tid >> 3, sch = tid & 7;
@@ -134,6 +143,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
   for (int kt = 0; kt < nkt; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nkt) SE_Q_ISSUE(kt + 1);
+    const uint2 mw_cur = mw_nxt;
+    if (DROP == 2 && kt + 1 < nkt) mw_nxt = *reinterpret_cast<const uint2*>(mrow + 2 * (kt + 1));
     const char* t_s = smem + cur * 16384;
     f32x16 s0, s1, p0, p1;
 #pragma unroll
@@ -158,7 +169,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
       }
     }
     // dS^T = P^T (m dP^T - D)   (the 1/8 of the score scale is applied once, in the epilogue)
-    if (DROP) {
+    if (DROP == 2) {
+      const uint32_t we_ = mw_cur.x >> (2 * hh), wo_ = mw_cur.y >> (2 * hh);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        // key 4 hh + (r & 3) + 8 (r >> 2) (+ 32): pair 2 hh + ((r & 3) >> 1) + 4 (r >> 2) (+ 16) of the tile, parity r & 1 (mhsa.hip)
+        const int pos = ((r & 3) >> 1) + 4 * (r >> 2);
+        const uint32_t w_ = (r & 1) ? wo_ : we_;
+        p0[r] = __uint_as_float(__float_as_uint(p0[r]) & (uint32_t)((int32_t)(w_ << (31 - pos)) >> 31));
+        p1[r] = __uint_as_float(__float_as_uint(p1[r]) & (uint32_t)((int32_t)(w_ << (15 - pos)) >> 31));
+      }
+    } else if (DROP) {
       const uint32_t pb = drop_row + (uint32_t)((kt * kAK + 4 * hh) >> 1);
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
@@ -172,8 +193,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
     for (int r = 0; r < 16; ++r) {
       const float e0 = __builtin_amdgcn_exp2f(fmaf(s0[r], c, -L2));
       const float e1 = __builtin_amdgcn_exp2f(fmaf(s1[r], c, -L2));
-      s0[r] = e0 * (p0[r] - dsum);
-      s1[r] = e1 * (p1[r] - dsum);
+      s0[r] = e0 * (DROP == 2 ? fmaf(p0[r], dscale, -dsum) : p0[r] - dsum);
+      s1[r] = e1 * (DROP == 2 ? fmaf(p1[r], dscale, -dsum) : p1[r] - dsum);
     }
     bf16x8 df[2][2];
 #pragma unroll
@@ -316,6 +337,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
   const uint32_t drop_row0 = (uint32_t)(b * heads + head) * (uint32_t)T, drop_ppr = (uint32_t)((T + 1) >> 1);
   const uint32_t drop_k2 = (uint32_t)(min(key, T - 1) >> 1);
   const int drop_h = key & 1;
+  // DROP == 2: the key-major bit matrix of dropmask.hip (row = this lane's key, bit j of word w = query 32 w + j); one 8-byte load per 64-query
+  // tile; the 1 / (1 - p) factor of P m goes into the dV epilogue and into the fma of dS
+  const uint32_t* mrow = nullptr;
+  uint2 mw_nxt = make_uint2(0u, 0u);
+  if (DROP == 2) {
+    const uint32_t* dmask = reinterpret_cast<const uint32_t*>(((uint64_t)thr16 << 32) | (uint64_t)dkey);
+    mrow = dmask + ((size_t)(b * heads + head) * (size_t)(128 * ((T + 127) >> 7)) + key) * (size_t)(8 * ((T + 255) >> 8));
+    mw_nxt = *reinterpret_cast<const uint2*>(mrow);
+  }
 
   SE_K_ISSUE(0);
   SE_K_WRITE(0);
@@ -324,6 +354,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
   for (int qt = 0; qt < nqt; ++qt) {
     const int cur = qt & 1;
     if (qt + 1 < nqt) SE_K_ISSUE(qt + 1);
+    const uint2 mw_cur = mw_nxt;
+    if (DROP == 2 && qt + 1 < nqt) mw_nxt = *reinterpret_cast<const uint2*>(mrow + 2 * (qt + 1));
     const char* t_s = smem + cur * kBufKV;
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
@@ -345,6 +377,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
         const float e1 = __builtin_amdgcn_exp2f(fmaf(sa[4 * g + 1], c, -l2.y));
         const float e2 = __builtin_amdgcn_exp2f(fmaf(sa[4 * g + 2], c, -l2.z));
         const float e3 = __builtin_amdgcn_exp2f(fmaf(sa[4 * g + 3], c, -l2.w));
+        if (DROP == 2) {
+          // query 32 qb + 4 hh + 8 g + j of the tile: word qb, bit 4 hh + 8 g + j.  All-ones / zero masks (v_bfe_i32) applied to the bit patterns:
+          // P m is accumulated unscaled (the dV epilogue multiplies by 1 / (1 - p)), m dP takes the scale inside the fma
+          const uint32_t w_ = (qb ? mw_cur.y : mw_cur.x) >> (4 * hh);
+          const uint32_t k0 = (uint32_t)((int32_t)(w_ << (31 - 8 * g)) >> 31), k1 = (uint32_t)((int32_t)(w_ << (30 - 8 * g)) >> 31);
+          const uint32_t k2 = (uint32_t)((int32_t)(w_ << (29 - 8 * g)) >> 31), k3 = (uint32_t)((int32_t)(w_ << (28 - 8 * g)) >> 31);
+          sa[4 * g + 0] = __uint_as_float(__float_as_uint(e0) & k0); sa[4 * g + 1] = __uint_as_float(__float_as_uint(e1) & k1);
+          sa[4 * g + 2] = __uint_as_float(__float_as_uint(e2) & k2); sa[4 * g + 3] = __uint_as_float(__float_as_uint(e3) & k3);
+          da[4 * g + 0] = e0 * fmaf(__uint_as_float(__float_as_uint(da[4 * g + 0]) & k0), dscale, -dd.x);
+          da[4 * g + 1] = e1 * fmaf(__uint_as_float(__float_as_uint(da[4 * g + 1]) & k1), dscale, -dd.y);
+          da[4 * g + 2] = e2 * fmaf(__uint_as_float(__float_as_uint(da[4 * g + 2]) & k2), dscale, -dd.z);
+          da[4 * g + 3] = e3 * fmaf(__uint_as_float(__float_as_uint(da[4 * g + 3]) & k3), dscale, -dd.w);
+        } else {
         float m0 = 1.f, m1 = 1.f, m2 = 1.f, m3 = 1.f;
         if (DROP) {
           // lane = key, registers walk the queries: one hash per element (its pair partner is the neighbouring key, i.e. the
@@ -361,6 +406,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
         da[4 * g + 1] = e1 * (m1 * da[4 * g + 1] - dd.y);
         da[4 * g + 2] = e2 * (m2 * da[4 * g + 2] - dd.z);
         da[4 * g + 3] = e3 * (m3 * da[4 * g + 3] - dd.w);
+        }
       }
       bf16x8 pf[2], df[2];
 #pragma unroll
@@ -399,7 +445,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
 
   // ---- epilogue: lane holds key k0 + l31, d = 32 dblk + (r&3) + 8 (r>>2) + 4 hh ; padded keys get zeros
   if (key < T) {
-    const float sk = key < len ? 0.125f : 0.f, sv = key < len ? 1.f : 0.f;
+    const float sk = key < len ? 0.125f : 0.f, sv = key < len ? (DROP == 2 ? dscale : 1.f) : 0.f;
     const bool live = key < len;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -441,5 +487,29 @@ extern "C" int se_mhsa_bwd_bf16(const uint16_t* qkv, const uint16_t* ctx, const 
     hipLaunchKernelGGL((se::mhsa_bwd_dkv_kernel<2, 0>), grid, dim3(256), 0, st, qkv, d_ctx, lse, dvec, lengths, T, H, dqkv, 0u, 0u, 1.f);
     SE_LAUNCH_CHECK();
   }
+  return SE_OK;
+}
+
+// Backward with the dropout mask of dropmask.hip (se_mhsa_dropmask) instead of the in-kernel hash: mask_r query-major (dQ kernel), mask_c key-major
+// (dK / dV kernel).  Same mask and the same gradients up to where the 1 / (1 - p) factor is applied.
+extern "C" int se_mhsa_bwd_masked_bf16(const uint16_t* qkv, const uint16_t* ctx, const uint16_t* d_ctx, const float* lse, const int32_t* lengths,
+                                       int B, int T, int heads, uint16_t* dqkv, float* dvec, const uint32_t* mask_r, const uint32_t* mask_c,
+                                       float dropout_p, void* stream) {
+  SE_REQUIRE(qkv && ctx && d_ctx && lse && dqkv && dvec && mask_r && mask_c, "se_mhsa_bwd_masked_bf16: null argument");
+  SE_REQUIRE(B > 0 && B <= 65535 && T > 0 && heads > 0 && heads <= 65535, "se_mhsa_bwd_masked_bf16: bad shape B=%d T=%d heads=%d", B, T, heads);
+  SE_REQUIRE((((uintptr_t)mask_r | (uintptr_t)mask_c) % 16) == 0, "se_mhsa_bwd_masked_bf16: masks must be 16-B aligned");
+  const se::DropoutCfg d = se::make_dropout(dropout_p, 0);
+  SE_REQUIRE(d.thr16 != 0, "se_mhsa_bwd_masked_bf16: dropout_p must be > 0");
+  const int H = heads * se::kHD;
+  hipStream_t st = se::as_stream(stream);
+  dim3 grid((T + se::kAQ - 1) / se::kAQ, heads, B);
+  se::ProfScope prof(se::kProfMhsaBwd, 14.0 * B * (double)heads * T * (double)T * se::kHD, st);
+  const uintptr_t pr = (uintptr_t)mask_r, pc = (uintptr_t)mask_c;
+  hipLaunchKernelGGL((se::mhsa_bwd_dq_kernel<2, 2>), grid, dim3(256), 0, st, qkv, ctx, d_ctx, lse, lengths, T, H, dqkv, dvec, (uint32_t)(pr & 0xffffffffu),
+                     (uint32_t)(pr >> 32), d.scale);
+  SE_LAUNCH_CHECK();
+  hipLaunchKernelGGL((se::mhsa_bwd_dkv_kernel<2, 2>), grid, dim3(256), 0, st, qkv, d_ctx, lse, dvec, lengths, T, H, dqkv, (uint32_t)(pc & 0xffffffffu),
+                     (uint32_t)(pc >> 32), d.scale);
+  SE_LAUNCH_CHECK();
   return SE_OK;
 }

@@ -230,6 +230,35 @@ def bench_mhsa_peaked():
         print(f'mhsa peaked gain {gain:5.1f} [SE_AMD_MHSA_SPEC={os.environ.get("SE_AMD_MHSA_SPEC")}]: {ms*1e3:8.1f} us   rows that fall back {rows:6.3f}   waves that fall back {waves:6.3f}   finite {bool(torch.isfinite(ctx.float()).all())}', flush=True)
 
 
+def bench_mhsa_train():
+    """training-mode attention (dropout 0.1): the in-kernel hash against the bit matrices of csrc/dropmask.hip (generated once, read three times)"""
+    B, T, heads, p = 32, 1001, 12, 0.1
+    qkv = torch.randn(B * T, 3 * 768, device=dev).bfloat16()
+    d_o = torch.randn(B * T, 768, device=dev).bfloat16()
+    ctx = torch.empty(B * T, 768, device=dev, dtype=torch.bfloat16)
+    lse = torch.empty(B, heads, T, device=dev)
+    dqkv = torch.empty_like(qkv)
+    dvec = torch.empty_like(lse)
+    mr = torch.empty(lib.se_mhsa_dropmask_bytes(B, T, heads, 0) // 4, device=dev, dtype=torch.int32)
+    mc = torch.empty(lib.se_mhsa_dropmask_bytes(B, T, heads, 1) // 4, device=dev, dtype=torch.int32)
+    seed, site = 1234, 5
+    runs = {
+        'fwd, hashed': lambda: L.check(lib.se_mhsa_fwd_lse_bf16(L.ptr(qkv), None, B, T, heads, L.ptr(ctx), L.ptr(lse), p, seed, site, L.stream()), 'f'),
+        'fwd, no dropout': lambda: L.check(lib.se_mhsa_fwd_lse_bf16(L.ptr(qkv), None, B, T, heads, L.ptr(ctx), L.ptr(lse), 0.0, seed, site, L.stream()), 'f'),
+        'mask generator': lambda: L.check(lib.se_mhsa_dropmask(B, T, heads, p, seed, site, L.ptr(mr), L.ptr(mc), L.stream()), 'g'),
+        'fwd, bit matrix': lambda: L.check(lib.se_mhsa_fwd_lse_masked_bf16(L.ptr(qkv), None, B, T, heads, L.ptr(ctx), L.ptr(lse), L.ptr(mr), p, L.stream()), 'f'),
+        'bwd, hashed': lambda: L.check(lib.se_mhsa_bwd_bf16(L.ptr(qkv), L.ptr(ctx), L.ptr(d_o), L.ptr(lse), None, B, T, heads, L.ptr(dqkv), L.ptr(dvec),
+                                                            p, seed, site, L.stream()), 'b'),
+        'bwd, no dropout': lambda: L.check(lib.se_mhsa_bwd_bf16(L.ptr(qkv), L.ptr(ctx), L.ptr(d_o), L.ptr(lse), None, B, T, heads, L.ptr(dqkv), L.ptr(dvec),
+                                                                0.0, seed, site, L.stream()), 'b'),
+        'bwd, bit matrix': lambda: L.check(lib.se_mhsa_bwd_masked_bf16(L.ptr(qkv), L.ptr(ctx), L.ptr(d_o), L.ptr(lse), None, B, T, heads, L.ptr(dqkv),
+                                                                       L.ptr(dvec), L.ptr(mr), L.ptr(mc), p, L.stream()), 'b'),
+    }
+    runs['mask generator']()
+    for k, (mn, md) in interleaved(runs, rounds=3, iters=10).items():
+        print(f'mhsa train B={B} T={T} p={p}: {k:18s} {mn*1e3:8.1f} us (min) {md*1e3:8.1f} us (median)', flush=True)
+
+
 def interleaved(variants, rounds=7, iters=20):
     """cdna_hip_programming.md rule 24: N variants x M rounds interleaved in ONE process; prints min and median per variant"""
     import statistics
@@ -311,6 +340,8 @@ if __name__ == '__main__':
         bench_res24()
     if what in ('mhsa', 'all'):
         bench_mhsa()
+    if what in ('mhsa_train',):
+        bench_mhsa_train()
     if what in ('mhsa_peaked',):
         bench_mhsa_peaked()
     if what in ('stft', 'all'):

@@ -11,7 +11,8 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 constexpr int ITER = 4096;
 
 // mode bit 0: role A active; bit 1: role B active; VK = 0: v_fma_f32, 1: v_exp_f32; SAME = 1: both roles in EVERY wave (one interleaved stream)
-template <int VK, int SAME>
+// IND = 1: role A's MFMAs rotate over four independent accumulators (no back-to-back dependency); PRIO = 1: role B raises its priority (s_setprio 3)
+template <int VK, int SAME, int IND = 0, int PRIO = 0>
 __global__ __launch_bounds__(512) void k(float* out, unsigned long long* cyc, float seed, int mode, int nv) {
   const int wave = threadIdx.x >> 6;
   const bool roleA = SAME ? true : wave < 4, roleB = SAME ? true : wave >= 4;
@@ -25,9 +26,20 @@ __global__ __launch_bounds__(512) void k(float* out, unsigned long long* cyc, fl
 #pragma unroll
   for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(seed + i); b[i] = (__bf16)(seed - i); }
   const bool doA = roleA && (mode & 1), doB = roleB && (mode & 2);
+  f32x16 acc1 = acc, acc2 = acc, acc3 = acc;
+  if (PRIO == 1 && roleB && !SAME) __builtin_amdgcn_s_setprio(3);
+  if (PRIO == 2 && roleA && !SAME) __builtin_amdgcn_s_setprio(3);
   __syncthreads();
   const unsigned long long t0 = __builtin_amdgcn_s_memtime();
   if (doA && !doB) {
+    if (IND) {
+      for (int it = 0; it < ITER; it += 4) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc1, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc2, 0, 0, 0);
+        acc3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc3, 0, 0, 0);
+      }
+    } else
     for (int it = 0; it < ITER; ++it) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
   } else if (doB && !doA) {
     for (int it = 0; it < ITER; ++it) {
@@ -50,16 +62,16 @@ __global__ __launch_bounds__(512) void k(float* out, unsigned long long* cyc, fl
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) s += v[i] + acc[i];
+  for (int i = 0; i < 16; ++i) s += v[i] + acc[i] + acc1[i] + acc2[i] + acc3[i];
   out[blockIdx.x * 512 + threadIdx.x] = s;
   if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 8 + wave] = t1 - t0;
 }
 
-template <int VK, int SAME>
+template <int VK, int SAME, int IND = 0, int PRIO = 0>
 void run(const char* name, int mode, float* out, unsigned long long* cyc) {
-  hipLaunchKernelGGL((k<VK, SAME>), dim3(256), dim3(512), 0, 0, out, cyc, 0.5f, mode, 8);
+  hipLaunchKernelGGL((k<VK, SAME, IND, PRIO>), dim3(256), dim3(512), 0, 0, out, cyc, 0.5f, mode, 8);
   CHECK(hipDeviceSynchronize());
-  hipLaunchKernelGGL((k<VK, SAME>), dim3(256), dim3(512), 0, 0, out, cyc, 0.5f, mode, 8);
+  hipLaunchKernelGGL((k<VK, SAME, IND, PRIO>), dim3(256), dim3(512), 0, 0, out, cyc, 0.5f, mode, 8);
   CHECK(hipDeviceSynchronize());
   unsigned long long h[256 * 8];
   CHECK(hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost));
@@ -81,5 +93,12 @@ int main() {
   run<1, 0>("MFMA waves + v_exp waves on the same SIMDs", 3, out, cyc);
   run<0, 1>("every wave: 1 MFMA + 8 v_fma interleaved (2 waves / SIMD)", 3, out, cyc);
   run<1, 1>("every wave: 1 MFMA + 8 v_exp interleaved (2 waves / SIMD)", 3, out, cyc);
+  run<0, 0, 1, 0>("independent MFMAs (4 accumulators) alone", 1, out, cyc);
+  run<0, 0, 1, 0>("independent MFMAs + v_fma waves", 3, out, cyc);
+  run<1, 0, 1, 0>("independent MFMAs + v_exp waves", 3, out, cyc);
+  run<0, 0, 0, 1>("dependent MFMAs + v_fma waves at s_setprio 3", 3, out, cyc);
+  run<0, 0, 1, 1>("independent MFMAs + v_fma waves at s_setprio 3", 3, out, cyc);
+  run<1, 0, 1, 1>("independent MFMAs + v_exp waves at s_setprio 3", 3, out, cyc);
+  run<0, 0, 0, 2>("dependent MFMAs at s_setprio 3 + v_fma waves", 3, out, cyc);
   return 0;
 }
