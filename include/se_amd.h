@@ -331,6 +331,11 @@ int se_gemm_f32(const float* A, long lda, const float* W, long ldw, int w_kmajor
                 int M, int N, int K, int act, float alpha, float* C, long ldc, int batch_outer, int batch_inner, long strideA_outer,
                 long strideA_inner, long strideW_outer, long strideW_inner, long strideC_outer, long strideC_inner, void* stream);
 int se_softmax_rows_f32(float* scores, const int32_t* lengths, int B, int heads, int T, void* stream);
+/* Three-term bf16 split of an fp32 matrix (rows, cols) [row stride ld] for the "bf16x3" parity mode: x = x1 + x2 + r, x1 = bf16(x),
+ * x2 = bf16(x - x1).  out (rows, 3 Kp) bf16, Kp >= cols (zero padded), Kp % 8 == 0: which = 0 -> [x1 | x1 | x2] (activations),
+ * which = 1 -> [w1 | w2 | w1] (nn.Linear weights), so that se_gemm_bf16 on the two outputs with K = 3 Kp sums x1 w1 + x1 w2 + x2 w1 in its fp32
+ * accumulators: fp32-operand products to 3 . 2^-18 relative on the bf16 matrix pipe (runner.py:556-575 at the 1e-4 tolerance, 3 x the bf16 cost). */
+int se_split3_bf16(const float* x, long ld, int rows, int cols, int Kp, int which, uint16_t* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Backward building blocks (row E2 beyond the linear heads: autograd through TransformerSpecPredictionHead /

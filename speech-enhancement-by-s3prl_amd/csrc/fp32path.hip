@@ -10,7 +10,9 @@
 //   se_softmax_rows_f32  in-place masked row softmax of the score tensor (exact expf, fp32 sums; keys >= length get the reference's
 //                      additive -10000 before the maximum, i.e. exp() == 0 in fp32)
 // Throughput is not the point (a 10 s utterance through the 6-layer encoder takes tens of ms); the tile is a plain 64 x 64 x 16 LDS-staged loop.
+#include <algorithm>
 #include "common.h"
+#include "bf16.h"
 
 namespace se {
 
@@ -105,7 +107,48 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ S
   for (int j = lane; j < T; j += 64) s[j] *= inv;
 }
 
+// ---- three-term bf16 split ("bf16x3"): x = x1 + x2 + r with x1 = bf16(x), x2 = bf16(x - x1), |r| <= 2^-17 |x|.  A product of two fp32 numbers is
+// x1 w1 + x1 w2 + x2 w1 up to 3 . 2^-18 relative; with the three operand slices laid side by side along K the sum of the three products is ONE
+// bf16 GEMM of depth 3 K on the fast kernels (exact bf16 products, fp32 accumulation):  [x1 | x1 | x2] . [w1 | w2 | w1]^T.
+// which = 0: activation layout [x1 | x1 | x2], which = 1: weight layout [w1 | w2 | w1]; each slice Kp >= cols columns wide, zero padded.
+__global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x, long ld, int cols, int Kp, int which, uint16_t* __restrict__ out) {
+  const long row = blockIdx.y;
+  const float* xr = x + row * ld;
+  uint16_t* o = out + row * 3 * (long)Kp;
+  for (int c = (blockIdx.x * 256 + threadIdx.x) * 4; c < Kp; c += gridDim.x * 1024) {
+    uint16_t hi[4], mid[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float v = (c + j < cols) ? xr[c + j] : 0.f;
+      hi[j] = f2bf(v);
+      mid[j] = f2bf(v - bf2f(hi[j]));
+    }
+    const uint2 h = make_uint2((uint32_t)hi[0] | ((uint32_t)hi[1] << 16), (uint32_t)hi[2] | ((uint32_t)hi[3] << 16));
+    const uint2 m = make_uint2((uint32_t)mid[0] | ((uint32_t)mid[1] << 16), (uint32_t)mid[2] | ((uint32_t)mid[3] << 16));
+    *reinterpret_cast<uint2*>(o + c) = h;
+    *reinterpret_cast<uint2*>(o + Kp + c) = which ? m : h;
+    *reinterpret_cast<uint2*>(o + 2 * (long)Kp + c) = which ? h : m;
+  }
+}
+
 }  // namespace se
+
+extern "C" int se_split3_bf16(const float* x, long ld, int rows, int cols, int Kp, int which, uint16_t* out, void* stream) {
+  SE_REQUIRE(x && out && rows > 0 && cols > 0 && Kp >= cols && Kp % 8 == 0 && ld >= cols, "se_split3_bf16: bad argument (rows=%d cols=%d Kp=%d)", rows, cols, Kp);
+  SE_REQUIRE(rows <= 0x7fffffff / 2 && ((uintptr_t)out % 16) == 0, "se_split3_bf16: bad argument");
+  SE_REQUIRE(which == 0 || which == 1, "se_split3_bf16: which = 0 (activations) or 1 (weights)");
+  // grid.y is limited to 65 535: fold the rows
+  const long total_rows = rows;
+  const int gx = (Kp / 4 + 255) / 256;
+  long done = 0;
+  while (done < total_rows) {
+    const int n = (int)std::min<long>(65535, total_rows - done);
+    hipLaunchKernelGGL(se::split3_kernel, dim3(gx, n), dim3(256), 0, se::as_stream(stream), x + done * ld, ld, cols, Kp, which, out + done * 3 * (long)Kp);
+    SE_LAUNCH_CHECK();
+    done += n;
+  }
+  return SE_OK;
+}
 
 extern "C" int se_gemm_f32(const float* A, long lda, const float* W, long ldw, int w_kmajor, const float* bias, const float* residual, int res_mod,
                            int M, int N, int K, int act, float alpha, float* C, long ldc, int batch_outer, int batch_inner, long strideA_outer,

@@ -110,8 +110,9 @@ class TransformerSpecPredictionHead(nn.Module):
         return torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
 
     def set_precision(self, precision):
-        """'bf16' (default: MFMA bf16 operands, fp32 sums) or 'fp32' (exact-fp32 parity mode, inference only)."""
-        assert precision in ('bf16', 'fp32')
+        """'bf16' (default: MFMA bf16 operands, fp32 sums), 'fp32' (exact-fp32 parity mode) or 'bf16x3' (three-term split parity mode); the last
+        two are inference only."""
+        assert precision in ('bf16', 'fp32', 'bf16x3')
         self._engine.precision = precision
         return self
 
@@ -443,6 +444,105 @@ class _Engine:
             x = self._ln32(o, layer.output.LayerNorm, M, H)
         return x.view(B, T, H)
 
+    # ---- three-term split parity mode: nn.Linear layers as bf16 GEMMs of depth 3 K over [x1 | x1 | x2] . [w1 | w2 | w1]^T (se_split3_bf16)
+    def _w3(self, weight):
+        """cached weight split (N, 3 Kp) bf16 of an nn.Linear weight (or a row-concatenation of several), re-made when a parameter changes"""
+        ws = weight if isinstance(weight, (tuple, list)) else (weight,)
+        key = tuple(id(t) for t in ws)
+        ver = tuple(t._version for t in ws) + (ws[0].device,)
+        cache = self.__dict__.setdefault('_w3_cache', {})
+        hit = cache.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1], hit[2]
+        lib = _lib.load()
+        w = torch.cat([t.detach().float() for t in ws], dim=0).contiguous() if len(ws) > 1 else ws[0].detach().float().contiguous()
+        N, K = w.shape
+        Kp = (K + 63) // 64 * 64
+        out = torch.empty(N, 3 * Kp, device=w.device, dtype=torch.bfloat16)
+        _lib.check(lib.se_split3_bf16(_lib.ptr(w), K, N, K, Kp, 1, _lib.ptr(out), _lib.stream()), 'se_split3_bf16')
+        cache[key] = (ver, out, Kp)
+        return out, Kp
+
+    def _linear3(self, x, weight, bias, M, N, K, act=0, residual=None, out=None):
+        """out (M, N) fp32 = act(x W^T + bias) [+ residual] with both operands split in three bf16 terms; x (M, K) fp32 contiguous"""
+        lib = _lib.load()
+        w3, Kp = self._w3(weight)
+        a3 = torch.empty(M, 3 * Kp, device=x.device, dtype=torch.bfloat16)
+        _lib.check(lib.se_split3_bf16(_lib.ptr(x), K, M, K, Kp, 0, _lib.ptr(a3), _lib.stream()), 'se_split3_bf16')
+        if out is None:
+            out = torch.empty(M, N, device=x.device, dtype=torch.float32)
+        _lib.check(lib.se_gemm_bf16(_lib.ptr(a3), 3 * Kp, _lib.ptr(w3), 3 * Kp, _lib.ptr(bias), _lib.ptr(residual), M, N, 3 * Kp, int(act), None, _lib.ptr(out), N,
+                                    _lib.stream()), 'se_gemm_bf16')
+        return out
+
+    def encode_x3(self, model, feats, lengths=None):
+        """rows B1-B3 at the 1e-4 tolerance on the bf16 matrix pipe: the chain of encode_fp32 with every nn.Linear through _linear3 (Q, K, V as one
+        projection of width 3 H) and the attention core (scores, softmax, P V) in exact fp32 as there."""
+        if not feats.is_cuda:
+            raise _lib.SEError('TRANSFORMER runs on MI355X only (no CPU fallback): move the module and inputs to the GPU')
+        lib = _lib.load()
+        cfg = model.config
+        feats = feats.contiguous().float()
+        B, T, D = feats.shape
+        H, heads, I = cfg.hidden_size, cfg.num_attention_heads, cfg.intermediate_size
+        dev = feats.device
+        if H != heads * 64:
+            raise NotImplementedError('head dim must be 64')
+        if lengths is None:
+            lengths = torch.empty(B, device=dev, dtype=torch.int32)
+            _lib.check(lib.se_valid_lengths_i32(_lib.ptr(feats), B, T, D, _lib.ptr(lengths), _lib.stream()), 'se_valid_lengths_i32')
+        M = B * T
+        pe = getattr(self, '_pe32x', None)
+        if pe is None or pe.shape != (M, H) or pe.device != dev:
+            pos = torch.arange(T, dtype=torch.float64)[:, None]
+            j = torch.arange(H, dtype=torch.float64)[None, :]
+            ang = pos / torch.pow(torch.tensor(10000.0, dtype=torch.float64), 2.0 * torch.floor(j / 2.0) / H)
+            tab = torch.where((torch.arange(H) % 2 == 0)[None, :], torch.sin(ang), torch.cos(ang))
+            pe = self._pe32x = tab.float().to(dev).repeat(B, 1).contiguous()      # (B T, H): the GEMM's residual operand is per output row
+        ir = model.input_representations
+        w = lambda p: p.detach().contiguous()       # noqa: E731
+        x = self._linear3(feats.view(M, D), ir.spec_transform.weight, w(ir.spec_transform.bias), M, H, D, residual=pe)
+        x = self._ln32(x, ir.LayerNorm, M, H)
+        scores = torch.empty(B, heads, T, T, device=dev, dtype=torch.float32)
+        qkv = torch.empty(M, 3 * H, device=dev, dtype=torch.float32)
+        ctx = torch.empty(M, H, device=dev, dtype=torch.float32)
+        for layer in model.encoder.layer:
+            att = layer.attention
+            qb = torch.cat([att.self.query.bias.detach(), att.self.key.bias.detach(), att.self.value.bias.detach()]).float().contiguous()
+            self._linear3(x, (att.self.query.weight, att.self.key.weight, att.self.value.weight), qb, M, 3 * H, H, out=qkv)
+            q, k, v = qkv[:, 0:H], qkv[:, H:2 * H], qkv[:, 2 * H:]
+            # scores[b, h] = Q_bh K_bh^T / sqrt(64): batched over (utterance, head): row stride 3 H, utterance stride T 3 H, head stride 64
+            self._gemm32(q, k, None, T, T, 64, alpha=0.125, out=scores, lda=3 * H, ldw=3 * H, ldc=T, batch=(B, heads),
+                         strides=(T * 3 * H, 64, T * 3 * H, 64, heads * T * T, T * T))
+            _lib.check(lib.se_softmax_rows_f32(_lib.ptr(scores), _lib.ptr(lengths), B, heads, T, _lib.stream()), 'se_softmax_rows_f32')
+            self._gemm32(scores, v, None, T, 64, T, out=ctx, lda=T, ldw=3 * H, ldc=H, w_kmajor=1, batch=(B, heads),
+                         strides=(heads * T * T, T * T, T * 3 * H, 64, T * H, 64))
+            a = self._linear3(ctx, att.output.dense.weight, w(att.output.dense.bias), M, H, H, residual=x)
+            x = self._ln32(a, att.output.LayerNorm, M, H)
+            h = self._linear3(x, layer.intermediate.dense.weight, w(layer.intermediate.dense.bias), M, I, H, act=_lib.SE_ACT['GELU'])
+            o = self._linear3(h, layer.output.dense.weight, w(layer.output.dense.bias), M, H, I, residual=x)
+            x = self._ln32(o, layer.output.LayerNorm, M, H)
+        return x.view(B, T, H)
+
+    def spechead_x3(self, head, hidden, mode='raw', log_target=False, act='ReLU', eps=1e-6):
+        """row B4 with the three-term split linears (see spechead_fp32)"""
+        if not hidden.is_cuda:
+            raise _lib.SEError('TransformerSpecPredictionHead runs on MI355X only (no CPU fallback)')
+        lib = _lib.load()
+        hidden = hidden.contiguous().float()
+        B, T, H = hidden.shape
+        M, N = B * T, head.output.out_features
+        w = lambda p: p.detach().contiguous()       # noqa: E731
+        h = self._linear3(hidden.view(M, H), head.dense.weight, w(head.dense.bias), M, H, H, act=_lib.SE_ACT['GELU'])
+        h = self._ln32(h, head.LayerNorm, M, H)
+        raw = self._linear3(h, head.output.weight, w(head.output.bias), M, N, H).view(B, T, N)
+        if mode == 'raw':
+            return raw
+        pred, logp = torch.empty_like(raw), torch.empty_like(raw)
+        _lib.check(lib.se_spec_epilogue_f32(_lib.ptr(raw), raw.numel(), int(bool(log_target)), _lib.SE_ACT[act], float(eps), _lib.ptr(pred), _lib.ptr(logp),
+                                            _lib.stream()), 'se_spec_epilogue_f32')
+        return pred, logp
+
     def spechead_fp32(self, head, hidden, mode='raw', log_target=False, act='ReLU', eps=1e-6):
         """row B4 in exact fp32: dense -> erf-GELU -> LayerNorm -> output linear (-> exp / log / activation epilogue)."""
         if not hidden.is_cuda:
@@ -465,6 +565,8 @@ class _Engine:
     def encode(self, model, head, feats, lengths=None):
         if self.precision == 'fp32':
             return self.encode_fp32(model, feats, lengths)
+        if self.precision == 'bf16x3':
+            return self.encode_x3(model, feats, lengths)
         if not feats.is_cuda:
             raise _lib.SEError('TRANSFORMER runs on MI355X only (no CPU fallback): move the module and inputs to the GPU')
         lib = _lib.load()
@@ -505,6 +607,8 @@ class _Engine:
     def spechead(self, head, model, hidden, mode='raw', log_target=False, act='ReLU', eps=1e-6):
         if self.precision == 'fp32':
             return self.spechead_fp32(head, hidden, mode=mode, log_target=log_target, act=act, eps=eps)
+        if self.precision == 'bf16x3':
+            return self.spechead_x3(head, hidden, mode=mode, log_target=log_target, act=act, eps=eps)
         if not hidden.is_cuda:
             raise _lib.SEError('TransformerSpecPredictionHead runs on MI355X only (no CPU fallback)')
         lib = _lib.load()
@@ -584,9 +688,10 @@ class TRANSFORMER(nn.Module):
 
     def set_precision(self, precision):
         """'bf16' (default; BASELINE.json's configuration) or 'fp32': the exact-fp32 parity mode of the inference forward (1e-4 on enhanced
-        magnitudes against the reference's fp32 path; ~16x the matrix time, for verification rather than serving).  Also switches an
-        attached `SpecHead` (run_downstream.py:185)."""
-        assert precision in ('bf16', 'fp32')
+        magnitudes against the reference's fp32 path; ~16x the matrix time, for verification rather than serving), or 'bf16x3': the same
+        tolerance with every nn.Linear as ONE bf16 GEMM over three-term splits of both operands (x1 w1 + x1 w2 + x2 w1, se_split3_bf16: 3 x the
+        bf16 matrix time) and the attention core in exact fp32.  Also switches an attached `SpecHead` (run_downstream.py:185)."""
+        assert precision in ('bf16', 'fp32', 'bf16x3')
         self._engine.precision = precision
         sh = getattr(self, 'SpecHead', None)
         if sh is not None and hasattr(sh, 'spechead'):
@@ -595,8 +700,8 @@ class TRANSFORMER(nn.Module):
 
     def forward(self, x):
         train = torch.is_grad_enabled() and not self.no_grad and any(p.requires_grad for p in self.model.parameters())
-        if train and self._engine.precision == 'fp32':
-            raise NotImplementedError("precision 'fp32' is the inference parity mode; training runs the bf16 kernels")
+        if train and self._engine.precision != 'bf16':
+            raise NotImplementedError("precisions 'fp32' / 'bf16x3' are the inference parity modes; training runs the bf16 kernels")
         dropout_p = self.model_config.hidden_dropout_prob if self.training else 0.0
         if dropout_p > 0:
             if self.model_config.attention_probs_dropout_prob != dropout_p:
