@@ -241,7 +241,7 @@ def extras_leg(args, w, dev, out):
         r['note'] = ("TRANSFORMER.set_precision('fp32'): fp32 operands / products / sums on v_mfma_f32_32x32x2_f32 (1/16 of the bf16 matrix rate), the rate at "
                      'which the stated 1e-4 tolerance holds; not the headline value')
         out['fp32_parity_mode'] = r
-        # the same tolerance on the bf16 matrix pipe: every nn.Linear as one bf16 GEMM over three-term operand splits, attention core in fp32
+        # the same tolerance on the bf16 matrix pipe: every nn.Linear as one bf16 GEMM over three-term operand splits, flash attention on two-term splits
         up.set_precision('bf16x3')
         try:
             r3 = rate(w['step'], 8, 5, warm=1)
@@ -249,8 +249,8 @@ def extras_leg(args, w, dev, out):
         finally:
             up.set_precision('bf16')
         r3['note'] = ("TRANSFORMER.set_precision('bf16x3'): x1 w1 + x1 w2 + x2 w1 of the bf16 splits x = x1 + x2 (+ 2^-17) as ONE GEMM of depth 3 K per "
-                      'nn.Linear (se_split3_bf16 + se_gemm_bf16), scores / softmax / P V in exact fp32; meets the same 1e-4 test '
-                      '(tests/test_gpu_encoder_fp32.py: enhanced magnitudes 7e-6); not the headline value')
+                      'nn.Linear (se_split3_bf16 + se_gemm_bf16), attention as a flash kernel on two-term splits of Q, K, V, P with an exact fp32 online '
+                      'softmax (se_mhsa_fwd_x3_f32); meets the same 1e-4 test (tests/test_gpu_encoder_fp32.py: enhanced magnitudes 7e-6); not the headline value')
         if r3b is not None:
             r3['at_bench_batch'] = r3b
         out['bf16x3_parity_mode'] = r3

@@ -336,6 +336,10 @@ int se_softmax_rows_f32(float* scores, const int32_t* lengths, int B, int heads,
  * which = 1 -> [w1 | w2 | w1] (nn.Linear weights), so that se_gemm_bf16 on the two outputs with K = 3 Kp sums x1 w1 + x1 w2 + x2 w1 in its fp32
  * accumulators: fp32-operand products to 3 . 2^-18 relative on the bf16 matrix pipe (runner.py:556-575 at the 1e-4 tolerance, 3 x the bf16 cost). */
 int se_split3_bf16(const float* x, long ld, int rows, int cols, int Kp, int which, uint16_t* out, void* stream);
+/* The attention core of the same mode (csrc/mhsa_x3.hip): ctx (B*T, H) fp32 = softmax(Q K^T / 8 + pad mask) V from the fp32 fused projection
+ * qkv (B*T, 3H) = [Q | K | V], flash style on the bf16 matrix pipe with two-term splits of Q, K, V and P (three products each); replaces the
+ * materialised scores of the fp32 mode (se_gemm_f32 batched + se_softmax_rows_f32).  heads of 64; buffers 16-B aligned. */
+int se_mhsa_fwd_x3_f32(const float* qkv, const int32_t* lengths, int B, int T, int heads, float* ctx, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Backward building blocks (row E2 beyond the linear heads: autograd through TransformerSpecPredictionHead /

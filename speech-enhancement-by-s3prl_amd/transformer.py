@@ -477,7 +477,7 @@ class _Engine:
 
     def encode_x3(self, model, feats, lengths=None):
         """rows B1-B3 at the 1e-4 tolerance on the bf16 matrix pipe: the chain of encode_fp32 with every nn.Linear through _linear3 (Q, K, V as one
-        projection of width 3 H) and the attention core (scores, softmax, P V) in exact fp32 as there."""
+        projection of width 3 H) and the attention core as a flash kernel on two-term splits of Q, K, V and P (se_mhsa_fwd_x3_f32)."""
         if not feats.is_cuda:
             raise _lib.SEError('TRANSFORMER runs on MI355X only (no CPU fallback): move the module and inputs to the GPU')
         lib = _lib.load()
@@ -503,20 +503,14 @@ class _Engine:
         w = lambda p: p.detach().contiguous()       # noqa: E731
         x = self._linear3(feats.view(M, D), ir.spec_transform.weight, w(ir.spec_transform.bias), M, H, D, residual=pe)
         x = self._ln32(x, ir.LayerNorm, M, H)
-        scores = torch.empty(B, heads, T, T, device=dev, dtype=torch.float32)
         qkv = torch.empty(M, 3 * H, device=dev, dtype=torch.float32)
         ctx = torch.empty(M, H, device=dev, dtype=torch.float32)
         for layer in model.encoder.layer:
             att = layer.attention
             qb = torch.cat([att.self.query.bias.detach(), att.self.key.bias.detach(), att.self.value.bias.detach()]).float().contiguous()
             self._linear3(x, (att.self.query.weight, att.self.key.weight, att.self.value.weight), qb, M, 3 * H, H, out=qkv)
-            q, k, v = qkv[:, 0:H], qkv[:, H:2 * H], qkv[:, 2 * H:]
-            # scores[b, h] = Q_bh K_bh^T / sqrt(64): batched over (utterance, head): row stride 3 H, utterance stride T 3 H, head stride 64
-            self._gemm32(q, k, None, T, T, 64, alpha=0.125, out=scores, lda=3 * H, ldw=3 * H, ldc=T, batch=(B, heads),
-                         strides=(T * 3 * H, 64, T * 3 * H, 64, heads * T * T, T * T))
-            _lib.check(lib.se_softmax_rows_f32(_lib.ptr(scores), _lib.ptr(lengths), B, heads, T, _lib.stream()), 'se_softmax_rows_f32')
-            self._gemm32(scores, v, None, T, 64, T, out=ctx, lda=T, ldw=3 * H, ldc=H, w_kmajor=1, batch=(B, heads),
-                         strides=(heads * T * T, T * T, T * 3 * H, 64, T * H, 64))
+            # flash attention on two-term splits of Q, K, V and P (csrc/mhsa_x3.hip): no (B, heads, T, T) score tensor
+            _lib.check(lib.se_mhsa_fwd_x3_f32(_lib.ptr(qkv), _lib.ptr(lengths), B, T, heads, _lib.ptr(ctx), _lib.stream()), 'se_mhsa_fwd_x3_f32')
             a = self._linear3(ctx, att.output.dense.weight, w(att.output.dense.bias), M, H, H, residual=x)
             x = self._ln32(a, att.output.LayerNorm, M, H)
             h = self._linear3(x, layer.intermediate.dense.weight, w(layer.intermediate.dense.bias), M, I, H, act=_lib.SE_ACT['GELU'])

@@ -135,3 +135,26 @@ def test_split3_terms_reconstruct_the_operand(gpu):
         assert (out[:, cols:Kp] == 0).all() and (out[:, Kp + cols:2 * Kp] == 0).all() and (out[:, 2 * Kp + cols:] == 0).all()
         err = ((hi + mid)[:, :cols].double() - x.double()).abs() / x.double().abs()
         assert err.max().item() < 2.0 ** -16
+
+
+@pytest.mark.parametrize('B,T,heads,lens', [(2, 333, 3, [333, 130]), (1, 1001, 2, None), (3, 64, 1, [64, 1, 33]), (1, 129, 12, [77])])
+def test_mhsa_x3_vs_fp64(gpu, B, T, heads, lens):
+    """se_mhsa_fwd_x3_f32 (two-term operand splits, three products each, exact online softmax) against fp64 attention with the reference's
+    additive -10000 on padded keys: 3e-5 of the largest context value (the split drops 2^-18-relative product terms)"""
+    from speech_enhancement_by_s3prl_amd import _lib as L
+    lib = L.load()
+    torch.manual_seed(T + heads)
+    H = 64 * heads
+    qkv = torch.randn(B * T, 3 * H, device=gpu) * 1.7
+    lengths = torch.tensor(lens if lens else [T] * B, device=gpu, dtype=torch.int32)
+    ctx = torch.full((B * T, H), float('nan'), device=gpu)
+    L.check(lib.se_mhsa_fwd_x3_f32(L.ptr(qkv), L.ptr(lengths), B, T, heads, L.ptr(ctx), L.stream()), 'mhsa_x3')
+    x = qkv.double().reshape(B, T, 3, heads, 64)
+    q, k, v = x[:, :, 0].transpose(1, 2), x[:, :, 1].transpose(1, 2), x[:, :, 2].transpose(1, 2)
+    s = q @ k.transpose(-1, -2) / 8.0
+    pad = (torch.arange(T, device=gpu)[None, :] >= lengths[:, None]).double() * -10000.0
+    p = torch.softmax(s + pad[:, None, None, :], dim=-1)
+    ref = (p @ v).transpose(1, 2).reshape(B * T, H)
+    assert torch.isfinite(ctx).all()
+    err = (ctx.double() - ref).abs().max().item() / ref.abs().max().item()
+    bounded(f'mhsa_x3[{B},{T},{heads}] context max-norm', err, 3e-5)
