@@ -90,7 +90,9 @@ def cpu_baseline(batch, layers, seconds_budget=25.0):
                       f'{dt:.2f} s per batch on {cpu_name}'}
 
 
-PMC_FILE = os.path.join(ROOT, 'profiles', 'r02_pmc_fetch_write.json')
+# committed counter passes (tools/collect_profiles.sh), one file per workload: bench.py cannot run counter passes on itself
+PMC_FILES = {'enhance': 'r03_pmc_fetch_write.json', 'finetune': 'r03_pmc_fetch_write_finetune.json',
+             'head:mel120': 'r03_pmc_fetch_write_head_mel120.json', 'head:linear201': 'r03_pmc_fetch_write_head_linear201.json'}
 
 
 # every kernel the prof family 'gemm_bf16' times (csrc/gemm*.hip): the traffic figure is the launch-weighted mean over the same launches
@@ -98,15 +100,15 @@ GEMM_KERNELS = ('gemm2_bf16_kernel', 'gemm3_bf16_kernel', 'gemm4_res_ln_kernel',
                 'gemm8_res24_ln_kernel', 'gemm5_bf16_kernel')
 
 
-def pmc_traffic(substrings):
+def pmc_traffic(substrings, which='enhance'):
     """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes of this same command (separate
     `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs, KB per dispatch; bench.py cannot run counter passes on itself).
     gfx950 correction (MI355X_MICROARCH.md, HBM / rocprofv3): FETCH_SIZE tallies 128-B requests at 64 B for 16-B-per-lane
     streams, so it is doubled; WRITE_SIZE is exact.  Returns None when the file is absent."""
     try:
-        with open(PMC_FILE) as fh:
+        with open(os.path.join(ROOT, 'profiles', PMC_FILES[which])) as fh:
             d = json.load(fh)
-    except (OSError, ValueError):
+    except (OSError, ValueError, KeyError):
         return None
     tot, n = 0.0, 0
     for name, v in d.items():
@@ -481,8 +483,10 @@ def roofline_report(args, lib, out):
     if args.workload == 'head':
         # HBM-bound pass: the dominant kernel is the two-channel STFT launch
         e = hbm_entry('stft') or {}
-        out['roofline'] = dict(e, kernel='stft_kernel', traffic=None,
-                               traffic_unit='HBM bytes per launch from PMC passes (none committed for this workload yet)')
+        which = 'head:' + args.head_feat
+        traffic = pmc_traffic(('stft_kernel',), which) if args.batch == 256 and not args.graph else None
+        out['roofline'] = dict(e, kernel='stft_kernel', traffic=traffic,
+                               traffic_unit='HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, committed PMC passes: profiles/' + PMC_FILES[which] + ')')
         for name in ('istft', 'head'):
             e = hbm_entry(name)
             if e:
@@ -492,11 +496,11 @@ def roofline_report(args, lib, out):
     g_ms, g_flop, g_n = fam['gemm_bf16']
     achieved = g_flop / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
     # the committed PMC passes are of the default command: report them only when this run is that command
-    pmc_matches = (args.workload == 'enhance' and args.batch == 32 and args.layers == 6 and args.streams == 1 and not args.graph)
-    traffic = pmc_traffic(GEMM_KERNELS) if pmc_matches else None
+    pmc_matches = (args.workload in ('enhance', 'finetune') and args.batch == 32 and args.layers == 6 and args.streams == 1 and not args.graph)
+    traffic = pmc_traffic(GEMM_KERNELS, args.workload) if pmc_matches else None
     out['roofline'] = {'bound': 'mfma', 'kernel': 'gemm_bf16_kernel', 'achieved': achieved, 'peak': MFMA_BF16_PEAK_TFLOPS,
                        'unit': 'TFLOP/s', 'frac': achieved / MFMA_BF16_PEAK_TFLOPS, 'traffic': traffic,
-                       'traffic_unit': 'HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, committed PMC passes: profiles/' + os.path.basename(PMC_FILE) +
+                       'traffic_unit': 'HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, committed PMC passes: profiles/' + PMC_FILES.get(args.workload, '-') +
                                        '); counts L2 misses incl. Infinity-Cache hits: ~1.45x the algorithmic bytes of these launches',
                        'launches': g_n, 'avg_launch_ms': g_ms / max(g_n, 1),
                        'algorithmic_flop_per_launch': g_flop / max(g_n, 1)}

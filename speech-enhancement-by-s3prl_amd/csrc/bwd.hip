@@ -398,9 +398,9 @@ int se::launch_layernorm_bwd(const float* x_in, const float* pe, int T, const fl
   const int groups = group_rows ? (M + group_rows - 1) / group_rows : 1;
   SE_REQUIRE(groups <= 65535, "layernorm backward: %d groups exceed grid.y", groups);
   if (!accumulate) {
-    if (dgamma) { const int zrc_ = se::zero_async(dgamma, sizeof(float) * H * groups, st); if (zrc_) return zrc_; }
-    if (dbeta) { const int zrc_ = se::zero_async(dbeta, sizeof(float) * H * groups, st); if (zrc_) return zrc_; }
-    if (dbias) { const int zrc_ = se::zero_async(dbias, sizeof(float) * H * groups, st); if (zrc_) return zrc_; }
+    const size_t zb = sizeof(float) * (size_t)H * groups;
+    const int zrc_ = se::zero_async3(dgamma, zb, dbeta, zb, dbias, zb, st);
+    if (zrc_) return zrc_;
   }
   const int rows_per_wave = 16;
   const dim3 grid(((group_rows ? group_rows : M) + 4 * rows_per_wave - 1) / (4 * rows_per_wave), groups);

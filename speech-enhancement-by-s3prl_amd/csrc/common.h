@@ -18,6 +18,7 @@ inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s);
 
 // clears a device buffer with a kernel (graph-capture safe; see zero.hip)
 int zero_async(void* ptr, size_t bytes, hipStream_t st);
+int zero_async3(void* p0, size_t b0, void* p1, size_t b1, void* p2, size_t b2, hipStream_t st);
 
 }  // namespace se
 

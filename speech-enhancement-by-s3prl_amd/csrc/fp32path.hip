@@ -111,23 +111,34 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ S
 // x1 w1 + x1 w2 + x2 w1 up to 3 . 2^-18 relative; with the three operand slices laid side by side along K the sum of the three products is ONE
 // bf16 GEMM of depth 3 K on the fast kernels (exact bf16 products, fp32 accumulation):  [x1 | x1 | x2] . [w1 | w2 | w1]^T.
 // which = 0: activation layout [x1 | x1 | x2], which = 1: weight layout [w1 | w2 | w1]; each slice Kp >= cols columns wide, zero padded.
-__global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x, long ld, int cols, int Kp, int which, uint16_t* __restrict__ out) {
-  const long row = blockIdx.y;
-  const float* xr = x + row * ld;
-  uint16_t* o = out + row * 3 * (long)Kp;
-  for (int c = (blockIdx.x * 256 + threadIdx.x) * 4; c < Kp; c += gridDim.x * 1024) {
-    uint16_t hi[4], mid[4];
+template <int VEC>
+__global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x, long ld, int rows, int cols, int Kp, int which, uint16_t* __restrict__ out) {
+  // one thread = 8 columns of one row (two 16-B loads when VEC: ld and cols multiples of 4, base 16-B aligned; three 16-B stores)
+  const int cpr = Kp >> 3;                                       // 8-column chunks per row
+  const long total = (long)rows * cpr;
+  for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += gridDim.x * 256L) {
+    const long row = idx / cpr;
+    const int c = (int)(idx - row * cpr) * 8;
+    const float* xr = x + row * ld;
+    uint16_t* o = out + row * 3 * (long)Kp;
+    float v[8];
+    if (VEC && c + 8 <= cols) {
+      const float4 a = *reinterpret_cast<const float4*>(xr + c), b = *reinterpret_cast<const float4*>(xr + c + 4);
+      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float v = (c + j < cols) ? xr[c + j] : 0.f;
-      hi[j] = f2bf(v);
-      mid[j] = f2bf(v - bf2f(hi[j]));
+      for (int j = 0; j < 8; ++j) v[j] = (c + j < cols) ? xr[c + j] : 0.f;
     }
-    const uint2 h = make_uint2((uint32_t)hi[0] | ((uint32_t)hi[1] << 16), (uint32_t)hi[2] | ((uint32_t)hi[3] << 16));
-    const uint2 m = make_uint2((uint32_t)mid[0] | ((uint32_t)mid[1] << 16), (uint32_t)mid[2] | ((uint32_t)mid[3] << 16));
-    *reinterpret_cast<uint2*>(o + c) = h;
-    *reinterpret_cast<uint2*>(o + Kp + c) = which ? m : h;
-    *reinterpret_cast<uint2*>(o + 2 * (long)Kp + c) = which ? h : m;
+    bf16x8 hi, mid;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const __bf16 h = (__bf16)v[j];
+      hi[j] = h;
+      mid[j] = (__bf16)(v[j] - (float)h);
+    }
+    *reinterpret_cast<bf16x8*>(o + c) = hi;
+    *reinterpret_cast<bf16x8*>(o + Kp + c) = which ? mid : hi;
+    *reinterpret_cast<bf16x8*>(o + 2 * (long)Kp + c) = which ? hi : mid;
   }
 }
 
@@ -137,16 +148,14 @@ extern "C" int se_split3_bf16(const float* x, long ld, int rows, int cols, int K
   SE_REQUIRE(x && out && rows > 0 && cols > 0 && Kp >= cols && Kp % 8 == 0 && ld >= cols, "se_split3_bf16: bad argument (rows=%d cols=%d Kp=%d)", rows, cols, Kp);
   SE_REQUIRE(rows <= 0x7fffffff / 2 && ((uintptr_t)out % 16) == 0, "se_split3_bf16: bad argument");
   SE_REQUIRE(which == 0 || which == 1, "se_split3_bf16: which = 0 (activations) or 1 (weights)");
-  // grid.y is limited to 65 535: fold the rows
-  const long total_rows = rows;
-  const int gx = (Kp / 4 + 255) / 256;
-  long done = 0;
-  while (done < total_rows) {
-    const int n = (int)std::min<long>(65535, total_rows - done);
-    hipLaunchKernelGGL(se::split3_kernel, dim3(gx, n), dim3(256), 0, se::as_stream(stream), x + done * ld, ld, cols, Kp, which, out + done * 3 * (long)Kp);
-    SE_LAUNCH_CHECK();
-    done += n;
-  }
+  const bool vec = (ld % 4 == 0) && (cols % 4 == 0) && (((uintptr_t)x) % 16 == 0);
+  const long total = (long)rows * (Kp / 8);
+  const unsigned grid = (unsigned)std::min<long>((total + 255) / 256, 1 << 20);
+  if (vec)
+    hipLaunchKernelGGL(se::split3_kernel<1>, dim3(grid), dim3(256), 0, se::as_stream(stream), x, ld, rows, cols, Kp, which, out);
+  else
+    hipLaunchKernelGGL(se::split3_kernel<0>, dim3(grid), dim3(256), 0, se::as_stream(stream), x, ld, rows, cols, Kp, which, out);
+  SE_LAUNCH_CHECK();
   return SE_OK;
 }
 

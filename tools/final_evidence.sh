@@ -11,9 +11,13 @@ cd "$root"
 python3 -m pytest tests -m gpu -x -q > "$out/pytest_gpu.log" 2>&1 || { tail -30 "$out/pytest_gpu.log"; exit 1; }
 tail -3 "$out/pytest_gpu.log"
 tools/collect_profiles.sh $tag
+tools/collect_profiles.sh $tag _head_mel120 --workload head --head-feat mel120
+tools/collect_profiles.sh $tag _head_linear201 --workload head --head-feat linear201
+tools/collect_profiles.sh $tag _finetune --workload finetune
 cd "$root"
-python3 bench.py --workload finetune --no-cpu-baseline > "$out/${tag}_finetune_bench.json" 2> "$out/ft.err"
 python3 bench.py --workload lstm --no-cpu-baseline > "$out/${tag}_lstm_bench.json" 2> "$out/lstm.err"
+python3 tools/bench_kernels.py mhsa_train > "$out/${tag}_mhsa_train.txt" 2>&1
+python3 tools/bench_kernels.py mhsa_peaked > "$out/${tag}_mhsa_peaked.txt" 2>&1
 python3 tools/bench_kernels.py all > "$out/${tag}_bench_kernels.txt" 2>&1
 python3 tools/bench_kernels.py hbm >> "$out/${tag}_bench_kernels.txt" 2>&1
 SE_AMD_GEMM_SMALL_M=0 python3 tools/bench_kernels.py square >> "$out/${tag}_bench_kernels.txt" 2>&1
