@@ -1,18 +1,24 @@
 #!/bin/bash
 # Round-end evidence run on the GPU box (everything under gpurun_out/<tag>/): full GPU test-suite, the profile set of
 # tools/collect_profiles.sh, the side workloads' bench lines, per-kernel SQ / matrix-pipe counter passes, the micro-benchmarks.
-#   tools/final_evidence.sh r02b
+#   tools/final_evidence.sh r02b [part]      part 1: tests + the enhance / head profile sets, part 2: the rest (default: both; one gpurun call
+#                                            is limited to 20 minutes)
 set -e
 tag=$1
+part=${2:-0}
 root=$(cd "$(dirname "$0")/.." && pwd)
 out=$root/gpurun_out/$tag
 mkdir -p "$out"
 cd "$root"
+if [ "$part" != 2 ]; then
 python3 -m pytest tests -m gpu -x -q > "$out/pytest_gpu.log" 2>&1 || { tail -30 "$out/pytest_gpu.log"; exit 1; }
 tail -3 "$out/pytest_gpu.log"
+cp gpurun_out/parity_measured.txt "$out/${tag}_parity_measured.txt" 2>/dev/null || true
 tools/collect_profiles.sh $tag
 tools/collect_profiles.sh $tag _head_mel120 --workload head --head-feat mel120
 tools/collect_profiles.sh $tag _head_linear201 --workload head --head-feat linear201
+fi
+[ "$part" = 1 ] && exit 0
 tools/collect_profiles.sh $tag _finetune --workload finetune
 cd "$root"
 python3 bench.py --workload lstm --no-cpu-baseline > "$out/${tag}_lstm_bench.json" 2> "$out/lstm.err"
