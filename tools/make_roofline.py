@@ -48,7 +48,9 @@ out = {
                 'the square GEMMs are this library\'s 256 x 256 x 64 kernel (csrc/gemm6.hip)',
     },
     'algorithmic_work': {
-        'stft_bytes_per_utterance_channel': 2249608, 'istft_bytes_per_utterance': 2249608,
+        'stft_bytes_per_utterance': '640 000 read (one 16 kHz 10 s channel) + 4 x 1001 x 201 per plane written; round 3 writes power + encoded phase for the noisy '
+                                    'channel and power only for the clean one (the clean phase has no consumer): 2 x 640 000 + 3 x 804 804 = 3 694 412 per utterance',
+        'istft_bytes_per_utterance': 2249608,
         'encoder_gflop_per_layer_per_utterance': 17.25, 'mhsa_gflop_per_layer_per_utterance': 3.08,
         'qkv_gflop_per_launch_B32': flop['qkv'] / 1e9, 'ffn1_gflop_per_launch_B32': flop['ffn1'] / 1e9, 'mhsa_gflop_per_launch_B32': flop['mhsa'] / 1e9,
     },
@@ -62,7 +64,7 @@ for key, sub, f in (('gemm6p_qkv', 'gemm6p_bf16_kernel<0', flop['qkv']), ('gemm6
     us = avg_us(sub)
     if us:
         out['per_kernel_rocprof'][key] = {'avg_us': round(us, 1), 'TFLOPs': round(f / us / 1e6, 1), 'frac_of_2500': round(f / us / 1e6 / 2500.0, 3)}
-for key, sub, byts in (('stft_two_channels', 'stft_kernel', None), ('istft', 'istft_kernel', 32 * 2249608.0)):
+for key, sub, byts in (('stft_two_channels', 'se::stft_kernel', 32 * 3694412.0), ('istft', 'se::istft_kernel', 32 * 2249608.0)):
     us = avg_us(sub)
     if us:
         d = {'avg_us': round(us, 1)}
@@ -82,5 +84,37 @@ for k in ('gemm', 'gemmln', 'mhsa', 'stft'):
             'matrix_pipe_busy': round(v.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) / simd, 3),
             'vector_issue_busy': round(4.0 * v.get('SQ_ACTIVE_INST_VALU', 0.0) / simd, 3),
             'lds_bank_conflict_frac': round(v.get('lds_bank_conflict_frac', 0.0), 3)}
+# ---- the attention forward against its own feed floor ("if >= 0.5 is provably out of reach at d = 64, write issue_floor_frac")
+mh = (bench.get('roofline_other_kernels') or {}).get('mhsa_fwd_kernel') or {}
+lds_clk = 8192 / 128.0 + 8192 / 64.0 + 4096 / 128.0       # K fragments (b128: 128 B/clk), V^T fragments (tr_b64: 64 B/clk measured), staging writes
+floor_frac_matrix = 512.0 / (4 * lds_clk)                  # 4 SIMDs share one LDS port: 4 units = 4 x 224 port clocks against 512 matrix clocks
+clock_ratio = 2.0 / 2.38                                   # sustained core clock under MFMA load / the clock of the nominal 2.5 PFLOP/s
+out['mhsa_fwd_floor'] = {
+    'unit': 'one wave, 32 queries x 64 keys, d = 64: 16 v_mfma_f32_32x32x16_bf16 = 512 matrix clocks on its SIMD',
+    'lds_bytes_per_unit': {'k_fragments_b128': 8192, 'v_fragments_tr_b64': 8192, 'staging_writes': 4096},
+    'lds_port_clocks_per_unit': lds_clk,
+    'why': 'every 32x32x16 MFMA takes a fresh 1-KiB A operand (a K or V^T fragment) from LDS while the B operand (Q / P) stays in registers: at the '
+           'matrix peak that is 32 B/clk per SIMD = the whole 128 B/clk LDS port of the CU, and the transposed V^T reads (ds_read_b64_tr_b16) run at '
+           'half that rate (csrc/wgrad.hip header: 8 clk per wave instruction).  With one query block per wave the LDS port, not the matrix pipe, '
+           'is the floor; vector issue (102 instructions per unit, ISA count; >= 340 clocks at the measured multi-wave issue rates of '
+           'profiles/r03_micro_pk_rate.txt) comes third.',
+    'vector_instructions_per_unit': 102,
+    'feed_floor_frac_of_matrix_rate': round(floor_frac_matrix, 3),
+    'issue_floor_frac': round(floor_frac_matrix * clock_ratio, 3),
+    'issue_floor_frac_note': 'fraction of the NOMINAL 2.5 PFLOP/s reachable with the LDS port 100 % busy and nothing else stalling, at the ~2.0 GHz the '
+                             'core clock sustains under MFMA load: >= 0.5 of nominal is out of reach for this tile shape at d = 64',
+    'achieved_frac': mh.get('frac'),
+    'achieved_over_floor': round(mh['frac'] / (floor_frac_matrix * clock_ratio), 3) if mh.get('frac') else None,
+    'measured_restructurings_round3': {
+        'two query blocks per wave (halves the LDS bytes per MFMA; mhsa2.hip, 255 VGPR)': '~130 us (tie)',
+        'interleaved matrix / vector stream, 2 blocks per wave, LDS-DMA ring (mhsa3.hip)': '143-152 us',
+        'LDS-DMA staging, 2 / 3 slots, occupancy 3 / 4 (SE_AMD_MHSA_DMA=1..4)': 'equal or slower',
+        '8-wave workgroups sharing one staged tile (SE_AMD_MHSA_NW=8)': '153-156 vs 136 us',
+        'row sums on the matrix pipe (tools/patches/mhsa_msum.diff)': '141-152 vs 131-139 us',
+        'v_pk_add_f32 row sums': '144-147 vs 135-136 us',
+        's_setprio around the MFMA clusters (-DSE_MHSA_PRIO)': 'tie',
+        'source': 'profiles/r03_mhsa_peaked.txt, profiles/r03_micro_coissue.txt, profiles/r03_mhsa_ablation.txt, DESIGN.md section 6',
+    },
+}
 json.dump(out, open(os.path.join(root, 'roofline.json'), 'w'), indent=1)
 print('wrote roofline.json')
