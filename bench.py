@@ -352,7 +352,7 @@ def build_workload(args, ranks):
         from speech_enhancement_by_s3prl_amd.heads import LinearResidual
         from speech_enhancement_by_s3prl_amd.objective import SISDR
         feat = HEAD_FEATS[args.head_feat]
-        pre = pipeline.build_preprocessor(cfg, dev, channel_inp=0, channel_tar=1, downstream_feat=feat)
+        pre = pipeline.build_preprocessor(cfg, dev, channel_inp=0, channel_tar=1, downstream_feat=feat, upstream='baseline')      # --upstream baseline
         torch.manual_seed(0)
         D = 120 if args.head_feat == 'mel120' else 201
         head = LinearResidual(input_size=D, output_size=201, cmvn=True).to(dev)

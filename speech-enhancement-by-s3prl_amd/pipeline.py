@@ -85,16 +85,19 @@ def build_upstream(ckpt, device):
     return upstream.to(device).eval()
 
 
-def build_preprocessor(config, device, channel_inp=0, channel_tar=1, downstream_feat=None):
-    """run_downstream.get_preprocessor (run_downstream.py:123-164): the six-feature list."""
+def build_preprocessor(config, device, channel_inp=0, channel_tar=1, downstream_feat=None, upstream='transformer'):
+    """run_downstream.get_preprocessor (run_downstream.py:123-164): the six-feature list.  upstream = 'transformer': the upstream feature is the
+    pre-training input (run_downstream.py:132-133); 'baseline' (no upstream model, `dummy_upstream`): it is the baseline feature itself (:134-135),
+    i.e. the same request as the downstream feature -- which the preprocessor then computes once."""
     online = config['online']
-    up = dict(online['input'], channel=channel_inp)
     down = dict(downstream_feat or BASELINE_FEAT, channel=channel_inp)
+    up = dict(online['input'], channel=channel_inp) if upstream == 'transformer' else dict(down)
     P = OnlinePreprocessor
     feat_list = [up, down, P.get_feat_config('linear', channel_inp), P.get_feat_config('phase', channel_inp),
                  P.get_feat_config('linear', channel_tar), P.get_feat_config('phase', channel_tar)]
     pre = OnlinePreprocessor(**online, feat_list=feat_list)
     pre.channel_inp, pre.channel_tar = channel_inp, channel_tar
+    pre.encoder_side = upstream == 'transformer'      # no upstream encoder: the first feature needs no bf16 operand copy / valid-frame counts
     return pre.to(device)
 
 

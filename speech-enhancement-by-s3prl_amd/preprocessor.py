@@ -337,14 +337,21 @@ class OnlinePreprocessor(nn.Module):
             planes.setdefault(ch, {})['mfcc'] = self._mfcc_channel(wavs3, ch)
 
         feats = []
+        done = {}          # identical requests are computed once: with `--upstream baseline` the reference's list asks for the baseline feature
+                           # twice (run_downstream.py:132-135, 150-151); both entries are then the same tensor, as two raw 'linear' requests already are
         for a in feat_list:
             ft, ch = a['feat_type'], int(a.get('channel', 0))
             log, delta, cmvn = bool(a.get('log', False)), int(a.get('delta', 0)), bool(a.get('cmvn', False))
+            key = (ft, ch, log, delta, cmvn)
+            if key in done:
+                feats.append(done[key])
+                continue
             raw = planes[ch][ft]                 # mel: (B, D, F) feature-major; everything else time-major
             if type(raw) is LazyPhase:
                 feats.append(raw)                # (*lead, F, K) already; materialises itself on any use but istft()
                 continue
-            first = len(feats) == 0 and home == wavs3.device       # feats_for_upstream (run_downstream.py:150): what the TRANSFORMER is fed
+            # feats_for_upstream (run_downstream.py:150): what the TRANSFORMER is fed -- unless the owner said there is none (`encoder_side = False`)
+            first = len(feats) == 0 and home == wavs3.device and getattr(self, 'encoder_side', True)
             if ft == 'mel':
                 feat = self._select(raw, False, log, delta, cmvn, encoder_side=first)
             elif log or delta or cmvn:
@@ -355,6 +362,7 @@ class OnlinePreprocessor(nn.Module):
             feat = feat.reshape(*lead, *feat.shape[-2:]).to(home)
             if side is not None:
                 feat._se_side = side + (feat._version,)           # (bf16 rows, valid-frame counts, version the pair belongs to)
+            done[key] = feat
             feats.append(feat)
         return feats
 

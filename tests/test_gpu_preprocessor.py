@@ -255,3 +255,19 @@ def test_istft_phasor_vs_oracle(P, gpu, T, B):
     dec = __import__('speech_enhancement_by_s3prl_amd.decode', fromlist=['decode_wav']).decode_wav(P, pred.to(gpu), feats[3], lengths.to(gpu), wavs[:, 1].to(gpu))
     rdec = odec.decode_wav(pred, ref[3], lengths, GEOM, wavs[:, 1])
     assert ((dec.cpu() - rdec).abs().max() / rdec.abs().max()).item() < 1e-4
+
+
+def test_identical_feature_requests_are_computed_once(P, gpu):
+    """`--upstream baseline` (run_downstream.py:134-135, 150-151): the reference's feature list then holds the baseline feature twice; the
+    preprocessor computes it once and returns it for both entries (as two raw 'linear' requests already were one tensor).  Values equal
+    the separately requested feature."""
+    torch.manual_seed(5)
+    wavs = torch.randn(2, 2, 16000, device=gpu) * 0.1
+    base = {'feat_type': 'mel', 'channel': 0, 'log': True, 'delta': 2, 'cmvn': False}       # pseudo_noise.yaml:11-15
+    twice = P(wavs, feat_list=[dict(base), dict(base), P.get_feat_config('linear', 0), P.get_feat_config('linear', 1)])
+    once = P(wavs, feat_list=[dict(base)])
+    assert twice[0] is twice[1]
+    assert torch.equal(twice[0], once[0])
+    assert twice[0].shape == (2, 101, 120)
+    other = P(wavs, feat_list=[dict(base), dict(base, delta=1)])          # different requests stay different
+    assert other[0] is not other[1] and other[1].shape == (2, 101, 80)
