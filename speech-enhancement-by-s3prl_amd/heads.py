@@ -97,9 +97,38 @@ class LinearResidual(nn.Module):
         self.eps = eps
 
     def forward(self, features, linears, **kwargs):
+        needs_grad = torch.is_grad_enabled() and (features.requires_grad or any(p.requires_grad for p in self.parameters()))
+        if not needs_grad and features.is_cuda and getattr(self, 'lazy_offset', True):
+            # evaluate(): `offset` is only read by the WSD criterion (objective.py:127); every other consumer drops it, so it is a LazyTensor that
+            # re-runs the kernel with the mask output when (and only when) something reads it -- the launch then stores one plane instead of two
+            return self._forward_lazy(features, linears)
         predicted, offset = _HeadLinearFn.apply(features, linears, self.linear.weight, self.linear.bias, self._act,
                                                 self.cmvn, self.eps)
         return predicted, {'offset': offset}
+
+    def _forward_lazy(self, features, linears):
+        from .preprocessor import LazyTensor
+        lib = _lib.load()
+        B, F, D = features.shape
+        N = self.linear.weight.shape[0]
+        feats = features.contiguous().float()
+        lin = linears.contiguous().float()
+        w, b = self.linear.weight.detach().float().clone(), self.linear.bias.detach().float().clone()
+        act, cmvn, eps = self._act, int(self.cmvn), float(self.eps)
+
+        def run(want_offset):
+            out = torch.empty(B, F, N, device=feats.device, dtype=torch.float32)
+            nbytes = lib.se_head_workspace_bytes(B, F, D, N)
+            ws = torch.empty(nbytes, device=feats.device, dtype=torch.uint8)
+            if want_offset:      # the mask itself: the same launch without the noisy-power product
+                _lib.check(lib.se_head_linear_f32(_lib.ptr(feats), _lib.ptr(w), _lib.ptr(b), None, B, F, D, N, act, cmvn, eps, _lib.ptr(out), None,
+                                                  _lib.ptr(ws), nbytes, _lib.stream()), 'se_head_linear_f32')
+            else:
+                _lib.check(lib.se_head_linear_f32(_lib.ptr(feats), _lib.ptr(w), _lib.ptr(b), _lib.ptr(lin), B, F, D, N, act, cmvn, eps, _lib.ptr(out), None,
+                                                  _lib.ptr(ws), nbytes, _lib.stream()), 'se_head_linear_f32')
+            return out
+        predicted = run(False)
+        return predicted, {'offset': LazyTensor((B, F, N), feats.device, lambda: run(True))}
 
 
 class SpecHead(nn.Module):

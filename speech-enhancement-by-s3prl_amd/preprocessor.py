@@ -26,21 +26,16 @@ from . import _lib
 N_SAMPLED_PSEUDO_WAV = 2
 
 
-class LazyPhase(torch.Tensor):
-    """The `phase` feature of the boundary (run_downstream.py:150-157: `get_feat_config('phase', channel)`), produced ON DEMAND.
-
-    Every consumer of the noisy phase inside the reference's pipelines is `preprocessor.istft(linears, phases)` (runner.py:267), and nothing
-    ever reads the clean channel's phase (runner.py:433,558 unpack it and drop it).  So the hot path neither computes atan2 in the STFT nor
-    sin / cos in the iSTFT: the STFT kernel writes the phase as one word per bin from which (cos, sin) follow rationally (`_tphase`, int32
-    (..., F, K): fp32 t = tan(half angle) with the sign of cos in bit 0, stft2.hip), `istft` recognises this object and runs
-    se_istft_tphase_f32 on it.  Any OTHER use -- arithmetic, indexing, .cpu(), printing, torch.save -- goes through __torch_dispatch__,
-    which first materialises the real (…, F, K) fp32 phase with the atan2 kernel (se_stft_f32 on the retained waveform: bit-identical to
-    what the eager path returns) and then runs the requested op on it.  Shape / dtype / device are the real tensor's."""
+class LazyTensor(torch.Tensor):
+    """An fp32 result of the boundary that its usual consumers never read, produced ON DEMAND: shape / dtype / device are the real tensor's, and
+    any use -- arithmetic, indexing, .cpu(), printing, torch.save -- goes through __torch_dispatch__, which first materialises the value with the
+    kernel that makes it and then runs the requested op on it.  Merely carrying the object around (returning it, passing it as a keyword
+    argument that the callee ignores) costs nothing.  Users: the `phase` features (LazyPhase below) and LinearResidual's `offset` result."""
 
     @staticmethod
-    def __new__(cls, shape, device, materialize, tphase=None):
+    def __new__(cls, shape, device, materialize, *args, **kwargs):
         r = torch.Tensor._make_wrapper_subclass(cls, tuple(shape), dtype=torch.float32, device=device, requires_grad=False)
-        r._materialize_fn, r._tphase, r._value = materialize, tphase, None
+        r._materialize_fn, r._value = materialize, None
         return r
 
     def materialize(self):
@@ -54,11 +49,29 @@ class LazyPhase(torch.Tensor):
         from torch.utils._pytree import tree_map
 
         def unwrap(t):
-            return t.materialize() if isinstance(t, LazyPhase) else t
+            return t.materialize() if isinstance(t, LazyTensor) else t
         return func(*tree_map(unwrap, args), **tree_map(unwrap, kwargs or {}))
 
     def __reduce_ex__(self, protocol):          # pickling / torch.save / deepcopy: as the plain tensor
         return self.materialize().__reduce_ex__(protocol)
+
+
+class LazyPhase(LazyTensor):
+    """The `phase` feature of the boundary (run_downstream.py:150-157: `get_feat_config('phase', channel)`), produced ON DEMAND.
+
+    Every consumer of the noisy phase inside the reference's pipelines is `preprocessor.istft(linears, phases)` (runner.py:267), and nothing
+    ever reads the clean channel's phase (runner.py:433,558 unpack it and drop it).  So the hot path neither computes atan2 in the STFT nor
+    sin / cos in the iSTFT: the STFT kernel writes the phase as one word per bin from which (cos, sin) follow rationally (`_tphase`, int32
+    (..., F, K): fp32 t = tan(half angle) with the sign of cos in bit 0, stft2.hip), `istft` recognises this object and runs
+    se_istft_tphase_f32 on it.  Any OTHER use -- arithmetic, indexing, .cpu(), printing, torch.save -- goes through __torch_dispatch__,
+    which first materialises the real (…, F, K) fp32 phase with the atan2 kernel (se_stft_f32 on the retained waveform: bit-identical to
+    what the eager path returns) and then runs the requested op on it.  Shape / dtype / device are the real tensor's."""
+
+    @staticmethod
+    def __new__(cls, shape, device, materialize, tphase=None):
+        r = LazyTensor.__new__(cls, shape, device, materialize)
+        r._tphase = tphase
+        return r
 
 
 class OnlinePreprocessor(nn.Module):

@@ -51,6 +51,35 @@ def test_linear_residual_vs_oracle(gpu, B, F, D, N):
     assert ((pred.cpu() - ref_pred).abs().max() / ref_pred.abs().max()).item() < 1e-4
 
 
+def test_linear_residual_lazy_offset(gpu, golden):
+    """evaluate() (no gradients): `offset` (model.py:34) comes back as a LazyTensor that costs nothing until something reads it, and then holds
+    exactly what the eager path returns; `predicted` is the eager value bit for bit"""
+    from speech_enhancement_by_s3prl_amd.heads import LinearResidual
+    from speech_enhancement_by_s3prl_amd.preprocessor import LazyTensor
+    m = LinearResidual(input_size=120, output_size=201, cmvn=True).to(gpu)
+    m.load_state_dict({'linear.weight': T(golden['c1_weight']), 'linear.bias': T(golden['c1_bias'])})
+    feats, lin = T(golden['c1_feats'], gpu), T(golden['c1_linears'], gpu)
+    pred_e, res_e = m(features=feats, linears=lin)                 # gradients enabled: the eager autograd path
+    with torch.no_grad():
+        pred, res = m(features=feats, linears=lin)
+    off = res['offset']
+    assert type(off) is LazyTensor and off._value is None
+    assert off.shape == res_e['offset'].shape and off.dtype == torch.float32 and off.device == pred.device
+    assert torch.equal(pred, pred_e.detach())
+
+    def ignores(**kwargs):          # a criterion that takes **kwargs and drops the mask (objective.py:103, 81): nothing is computed
+        return None
+    ignores(**res)
+    assert off._value is None
+    assert torch.equal(off + 0.0, res_e['offset'].detach())        # first real use materialises it
+    assert off._value is not None
+    assert torch.allclose(off.cpu(), T(golden['c1_offset']), atol=2e-5, rtol=1e-5)
+    m.lazy_offset = False
+    with torch.no_grad():
+        _, res2 = m(features=feats, linears=lin)
+    assert type(res2['offset']) is torch.Tensor
+
+
 def test_length_masks_golden(gpu, golden):
     from speech_enhancement_by_s3prl_amd.decode import get_length_masks
     m = get_length_masks(T(golden['d1_lengths'], gpu))
