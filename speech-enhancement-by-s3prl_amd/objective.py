@@ -93,7 +93,7 @@ class _SISDRFn(torch.autograd.Function):
         grad = torch.empty_like(p) if predicted.requires_grad else None
         _lib.check(lib.se_sisdr_spec_f32(_lib.ptr(p), _lib.ptr(t), _lib.ptr(lens), B, F, N, float(eps), 1.0, _lib.ptr(scratch), _lib.ptr(loss_b),
                                          _lib.ptr(grad), _lib.stream()), 'se_sisdr_spec_f32')
-        sums = torch.stack([loss_b.double().sum(), torch.tensor(float(B), device=p.device, dtype=torch.float64)])
+        sums = torch.stack([loss_b.double().sum(), torch.full((), float(B), device=p.device, dtype=torch.float64)])      # a fill kernel: capturable in a hipGraph (torch.tensor() is a host copy)
         if reduce_fn is not None:
             sums = reduce_fn(sums)          # (sum of per-utterance losses, utterance count) across ranks: a global mean over utterances
         ctx.save_for_backward(grad if grad is not None else torch.empty(0), sums)
@@ -134,7 +134,7 @@ class _WSDFn(torch.autograd.Function):
         grad = torch.empty_like(off) if offset.requires_grad else None
         _lib.check(lib.se_wsd_f32(_lib.ptr(inp), _lib.ptr(off), _lib.ptr(tar), _lib.ptr(lens), _lib.ptr(energy), _lib.ptr(emax), B, F, N, float(alpha),
                                   float(db_interval), float(eps), 1.0, _lib.ptr(sums), _lib.ptr(grad), _lib.stream()), 'se_wsd_f32')
-        tot = torch.stack([alpha * sums[0] + (1.0 - alpha) * sums[1], torch.tensor(float(B), device=dev, dtype=torch.float64)])
+        tot = torch.stack([alpha * sums[0] + (1.0 - alpha) * sums[1], torch.full((), float(B), device=dev, dtype=torch.float64)])
         if reduce_fn is not None:
             tot = reduce_fn(tot)
         ctx.save_for_backward(grad if grad is not None else torch.empty(0), tot)
