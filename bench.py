@@ -579,6 +579,10 @@ def head_pass_bytes(head_feat):
 
 
 def main():
+    wd = os.environ.get('SE_BENCH_WATCHDOG')          # seconds: every thread's Python stack on stderr if the run is still going then (hang diagnosis)
+    if wd:
+        import faulthandler
+        faulthandler.dump_traceback_later(float(wd), exit=False)
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)

@@ -13,6 +13,8 @@ collective per step -- small messages are latency-bound on the xGMI mesh, large 
 reduce-scatter instead of many small buckets."""
 import math
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -187,6 +189,11 @@ class BucketedGradSink:
             lo = self.offsets[run[0]]
             hi = self.offsets[run[-1]] + self.reducer.params[run[-1]].numel()
             self.handles.append(dist.all_reduce(self.reducer.flat[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+            # gloo on DEVICE tensors (the several-ranks-on-one-GPU rehearsal, bench.py --one-device --backend gloo) hung with four ranks and seven
+            # bucket all-reduces in flight (every rank inside the tail all_reduce, stacks in DESIGN section 7; three ranks, or completing each bucket
+            # first, pass): there the buckets complete one by one.  RCCL orders its collectives on the stream and keeps the overlap.
+            if (dist.get_backend() == 'gloo' and self.reducer.flat.is_cuda) or os.environ.get('SE_DP_BUCKET_SYNC') == '1':
+                self.handles.pop().wait()
             self.collectives += 1
             if i is not None:
                 run = [i]
