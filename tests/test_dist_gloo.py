@@ -128,21 +128,21 @@ def _run_bench(argv, timeout=300):
                           text=True, timeout=timeout)
 
 
-@pytest.mark.parametrize('workload', ['finetune', 'enhance'])
-def test_bench_control_flow_two_ranks_stubbed(workload):
-    """The WHOLE control flow of bench.py at N = 2 over gloo with the step stubbed (`--stub-step`: same collective sequence per step --
+@pytest.mark.parametrize('workload,world', [('finetune', 2), ('enhance', 2), ('finetune', 4)])
+def test_bench_control_flow_two_ranks_stubbed(workload, world):
+    """The WHOLE control flow of bench.py at N = 2 (and, for the all-reducing step, N = 4) over gloo with the step stubbed (`--stub-step`: same collective sequence per step --
     (sum, count) all-reduce, per-layer async bucket all-reduces, tail reduce + wait -- through the product's own dist.py classes): warm-up,
     timed loop, max-over-ranks, the roofline leg on EVERY rank, teardown, then rank 0's side legs with no process group left.  Round 2's
     2-rank fine-tune rehearsal deadlocked because rank 0 alone re-ran all-reducing steps; this is the test that would have caught it
     (a hang here fails by timeout)."""
     import json
-    out = _run_bench(['--gpus', '2', '--workload', workload, '--stub-step', '--backend', 'gloo', '--steps', '3', '--warmup', '1'], timeout=240)
+    out = _run_bench(['--gpus', str(world), '--workload', workload, '--stub-step', '--backend', 'gloo', '--steps', '3', '--warmup', '1'], timeout=240)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, lines
     rec = json.loads(lines[0])
-    assert rec['n_gpus'] == 2 and rec['steps'] == 3 and 'stub' in rec and rec['value'] > 0
-    assert rec['config']['global_batch'] == 2 * rec['config']['batch_per_gpu']
+    assert rec['n_gpus'] == world and rec['steps'] == 3 and 'stub' in rec and rec['value'] > 0
+    assert rec['config']['global_batch'] == world * rec['config']['batch_per_gpu']
 
 
 def test_bench_phase_b_is_collective_free():
