@@ -26,7 +26,7 @@ if os.environ.get('SE_AMD_EXTRA_DEFINES'):              # developer A/B builds, 
 # per-file extra flags.  The flash attention forward and the STFT / iSTFT are VALU-issue bound and v_pk_*_f32 (what the SLP vectoriser
 # makes of adjacent fp32 adds / multiplies) costs more issue time there than the two plain instructions it replaces: MHSA 147 -> 139 us,
 # STFT 2.57 -> 2.78 TB/s.  Applied to every file it is a small net loss (GEMM epilogues, element-wise passes), hence per file.
-FILE_FLAGS = {'mhsa.hip': ['-fno-slp-vectorize'], 'mhsa2.hip': ['-fno-slp-vectorize'], 'mhsa3.hip': ['-fno-slp-vectorize'], 'mhsa_pipe.hip': ['-fno-slp-vectorize'], 'stft.hip': ['-fno-slp-vectorize'], 'istft.hip': ['-fno-slp-vectorize'],
+FILE_FLAGS = {'mhsa.hip': ['-fno-slp-vectorize'], 'mhsa2.hip': ['-fno-slp-vectorize'], 'mhsa3.hip': ['-fno-slp-vectorize'], 'mhsa_pipe.hip': ['-fno-slp-vectorize'], 'stft.hip': ['-fno-slp-vectorize'], 'stft_small.hip': ['-fno-slp-vectorize'], 'istft.hip': ['-fno-slp-vectorize'],
               'stft2.hip': ['-fno-slp-vectorize'], 'istft2.hip': ['-fno-slp-vectorize']}
 
 

@@ -23,8 +23,11 @@
 
 namespace se {
 
-constexpr int kIFR = 30;                 // frames transformed per workgroup (30 x 25 = 750 pass-A items = 3 full rounds; 3 workgroups / CU)
-constexpr int kIHB = 27;                 // hop-blocks of output per workgroup
+#ifndef SE_ISTFT_FR
+#define SE_ISTFT_FR 30
+#endif
+constexpr int kIFR = SE_ISTFT_FR;        // frames transformed per workgroup (30 x 25 = 750 pass-A items = 3 full rounds; 3 workgroups / CU)
+constexpr int kIHB = kIFR - 3;           // hop-blocks of output per workgroup (three frames are shared with the neighbours)
 constexpr int kISpan = kIHB * kHop;      // 4320 samples
 constexpr int kIThreads = 256;
 constexpr int kIPairs = 101;             // bin pairs (k, 200 - k) per frame

@@ -23,12 +23,25 @@
 
 namespace se {
 
-constexpr int kFR = 30;          // frames per workgroup: 30 x 25 = 750 pass-A items = 3 full rounds of 256 threads (31 would need a
-                                 // 4th, nearly empty round), 30 x 8 = 240 pass-B items; LDS 51.2 KB -> 3 workgroups / CU
+#ifndef SE_STFT_FR
+#define SE_STFT_FR 20
+#endif
+// frames per workgroup.  Round 1-2: 30 (750 pass-A items = 3 full rounds of 256 threads; LDS 53 KB -> 3 workgroups per CU).  Round 3 sweep
+// (tools/stft_fr.sh, profiles/r03_stft_fr.txt): the launch is latency-bound (every phase of a workgroup waits on the one before), so MORE, SMALLER
+// workgroups per CU win although each is less efficient: 20 frames (500 pass-A items = 2 rounds; 4 workgroups per CU with the mel table's
+// 4 360-float floor on the plane size) for launches that produce a mel plane, 10 frames without that floor (stft_small.hip: the same source
+// compiled with SE_STFT_FR=10, SE_STFT_MELPLANE=0 -> 17.7 KB of LDS, 8 workgroups per CU) for launches that do not.
+constexpr int kFR = SE_STFT_FR;
 constexpr int kThreads = 256;
 constexpr int kFillIters = (kFR * kHalf + kThreads - 1) / kThreads;     // 25
 constexpr int kPostIters = (kFR * 101 + kThreads - 1) / kThreads;       // 13
-constexpr int kPlane = 6036;     // floats per output plane in LDS: >= 3 (alignment shift) + 30 x 201, a multiple of 4
+#ifndef SE_STFT_MELPLANE
+#define SE_STFT_MELPLANE 1
+#endif
+// floats per output plane in LDS: >= 3 (alignment shift) + kFR x 201, a multiple of 4; the mel stage parks its filter table in the phase plane
+// (kMelMax x kMelMaxW weights + 2 kMelMax indices behind 4 floats of slack), which needs 4 360 floats whatever kFR
+constexpr int kPlaneOut = (3 + kFR * 201 + 3) / 4 * 4;
+constexpr int kPlane = (SE_STFT_MELPLANE && kPlaneOut < 4360) ? 4360 : kPlaneOut;     // floats per output plane in LDS: >= 3 (alignment shift) + 30 x 201, a multiple of 4
 
 __device__ __forceinline__ int reflect(int i, int T) {
   // numpy / torch 'reflect' (no edge repeat); valid for |overshoot| < T
@@ -74,6 +87,9 @@ __device__ __forceinline__ float encode_phase(float x, float y, float q) {
 // enc != 0: the `phase` plane receives the encoded phase words of se_stft_tphase_f32 (encode_phase) instead of atan2
 struct StftOut { float* power; float* phase; float* complx; float* mel; int channel; int vec_ok; int enc; };
 
+#ifdef SE_STFT_TU_SMALL
+#define stft_kernel stft_small_kernel
+#endif
 __global__ __launch_bounds__(kThreads) void stft_kernel(
     const float* __restrict__ wavs, int C, int T, int F,
     const float* __restrict__ window, const float2* __restrict__ tw400g, const float2* __restrict__ tw200g,
@@ -327,6 +343,20 @@ __global__ __launch_bounds__(kThreads) void stft_kernel(
 
 }  // namespace se
 
+#ifdef SE_STFT_TU_SMALL
+// the no-mel build of this file (stft_small.hip): only the kernel and this launcher
+extern "C" int se_stft_launch_small(const se_plan* plan, const float* wavs, int B, int C, int T, const void* jobs_, int njobs, void* stream) {
+  const se::StftOut* jobs = static_cast<const se::StftOut*>(jobs_);
+  const int F = T / se::kHop + 1;
+  dim3 grid((F + se::kFR - 1) / se::kFR, B, njobs);
+  hipLaunchKernelGGL(se::stft_kernel, grid, dim3(se::kThreads), 0, se::as_stream(stream), wavs, C, T, F, plan->d_window, plan->d_tw400, plan->d_tw200,
+                     plan->d_mel_start, plan->d_mel_len, plan->d_mel_w, plan->geom.n_mels, jobs[0], jobs[njobs > 1 ? 1 : 0], nullptr);
+  SE_LAUNCH_CHECK();
+  return SE_OK;
+}
+#else
+extern "C" int se_stft_launch_small(const se_plan* plan, const float* wavs, int B, int C, int T, const void* jobs, int njobs, void* stream);
+
 static int stft_launch(const se_plan* plan, const float* wavs, int B, int C, int T, const se::StftOut* jobs, int njobs, unsigned long long* dbgbuf, void* stream) {
   const int F = T / se::kHop + 1;
   dim3 grid((F + se::kFR - 1) / se::kFR, B, njobs);
@@ -335,6 +365,10 @@ static int stft_launch(const se_plan* plan, const float* wavs, int B, int C, int
     bytes += (double)B * (4.0 * T + 4.0 * F * se::kBins * ((jobs[j].power != nullptr) + (jobs[j].phase != nullptr) + 2 * (jobs[j].complx != nullptr)) +
                           (jobs[j].mel ? 4.0 * F * plan->geom.n_mels : 0.0));
   se::ProfScope prof(se::kProfStft, bytes, se::as_stream(stream));
+  static const bool small_ok = getenv("SE_AMD_STFT_SMALL") == nullptr || atoi(getenv("SE_AMD_STFT_SMALL")) != 0;      // 0: always this file's kernel (A/B)
+  bool any_mel = false;
+  for (int j = 0; j < njobs; ++j) any_mel = any_mel || jobs[j].mel != nullptr;
+  if (small_ok && !any_mel && !dbgbuf) return se_stft_launch_small(plan, wavs, B, C, T, jobs, njobs, stream);      // 10-frame workgroups, no mel table
   hipLaunchKernelGGL(se::stft_kernel, grid, dim3(se::kThreads), 0, se::as_stream(stream), wavs, C, T, F, plan->d_window, plan->d_tw400, plan->d_tw200,
                      plan->d_mel_start, plan->d_mel_len, plan->d_mel_w, plan->geom.n_mels, jobs[0], jobs[njobs > 1 ? 1 : 0], dbgbuf);
   SE_LAUNCH_CHECK();
@@ -386,3 +420,4 @@ extern "C" int se_stft_tphase_f32(const se_plan* plan, const float* wavs, int B,
                                {power_b, pb, nullptr, mel_b, njobs > 1 ? channel_b : channel_a, (((uintptr_t)power_b | (uintptr_t)pb) % 16) == 0, 1}};
   return stft_launch(plan, wavs, B, C, T, jobs, njobs, nullptr, stream);
 }
+#endif  // SE_STFT_TU_SMALL
