@@ -68,9 +68,18 @@ __global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__
 }
 
 constexpr int kHM = 128;     // frames per workgroup
-constexpr int kHK = 40;      // K chunk (ten 16-B pieces per row)
+// LDS footprint = occupancy: K chunks of 40 with 16-row epilogue passes are 57.7 KB (2 workgroups per CU); chunks of 20 with 8-row passes are
+// 29.6 KB, and the 168 registers of the N = 201 instantiation then allow 3 workgroups per CU: 328 -> 307 us (D = 120), 460 -> 419 us (D = 201)
+// per launch at B = 256 (tools/head_occ.sh; either change alone does nothing)
+#ifndef SE_HEAD_HK
+#define SE_HEAD_HK 20
+#endif
+#ifndef SE_HEAD_HALF
+#define SE_HEAD_HALF 8
+#endif
+constexpr int kHK = SE_HEAD_HK;      // K chunk (kHK / 4 16-B pieces per row)
 constexpr int kHP = kHK + 1; // LDS pitch (odd: conflict-free ds_read_b32 operand fetches)
-constexpr int kHHalf = 16;   // rows of a wave's 32 that go out per epilogue pass
+constexpr int kHHalf = SE_HEAD_HALF;   // rows of a wave's 32 that go out per epilogue pass (16 or 8)
 
 // Round 3 rewrite (the first version staged every element with its own index division and 4-B accesses and stored the outputs as 128-B row
 // pieces straight from the accumulator layout: 787 us for 256 utterances, 0.12 of the HBM rate).  Now:
@@ -167,15 +176,15 @@ __global__ __launch_bounds__(256, 2) void head_kernel(const float* __restrict__ 
     bn[t] = (bias && n < N) ? bias[n] : 0.f;
   }
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
+  for (int h = 0; h < 32 / kHHalf; ++h) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int n = t * 32 + (lane & 31);
       if (n < N) {
 #pragma unroll
-        for (int r8 = 0; r8 < 8; ++r8) {
-          const int r = 8 * h + r8;
-          const int rl = (r & 3) + 8 * ((r >> 2) & 1) + 4 * (lane >> 5);       // row within the 16-row half
+        for (int r8 = 0; r8 < kHHalf / 2; ++r8) {
+          const int r = (kHHalf / 2) * h + r8;
+          const int rl = (r & 3) + (kHHalf == 16 ? 8 * ((r >> 2) & 1) : 0) + 4 * (lane >> 5);       // row within the pass's 16 (8) rows
           Es[rl * N + n] = apply_act(acc[t][r] + bn[t], act);
         }
       }
