@@ -310,29 +310,35 @@ __global__ __launch_bounds__(kThreads) void stft_kernel(
   __syncthreads();
   SE_STAMP();
   // ---- mel: sparse HTK triangles over the power plane; the filter table is staged into the (now dead) phase plane
-  float* Tb = reinterpret_cast<float*>(Y) + kPlane + 4;     // [kMelMax * kMelMaxW weights][kMelMax starts][kMelMax lengths]
+  // table = [n_mels x kMelMaxW weights][n_mels starts][n_mels lengths]: only the rows this bank has (40 in the reference's configs: 6 KiB; the
+  // launcher checks that it fits behind the 4 floats of slack -- stft_small.hip's 10-frame planes take banks of up to 59 filters)
+  float* Tb = reinterpret_cast<float*>(Y) + kPlane + 4;
+  const int moff = n_mels * kMelMaxW;
   {
-    constexpr int kTbIters = kMelMax * kMelMaxW / kThreads;      // 16: the whole table, whatever n_mels (40 ... 128)
+    constexpr int kTbIters = kMelMax * kMelMaxW / kThreads;      // 16 covers the largest bank (128 filters)
     float wv[kTbIters];
 #pragma unroll
     for (int r = 0; r < kTbIters; ++r) {
       const int i = tid + kThreads * r;
-      wv[r] = (i < n_mels * kMelMaxW) ? mel_w[i] : 0.f;
+      wv[r] = (i < moff) ? mel_w[i] : 0.f;
     }
     const int ms = (tid < n_mels) ? mel_start[tid] : 0, ml = (tid < n_mels) ? mel_len[tid] : 0;
 #pragma unroll
-    for (int r = 0; r < kTbIters; ++r) Tb[tid + kThreads * r] = wv[r];
-    if (tid < kMelMax) {
-      Tb[kMelMax * kMelMaxW + tid] = __int_as_float(ms);
-      Tb[kMelMax * kMelMaxW + kMelMax + tid] = __int_as_float(ml);
+    for (int r = 0; r < kTbIters; ++r) {
+      const int i = tid + kThreads * r;
+      if (i < moff) Tb[i] = wv[r];
+    }
+    if (tid < n_mels) {
+      Tb[moff + tid] = __int_as_float(ms);
+      Tb[moff + n_mels + tid] = __int_as_float(ml);
     }
   }
   __syncthreads();
   for (int it = tid; it < n_mels * 32; it += kThreads) {
     const int m = it >> 5, fl = it & 31;                    // lane <-> frame: power reads at stride 201 floats (odd: conflict-free)
     if (fl >= nf) continue;
-    const int st = __float_as_int(Tb[kMelMax * kMelMaxW + m]);
-    const int len = __float_as_int(Tb[kMelMax * kMelMaxW + kMelMax + m]);
+    const int st = __float_as_int(Tb[moff + m]);
+    const int len = __float_as_int(Tb[moff + n_mels + m]);
     const float* pr = Pw + fl * kBins + st;
     const float* wr_ = Tb + m * kMelMaxW;
     float acc = 0.f;
@@ -368,7 +374,9 @@ static int stft_launch(const se_plan* plan, const float* wavs, int B, int C, int
   static const bool small_ok = getenv("SE_AMD_STFT_SMALL") == nullptr || atoi(getenv("SE_AMD_STFT_SMALL")) != 0;      // 0: always this file's kernel (A/B)
   bool any_mel = false;
   for (int j = 0; j < njobs; ++j) any_mel = any_mel || jobs[j].mel != nullptr;
-  if (small_ok && !any_mel && !dbgbuf) return se_stft_launch_small(plan, wavs, B, C, T, jobs, njobs, stream);      // 10-frame workgroups, no mel table
+  // 10-frame workgroups (stft_small.hip): planes of 2 016 floats; a mel bank fits its table (34 floats per filter + 4) there up to 59 filters
+  const bool small_fits = !any_mel || plan->geom.n_mels * (se::kMelMaxW + 2) + 4 <= 2016;
+  if (small_ok && small_fits && !dbgbuf) return se_stft_launch_small(plan, wavs, B, C, T, jobs, njobs, stream);
   hipLaunchKernelGGL(se::stft_kernel, grid, dim3(se::kThreads), 0, se::as_stream(stream), wavs, C, T, F, plan->d_window, plan->d_tw400, plan->d_tw200,
                      plan->d_mel_start, plan->d_mel_len, plan->d_mel_w, plan->geom.n_mels, jobs[0], jobs[njobs > 1 ? 1 : 0], dbgbuf);
   SE_LAUNCH_CHECK();
