@@ -176,6 +176,9 @@ def ptr(t):
     """Device pointer of a contiguous CUDA(HIP) tensor, or NULL for None."""
     if t is None:
         return None
+    mat = getattr(t, 'materialize', None)
+    if mat is not None:              # a LazyTensor (preprocessor.py) handed to a kernel: `.contiguous()` / `.float()` on it are no-ops that return the
+        t = mat()                    # wrapper itself, whose data_ptr() is NULL -- the kernel gets the value (kept alive by the wrapper)
     if not t.is_cuda:
         raise SEError('libse_amd kernels take device tensors only (got a CPU tensor); there is no CPU fallback')
     if not t.is_contiguous():

@@ -56,6 +56,11 @@ class LazyTensor(torch.Tensor):
         return self.materialize().__reduce_ex__(protocol)
 
 
+def Fp_(raw, time_major):
+    """frame count of a raw feature plane: (B, F, D) time-major or (B, D, F) feature-major"""
+    return raw.shape[1] if time_major else raw.shape[2]
+
+
 class LazyPhase(LazyTensor):
     """The `phase` feature of the boundary (run_downstream.py:150-157: `get_feat_config('phase', channel)`), produced ON DEMAND.
 
@@ -365,6 +370,17 @@ class OnlinePreprocessor(nn.Module):
                 continue
             # feats_for_upstream (run_downstream.py:150): what the TRANSFORMER is fed -- unless the owner said there is none (`encoder_side = False`)
             first = len(feats) == 0 and home == wavs3.device and getattr(self, 'encoder_side', True)
+            time_major = ft != 'mel'
+            if (ft == 'mel' or log or delta or cmvn) and lazy and len(feats) > 0 and getattr(self, 'lazy_features', True):
+                # a derived feature that is not the first of the list (run_downstream.py:150: the first is what the upstream is fed): the pipelines
+                # that run an upstream never read feats_for_downstream (runner.py:273-284, 556-575 with --from_waveform / the SpecHead path), so it
+                # is produced when -- and only when -- something reads it (LazyTensor); shape / dtype / device are known without computing it
+                Bp, Dp, Fp = (raw.shape[0], raw.shape[2], raw.shape[1]) if time_major else raw.shape
+                feat = LazyTensor((*lead, Fp, Dp * (1 + delta)), home,
+                                  lambda raw=raw, tm=time_major, a=(log, delta, cmvn): self._select(raw, tm, *a).reshape(*lead, Fp_(raw, tm), -1))
+                done[key] = feat
+                feats.append(feat)
+                continue
             if ft == 'mel':
                 feat = self._select(raw, False, log, delta, cmvn, encoder_side=first)
             elif log or delta or cmvn:
