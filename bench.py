@@ -501,7 +501,7 @@ def roofline_report(args, lib, out):
         # HBM-bound pass: the dominant kernel is the two-channel STFT launch
         e = hbm_entry('stft') or {}
         which = 'head:' + args.head_feat
-        traffic = pmc_traffic(('se::stft_kernel',), which) if args.batch == 256 and not args.graph else None
+        traffic = pmc_traffic(('se::stft_kernel', 'se::stft_small_kernel'), which) if args.batch == 256 and not args.graph else None
         out['roofline'] = dict(e, kernel='stft_kernel', traffic=traffic,
                                traffic_unit='HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, committed PMC passes: profiles/' + PMC_FILES[which] + ')')
         for name in ('istft', 'head'):

@@ -14,8 +14,9 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 names = [r['Kernel_Name'] for r in rows]
 # last pass = from the last stft kernel on
-last = max(i for i, n in enumerate(names) if 'stft_kernel' in n and 'istft' not in n)
-prev = max(i for i, n in enumerate(names[:last]) if 'stft_kernel' in n and 'istft' not in n)
+is_stft = lambda n: ('stft_kernel' in n or 'stft_small_kernel' in n) and 'istft' not in n
+last = max(i for i, n in enumerate(names) if is_stft(n))
+prev = max(i for i, n in enumerate(names[:last]) if is_stft(n))
 t0 = int(rows[prev]['Start_Timestamp'])
 for r in rows[prev:last]:
     print(f"{(int(r['Start_Timestamp']) - t0)/1e3:9.1f} us  {(int(r['End_Timestamp']) - int(r['Start_Timestamp']))/1e3:7.1f} us  {r['Kernel_Name'][:110]}")
