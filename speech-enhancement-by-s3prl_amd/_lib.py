@@ -11,7 +11,8 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libse_amd.so')
+# SE_AMD_LIB: developer switch for A/B and stamp builds (tools/): another build of the SAME library; never a fallback
+LIB_PATH = os.environ.get('SE_AMD_LIB') or os.path.join(_HERE, 'libse_amd.so')
 
 SE_ACT = {'Identity': 0, 'ReLU': 1, 'Sigmoid': 2, 'GELU': 3, 'Exp': 4}
 

@@ -14,8 +14,10 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
-OBJ = os.path.join(HERE, 'build')
-LIB = os.path.join(HERE, 'libse_amd.so')
+# SE_AMD_BUILD_TAG=<tag>: a developer build (stamps, ablation defines) lands in libse_amd.<tag>.so / build_<tag>/ beside the product's library
+_TAG = os.environ.get('SE_AMD_BUILD_TAG')
+OBJ = os.path.join(HERE, 'build' + ('_' + _TAG if _TAG else ''))
+LIB = os.path.join(HERE, 'libse_amd' + ('.' + _TAG if _TAG else '') + '.so')
 ARCH = 'gfx950'
 FLAGS = ['-O3', '-std=c++17', '-fPIC', f'--offload-arch={ARCH}', '-fno-gpu-rdc', '-Wall', '-Wno-unused-function',
          '-Wno-comment', '-I' + os.path.join(HERE, '..', 'include')]
@@ -26,7 +28,7 @@ if os.environ.get('SE_AMD_EXTRA_DEFINES'):              # developer A/B builds, 
 # per-file extra flags.  The flash attention forward and the STFT / iSTFT are VALU-issue bound and v_pk_*_f32 (what the SLP vectoriser
 # makes of adjacent fp32 adds / multiplies) costs more issue time there than the two plain instructions it replaces: MHSA 147 -> 139 us,
 # STFT 2.57 -> 2.78 TB/s.  Applied to every file it is a small net loss (GEMM epilogues, element-wise passes), hence per file.
-FILE_FLAGS = {'mhsa.hip': ['-fno-slp-vectorize'], 'mhsa2.hip': ['-fno-slp-vectorize'], 'mhsa3.hip': ['-fno-slp-vectorize'], 'mhsa_pipe.hip': ['-fno-slp-vectorize'], 'stft.hip': ['-fno-slp-vectorize'], 'stft_small.hip': ['-fno-slp-vectorize'], 'istft.hip': ['-fno-slp-vectorize'],
+FILE_FLAGS = {'mhsa.hip': ['-fno-slp-vectorize'], 'mhsa2.hip': ['-fno-slp-vectorize'], 'mhsa3.hip': ['-fno-slp-vectorize'], 'mhsa8.hip': ['-fno-slp-vectorize'], 'mhsa9.hip': ['-fno-slp-vectorize'], 'mhsa_pipe.hip': ['-fno-slp-vectorize'], 'stft.hip': ['-fno-slp-vectorize'], 'stft_small.hip': ['-fno-slp-vectorize'], 'istft.hip': ['-fno-slp-vectorize'],
               'stft2.hip': ['-fno-slp-vectorize'], 'istft2.hip': ['-fno-slp-vectorize']}
 
 

@@ -51,6 +51,20 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OC
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hh = lane >> 5;
+#ifdef SE_AMD_STAMPS
+  // developer build only (SE_AMD_BUILD_STAMPS=1; tools/mhsa_stamps.py): per-wave sums of the s_memtime spent in each phase of the key tile.  The
+  // PRE instantiations take the stamp buffer through `lse` (unused in inference).  Phases: 0 top -> QK^T MFMAs issued, 1 -> first exponential
+  // issued (= matrix results back), 2 -> last bf16 pack issued, 3 -> PV MFMAs issued (V^T fragment reads inside), 4 -> next tile written to LDS
+  // (global-load wait inside), 5 -> barrier passed; 6 prologue, 7 whole kernel
+  unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const unsigned long long st_t0 = __builtin_amdgcn_s_memtime();
+  unsigned long long st_prev = st_t0;
+#define SE_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_prev; st_prev = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define SE_STAMP_PIN2(a, b) asm volatile("" :: "v"(a), "v"(b))
+#else
+#define SE_STAMP(i) do { } while (0)
+#define SE_STAMP_PIN2(a, b) do { } while (0)
+#endif
   // XCD-aware work mapping: workgroups are dealt round-robin to the 8 XCDs (linear id % 8), each with its own L2.  All
   // query tiles of one (utterance, head) re-read the same K / V, so they are placed on ONE XCD, consecutive in its
   // dispatch order: workgroup (xcd, i) -> pair 8 (i / nqt) + xcd, query tile i % nqt   [needs pairs % 8 == 0]
@@ -185,6 +199,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OC
     SE_A_WRITE(0);
   }
   if (DMA != 2) __syncthreads();
+  SE_STAMP(6);
 
 #ifndef SE_MHSA_PRIO
 #define SE_MHSA_PRIO 0          /* bit 0: raised wave priority around the QK^T products, bit 1: around the PV products */
@@ -211,6 +226,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OC
       s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb_, qf[s], s == 0 ? kZero16 : s1, 0, 0, 0); }                           \
     }                                                                                                                      \
     if (SE_MHSA_PRIO & 1) __builtin_amdgcn_s_setprio(0);                                                                   \
+    SE_STAMP(0);                                                                                                           \
     if ((kt + 1) * kAK > len) {                                                                                            \
       const int kbase = kt * kAK + 4 * hh;                                                                                 \
       _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                                     \
@@ -236,7 +252,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OC
           rs1 += a1;                                                                                                       \
           pf[0][s][j] = (__bf16)a0;                                                                                        \
           pf[1][s][j] = (__bf16)a1;                                                                                        \
+          if (s == 0 && j == 0) { SE_STAMP_PIN2(a0, a1); SE_STAMP(1); }                                                    \
         }                                                                                                                  \
+      SE_STAMP_PIN2(pf[0][0], pf[0][1]); SE_STAMP_PIN2(pf[1][0], pf[1][1]);                                                \
+      SE_STAMP(2);                                                                                                         \
       const float rs = rs0 + rs1;                                                                                          \
       const bool bad = !(rs < 0x1p60f) || (kt == 0 && rs < 0x1p-60f);                                                      \
       if (!__any(bad)) {                                                                                                   \
@@ -318,11 +337,14 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OC
         }                                                                                                                  \
       }                                                                                                                    \
     if (SE_MHSA_PRIO & 2) __builtin_amdgcn_s_setprio(0);                                                                   \
+    SE_STAMP(3);                                                                                                           \
     if (!DMA && kt + 1 < nkt && !(SE_MHSA_ABL & 1)) SE_A_WRITE((CUR) ^ 1);                                                 \
+    SE_STAMP(4);                                                                                                           \
     if (DMA == 2) {                                                                                                        \
       if (kt + 2 < nkt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  \
       __builtin_amdgcn_s_barrier();                                                                                        \
     } else if (!(SE_MHSA_ABL & 2)) __syncthreads();                                                                        \
+    SE_STAMP(5);                                                                                                           \
   }
 
   int kt = 0;
@@ -356,7 +378,12 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OC
   const float inv = (DROP == 2 ? dscale : 1.0f) / l_tot;
   const int q = q0 + l31;
   // training: log2-domain log-sum-exp of the scaled scores, P = exp2(c s - lse) in the backward kernels
-  if (lse && q < T && hh == 0) lse[((size_t)b * (H / kHD) + head) * T + q] = fmaf(m_run, c, __builtin_amdgcn_logf(l_tot));
+#ifdef SE_AMD_STAMPS
+  const bool lse_is_stamps = PRE;          // stamp builds: the PRE instantiations receive the stamp buffer through `lse`
+#else
+  const bool lse_is_stamps = false;
+#endif
+  if (lse && !lse_is_stamps && q < T && hh == 0) lse[((size_t)b * (H / kHD) + head) * T + q] = fmaf(m_run, c, __builtin_amdgcn_logf(l_tot));
   if (q < T) {
     uint16_t* op = ctx + ((size_t)b * T + q) * H + head * kHD + 4 * hh;
 #pragma unroll
@@ -367,6 +394,17 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OC
       *reinterpret_cast<uint2*>(op + 32 + 8 * g) = w1;
     }
   }
+#ifdef SE_AMD_STAMPS
+  if (PRE && lse) {
+    st_acc[7] = __builtin_amdgcn_s_memtime() - st_t0;
+    const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    unsigned long long* sp = reinterpret_cast<unsigned long long*>(lse) + ((size_t)lin * NW + wave) * 8;
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) sp[i] = st_acc[i];
+    }
+  }
+#endif
 }
 
 
@@ -375,6 +413,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OC
 int se_mhsa_fwd_pipe_launch(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, int occ, hipStream_t st);   // mhsa_pipe.hip
 int se_mhsa2_fwd_launch(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, int never_speculate, hipStream_t st);   // mhsa2.hip
 int se_mhsa3_fwd_launch(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, int never_speculate, hipStream_t st);   // mhsa3.hip
+int se_mhsa8_fwd_launch(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, int never_speculate, hipStream_t st);   // mhsa8.hip
+int se_mhsa9_fwd_launch(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, int never_speculate, hipStream_t st);   // mhsa9.hip
+int se_mhsaN_fwd_launch(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, int never_speculate, int nw, int wpe, hipStream_t st);   // mhsa8.hip
 
 static int mhsa_fwd_launch(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, float* lse, float dropout_p,
                            uint64_t seed, uint32_t site, void* stream) {
@@ -420,6 +461,9 @@ static int mhsa_prescaled_launch(const uint16_t* qkv, const int32_t* lengths, in
   if (pipe == 1) return se_mhsa_fwd_pipe_launch(qkv, lengths, B, T, heads, ctx, pipe_occ, se::as_stream(stream));
   static int spec = -1;
   if (spec < 0) { const char* e = getenv("SE_AMD_MHSA_SPEC"); spec = e ? atoi(e) : 1; }      // 0: always the exact online-softmax tile (A/B)
+  if (pipe == 12) return se_mhsa9_fwd_launch(qkv, lengths, B, T, heads, ctx, spec ? 0 : 1, se::as_stream(stream));      // 8 waves, software-pipelined over the key tiles (mhsa9.hip)
+  if (pipe == 9 || pipe == 10 || pipe == 16) return se_mhsaN_fwd_launch(qkv, lengths, B, T, heads, ctx, spec ? 0 : 1, pipe == 16 ? 16 : 8, pipe == 9 ? 2 : 4, se::as_stream(stream));   // 8 / 16 free-running waves on one LDS-DMA staged tile (mhsa8.hip)
+  if (pipe == 8) return se_mhsa8_fwd_launch(qkv, lengths, B, T, heads, ctx, spec ? 0 : 1, se::as_stream(stream));      // 8-wave alternating segments (mhsa8.hip)
   if (pipe == 3) return se_mhsa3_fwd_launch(qkv, lengths, B, T, heads, ctx, spec ? 0 : 1, se::as_stream(stream));      // interleaved matrix / vector stream, two query blocks per wave (mhsa3.hip)
   if (pipe == 2) return se_mhsa2_fwd_launch(qkv, lengths, B, T, heads, ctx, spec ? 0 : 1, se::as_stream(stream));      // two query blocks per wave (mhsa2.hip)
   static int dma = -1;
@@ -443,6 +487,21 @@ static int mhsa_prescaled_launch(const uint16_t* qkv, const int32_t* lengths, in
   return SE_OK;
 }
 
+#ifdef SE_AMD_STAMPS
+// developer entry of stamp builds (not in include/se_amd.h): the inference kernel at 1 / 2 / 3 waves per SIMD with the per-phase cycle sums of every
+// wave written to `stamps` (grid workgroups x 4 waves x 8 uint64)
+extern "C" int se_mhsa_fwd_stamps_bf16(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, void* stamps, int occ, void* stream) {
+  const int H = heads * se::kHD;
+  dim3 grid((T + se::kAQ - 1) / se::kAQ, heads, B);
+  float* sp = reinterpret_cast<float*>(stamps);
+  if (occ == 1) hipLaunchKernelGGL((se::mhsa_fwd_kernel<1, 0, 1, 0>), grid, dim3(256), 0, se::as_stream(stream), qkv, lengths, T, H, ctx, sp, 0u, 0u, 1.f);
+  else if (occ == 2) hipLaunchKernelGGL((se::mhsa_fwd_kernel<2, 0, 1, 0>), grid, dim3(256), 0, se::as_stream(stream), qkv, lengths, T, H, ctx, sp, 0u, 0u, 1.f);
+  else hipLaunchKernelGGL((se::mhsa_fwd_kernel<3, 0, 1, 0>), grid, dim3(256), 0, se::as_stream(stream), qkv, lengths, T, H, ctx, sp, 0u, 0u, 1.f);
+  SE_LAUNCH_CHECK();
+  return SE_OK;
+}
+#endif
+
 extern "C" int se_mhsa_fwd_prescaled_bf16(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, void* stream) {
   static int pipe = -1;
   if (pipe < 0) {
@@ -455,7 +514,7 @@ extern "C" int se_mhsa_fwd_prescaled_bf16(const uint16_t* qkv, const int32_t* le
 // test / measurement surface: variant 0 = this file's kernel, 1 = the software-pipelined experiment of mhsa_pipe.hip, 2 = two query blocks per wave (mhsa2.hip)
 extern "C" int se_mhsa_fwd_prescaled_variant_bf16(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, int variant,
                                                   void* stream) {
-  SE_REQUIRE(variant >= 0 && variant <= 3, "se_mhsa_fwd_prescaled_variant_bf16: variant %d (0 .. 3)", variant);
+  SE_REQUIRE((variant >= 0 && variant <= 3) || variant == 8 || variant == 9 || variant == 10 || variant == 12 || variant == 16, "se_mhsa_fwd_prescaled_variant_bf16: variant %d (0 .. 3, 8, 9, 10, 12, 16)", variant);
   return mhsa_prescaled_launch(qkv, lengths, B, T, heads, ctx, variant, stream);
 }
 

@@ -19,6 +19,13 @@ def golden():
 
 
 @pytest.fixture(scope='session')
+def golden_heads():
+    """outputs of the reference's own model.LSTM / model.Residual / sampler.scoring (tests/golden/make_golden.py: heads_fixture)"""
+    import numpy as np
+    return np.load(os.path.join(ROOT, 'tests', 'golden', 'reference_golden_heads.npz'))
+
+
+@pytest.fixture(scope='session')
 def gpu():
     """cuda:0 on a box where libse_amd.so is built and a gfx950 is visible; fails (never skips) otherwise,
     so a silent fallback cannot make GPU tests pass."""

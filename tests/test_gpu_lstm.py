@@ -1,6 +1,8 @@
-"""GPU parity of the (Bi)LSTM downstream head (model.py:37-59) against torch.nn.LSTM itself -- the very module
-the reference's head wraps -- run on the CPU in fp64 with the same parameters.  bf16 recurrent / projection weights and bf16
-h operands on the HIP side: bounds are relative L2 per tensor, stated at the asserts."""
+"""GPU parity of the (Bi)LSTM downstream heads (model.py:37-91): (a) against OUTPUTS OF THE REFERENCE'S OWN model.LSTM /
+model.Residual (tests/golden/reference_golden_heads.npz: forward + every parameter gradient, hidden 201 / 256, both directions, CMVN on / off),
+(b) at the sizes no fixture holds (T up to 1001) against the class bodies restated on torch.nn.LSTM in fp64 (tests/ref_heads.py, themselves pinned
+to the same fixture by tests/test_oracle_golden.py).  bf16 recurrent / projection weights and bf16 h operands on the HIP side: bounds are relative
+L2 per tensor, stated at the asserts."""
 import copy
 
 import pytest
@@ -17,16 +19,8 @@ def rel_l2(a, b):
     return ((a - b).norm() / b.norm()).item()
 
 
-class RefLSTM(nn.Module):      # the reference's class body (model.py:37-59), fp64 on the CPU
-    def __init__(self, input_size, output_size, hidden_size, num_layers, bidirectional, activation='Identity'):
-        super().__init__()
-        self.lstm = nn.LSTM(input_size=input_size, hidden_size=hidden_size, num_layers=num_layers, batch_first=True, bidirectional=bidirectional)
-        self.scaling_layer = nn.Sequential(nn.Linear(max(1, int(bidirectional) * 2) * hidden_size, output_size), getattr(nn, activation)())
-
-    def forward(self, features):
-        predicted, _ = self.lstm(features)
-        log_predicted = self.scaling_layer(predicted)
-        return log_predicted.exp(), log_predicted
+from ref_heads import RefLSTM, RefResidual      # noqa: E402  (pinned to the reference's own classes by tests/test_oracle_golden.py)
+import ref_heads as RH      # noqa: E402
 
 
 @pytest.mark.parametrize('B,T,D,layers,bidir', [(3, 50, 120, 3, True), (2, 37, 120, 2, False), (2, 1001, 120, 1, True),
@@ -118,21 +112,6 @@ def test_lstm_head_trains(gpu):
     assert losses[-1] < losses[0], losses
 
 
-class RefResidual(nn.Module):      # the reference's class body (model.py:62-91)
-    def __init__(self, input_size, output_size, hidden_size, num_layers, bidirectional, cmvn, eps=1e-6):
-        super().__init__()
-        self.lstm = nn.LSTM(input_size=input_size, hidden_size=hidden_size, num_layers=num_layers, batch_first=True, bidirectional=bidirectional)
-        self.scaling_layer = nn.Sequential(nn.Linear(max(1, int(bidirectional) * 2) * hidden_size, output_size), nn.Sigmoid())
-        self.cmvn, self.eps = cmvn, eps
-
-    def forward(self, features, linears):
-        offset, _ = self.lstm(features)
-        if self.cmvn:
-            offset = (offset - offset.mean(dim=1, keepdim=True)) / (offset.std(dim=1, keepdim=True) + self.eps)
-        offset = self.scaling_layer(offset)
-        return linears * offset, offset
-
-
 @pytest.mark.parametrize('bidir,cmvn,hidden', [(False, True, 256), (True, False, 256), (True, True, 201)])
 def test_residual_head_vs_torch(gpu, bidir, cmvn, hidden):
     """LSTM -> CMVN over time -> Linear + Sigmoid mask -> mask (.) noisy power, trained through `predicted` AND the mask
@@ -161,3 +140,31 @@ def test_residual_head_vs_torch(gpu, bidir, cmvn, hidden):
         assert p.grad is not None, n
         r = rel_l2(p.grad, refp[n].grad)
         assert r < 4e-2, (n, r)
+
+
+def _T(x, dev=None):
+    import numpy as np
+    t = torch.from_numpy(np.asarray(x))
+    return t.to(dev) if dev is not None else t
+
+
+@pytest.mark.parametrize('ci', range(len(RH.HEAD_CASES)))
+def test_lstm_and_residual_heads_vs_reference_golden(gpu, golden_heads, ci):
+    """the HIP heads against what the REFERENCE's classes returned for the same seeded parameters and inputs (make_golden.py: heads_fixture)"""
+    from speech_enhancement_by_s3prl_amd.lstm import LSTM, Residual
+    G = golden_heads
+    tag, hidden, bidir, cmvn, layers = RH.HEAD_CASES[ci]
+    feats, G1, G2 = _T(G[f'lstm_{tag}_feats'], gpu), _T(G[f'lstm_{tag}_G1'], gpu), _T(G[f'lstm_{tag}_G2'], gpu)
+    head = RH.seeded.fill_params(LSTM(input_size=RH.HEAD_D, output_size=RH.HEAD_K, hidden_size=hidden, num_layers=layers, bidirectional=bidir), 100 + ci).to(gpu)
+    pred, res = head(features=feats)
+    ((pred * G1).sum() + (res['log_predicted'] * G2).sum()).backward()
+    assert rel_l2(res['log_predicted'], _T(G[f'lstm_{tag}_log_predicted'])) < 1.5e-2
+    assert rel_l2(pred, _T(G[f'lstm_{tag}_predicted'])) < 2.5e-2
+    RH.check_grad_samples(G, f'lstm_{tag}', [p.grad for p in head.parameters()], 1000 * ci, 4e-2, 'LSTM')
+    rhead = RH.seeded.fill_params(Residual(input_size=RH.HEAD_D, output_size=RH.HEAD_K, hidden_size=hidden, num_layers=layers, bidirectional=bidir,
+                                           activation='Sigmoid', cmvn=cmvn), 200 + ci).to(gpu)
+    pred, res = rhead(features=feats, linears=_T(G[f'res_{tag}_linears'], gpu))
+    ((pred * G1).sum() + (res['offset'] * G2).sum()).backward()
+    assert rel_l2(res['offset'], _T(G[f'res_{tag}_offset'])) < 1e-2
+    assert rel_l2(pred, _T(G[f'res_{tag}_predicted'])) < 1e-2
+    RH.check_grad_samples(G, f'res_{tag}', [p.grad for p in rhead.parameters()], 1000 * ci + 500, 4e-2, 'Residual')

@@ -130,3 +130,35 @@ def test_colsum_groups(gpu):
     out = torch.empty(G, 1024, device=gpu)
     L.check(lib.se_colsum_groups(L.ptr(xb), 1, G, R, 1024, 1024, L.ptr(out), L.stream()), 'colsum_groups')
     assert (out.double() - xb.double().view(G, R, 1024).sum(1)).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize('lid', [None, 1])
+def test_lstm_scoring_vs_reference_golden(gpu, golden_heads, lid):
+    """one batched sweep against what the REFERENCE's own sampler.scoring + sampler.matching returned (B sequential backward passes through its
+    model.LSTM + objective.L1; tests/golden/make_golden.py: heads_fixture) for the same seeded parameters and fixture features"""
+    import numpy as np
+    import ref_heads as RH
+    from speech_enhancement_by_s3prl_amd import scoring
+    from speech_enhancement_by_s3prl_amd.lstm import LSTM
+    G = golden_heads
+    t = 'all' if lid is None else f'l{lid}'
+    T_ = lambda x: torch.from_numpy(np.asarray(x))      # noqa: E731
+    feats, tar, lengths = T_(G['score_feats']), T_(G['score_linear_tar']), T_(G['score_lengths'])
+    head = RH.seeded.fill_params(LSTM(input_size=RH.HEAD_D, output_size=RH.HEAD_K, hidden_size=256, num_layers=2, bidirectional=True), 300).to(gpu)
+    frames = (lengths // 160 + 1).to(gpu)                           # runner.py:455
+    got = scoring.per_sample_gradients_lstm(head, feats.to(gpu), tar.to(gpu), frames, active_layerid=lid).double().cpu()
+    assert got.shape == (3, int(G[f'score_{t}_numel']))
+    idx = RH.seeded.sample_index(got.shape[1], RH.seeded.SCORE_SAMPLES, 4242)
+    ref_s, ref_n = T_(G[f'score_{t}_samp']).double(), T_(G[f'score_{t}_norms']).double()
+    for b in range(3):
+        cos = torch.nn.functional.cosine_similarity(got[b, idx], ref_s[b], dim=0).item()
+        ratio = (got[b].norm() / ref_n[b]).item()
+        assert cos > 0.99, (b, cos)
+        assert abs(ratio - 1) < 0.05, (b, ratio)
+    gram = got @ got.t()
+    rg = T_(G[f'score_{t}_gram']).double()
+    d = rg.diag().sqrt()
+    assert ((gram / (got.norm(dim=1)[:, None] * got.norm(dim=1)[None])) - rg / (d[:, None] * d[None])).abs().max().item() < 0.03      # pairwise cosines
+    m_got = scoring.matching(got[:2].float(), got.float())
+    assert (m_got - T_(G[f'score_{t}_match'])).abs().max().item() < 0.03
+    assert torch.equal(scoring.thresholding(m_got), T_(G[f'score_{t}_keep']))

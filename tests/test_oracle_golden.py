@@ -84,3 +84,49 @@ def test_input_contract_add_noise_collate(golden):
     assert torch.allclose(synth.normalize_wav_decibel(T(golden['nwd_in'])), T(golden['nwd_out']), rtol=1e-6)
     lengths, wavs = synth.collate_fn([T(golden['col_s0']), T(golden['col_s1']), T(golden['col_s2'])])
     assert torch.equal(lengths, T(golden['col_lengths'])) and torch.equal(wavs, T(golden['col_wavs']))
+
+
+# ---- the restatements the HIP recurrent heads and the per-utterance scoring are compared with (tests/ref_heads.py) are
+# pinned HERE to outputs of the reference's own model.LSTM / model.Residual / sampler.scoring (tests/golden/reference_golden_heads.npz)
+import pytest  # noqa: E402
+
+import ref_heads as RH  # noqa: E402
+
+
+@pytest.mark.parametrize('ci', range(len(RH.HEAD_CASES)))
+def test_ref_lstm_and_residual_restatements_vs_reference(golden_heads, ci):
+    G = golden_heads
+    tag, hidden, bidir, cmvn, layers = RH.HEAD_CASES[ci]
+    feats, G1, G2 = T(G[f'lstm_{tag}_feats']), T(G[f'lstm_{tag}_G1']), T(G[f'lstm_{tag}_G2'])
+    m = RH.seeded.fill_params(RH.RefLSTM(RH.HEAD_D, RH.HEAD_K, hidden, layers, bidir), 100 + ci)      # same seed as make_golden.py
+    pred, logp = m(feats)
+    ((pred * G1).sum() + (logp * G2).sum()).backward()
+    assert torch.allclose(logp, T(G[f'lstm_{tag}_log_predicted']), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(pred, T(G[f'lstm_{tag}_predicted']), rtol=1e-5, atol=1e-6)
+    RH.check_grad_samples(G, f'lstm_{tag}', [p.grad for p in m.parameters()], 1000 * ci, 1e-4, 'RefLSTM')
+    r = RH.seeded.fill_params(RH.RefResidual(RH.HEAD_D, RH.HEAD_K, hidden, layers, bidir, cmvn), 200 + ci)
+    pred, off = r(feats, T(G[f'res_{tag}_linears']))
+    ((pred * G1).sum() + (off * G2).sum()).backward()
+    assert torch.allclose(off, T(G[f'res_{tag}_offset']), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(pred, T(G[f'res_{tag}_predicted']), rtol=1e-5, atol=1e-6)
+    RH.check_grad_samples(G, f'res_{tag}', [p.grad for p in r.parameters()], 1000 * ci + 500, 1e-4, 'RefResidual')
+
+
+@pytest.mark.parametrize('lid', [None, 1])
+def test_sequential_scoring_restatement_vs_reference(golden_heads, lid):
+    G = golden_heads
+    t = 'all' if lid is None else f'l{lid}'
+    feats, tar, lengths = T(G['score_feats']), T(G['score_linear_tar']), T(G['score_lengths'])
+    m = RH.seeded.fill_params(RH.RefLSTM(RH.HEAD_D, RH.HEAD_K, 256, 2, True), 300)
+    _, logp = m(feats)
+    frames = lengths // 160 + 1                                     # runner.py:455
+    masks = odec.get_length_masks(frames)
+    grads = RH.sequential_scoring(list(m.named_parameters()), logp, tar, masks, oobj.l1, lid)
+    assert grads.shape[1] == int(G[f'score_{t}_numel'])
+    idx = RH.seeded.sample_index(grads.shape[1], RH.seeded.SCORE_SAMPLES, 4242)
+    assert torch.allclose(grads[:, idx], T(G[f'score_{t}_samp']), rtol=1e-4, atol=1e-7)
+    assert torch.allclose(grads.norm(dim=1), T(G[f'score_{t}_norms']), rtol=1e-5)
+    assert torch.allclose(grads @ grads.t(), T(G[f'score_{t}_gram']), rtol=1e-4, atol=1e-9)
+    match = oobj.matching(grads[:2], grads)
+    assert torch.allclose(match, T(G[f'score_{t}_match']), rtol=1e-4, atol=1e-6)
+    assert torch.equal(match > 0, T(G[f'score_{t}_keep']))

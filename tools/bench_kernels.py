@@ -203,6 +203,15 @@ def bench_mhsa():
     ms = timeit(run2)
     d = (ctx2.float() - ctx.float()).abs().max().item() / ctx.float().abs().max().item()
     print(f'mhsa prescaled B={B} T={T}: {ms*1e3:8.1f} us  {4.0*B*heads*T*T*64/ms/1e9:8.1f} TF/s   max diff vs the unscaled kernel {d:.2e}', flush=True)
+    # the selectable variants side by side, interleaved (0 = mhsa.hip, 8 = mhsa8.hip: 8-wave alternating segments)
+    ctx3 = torch.empty_like(ctx)
+    runs = {f'variant {v}': (lambda v=v: L.check(lib.se_mhsa_fwd_prescaled_variant_bf16(L.ptr(q2), None, B, T, heads, L.ptr(ctx3), v, L.stream()), 'mhsa-v'))
+            for v in (0, 8, 9, 16)}
+    for k, (mn, md) in interleaved(runs, rounds=5, iters=20).items():
+        print(f'mhsa prescaled {k}: {mn*1e3:8.1f} us (min) {md*1e3:8.1f} us (median)   {4.0*B*heads*T*T*64/md/1e9:8.1f} TF/s', flush=True)
+    runs['variant 8']()
+    d8 = (ctx3.float() - ctx2.float()).abs().max().item() / ctx2.float().abs().max().item()
+    print(f'mhsa variant 8 vs variant 0: max diff {d8:.2e}', flush=True)
 
 
 def bench_mhsa_peaked():
