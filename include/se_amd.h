@@ -175,7 +175,8 @@ int se_length_masks_i64(const int64_t* lengths, int B, int max_len, int64_t* mas
  *   offset    (B, F, N) = act(feats W^T + bias)                      (may be NULL)
  *   predicted (B, F, N) = linears * offset  if linears != NULL (C1)  else = offset (C2)
  *   workspace >= se_head_workspace_bytes(B, F, D, N)
- *   Exact fp32 arithmetic (f32-input MFMA, k-ordered fmaf chain).
+ *   fp32 arithmetic: both operands as three-term bf16 splits (x = x1 + x2 + x3, residuals exact), the six products of weight >= 2^-16 on the
+ *   bf16 matrix instruction with fp32 accumulation (every product exact; dropped terms <= 2^-24): an fp32 dot product in another summation order.
  */
 size_t se_head_workspace_bytes(int B, int F, int D, int N);
 int se_head_linear_f32(const float* feats, const float* W, const float* bias, const float* linears,

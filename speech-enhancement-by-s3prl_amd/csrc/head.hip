@@ -9,6 +9,7 @@
 //              conflict-free ds_read_b32 operand fetches).
 // Bound: HBM (4*F*(D + 2N) bytes per utterance, +4*F*N when `offset` is stored); the f32 MFMA rate
 // (157 TF) puts the GEMM itself at about the same time, so the kernel is balanced, not MFMA-bound.
+#include <stdlib.h>
 #include "common.h"
 #include "prof.h"
 
@@ -230,6 +231,198 @@ __global__ __launch_bounds__(256, 2) void head_kernel(const float* __restrict__ 
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+// Round 4: the SAME fp32 result on the bf16 matrix instruction.  VERDICT r3 #6: the kernel above is not HBM-bound but fp32-MFMA-bound --
+// v_mfma_f32_32x32x2_f32 runs at 1/16 of the bf16 rate: at D = 201, 256 utterances, 23 GFLOP / 155 TF/s = 149 us against a 77 us HBM floor.
+// Here both operands are split into THREE bf16 terms, x = x1 + x2 + x3 (x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2): the residuals are
+// exact in fp32, the dropped remainder is <= 2^-24 |x|), and the product is the six terms whose weight is >= 2^-16:
+//     x w  =  x1 w1 + (x1 w2 + x2 w1) + (x2 w2 + x1 w3 + x3 w1)  + O(2^-24)
+// -- every bf16 product is exact in the fp32 accumulator, so the sum is an fp32 dot product with a different (and no worse) summation order.  Six
+// v_mfma_f32_32x32x16_bf16 (6 x 32 cycles for 16 k) replace eight v_mfma_f32_32x32x2_f32 (8 x 64 cycles): 2.7 x less matrix time, which puts the
+// kernel under its HBM floor.  Weights arrive pre-split (head_split_w_kernel: 3 planes [NT * 32][Kp] bf16, zero padded), the features are split
+// while they are staged (CMVN first, in fp32).  LDS: 16-k chunks, rows at a 48-B pitch (conflict-free ds_read_b128 of 16 consecutive rows):
+// 3 x (128 + NT * 32) x 48 B = 50.7 KB at N = 201 -> 3 workgroups per CU as before.  Epilogue: the kernel above's, unchanged (same C / D map).
+constexpr int kH3K = 16;          // k per chunk
+constexpr int kH3P = 48;          // row pitch of a plane in bytes: 32 B of data (16 bf16) + 16 B
+typedef __attribute__((ext_vector_type(8))) __bf16 h3_bf16x8;
+
+__device__ __forceinline__ void split3(float x, uint16_t& a, uint16_t& b, uint16_t& c) {
+  const __bf16 x1 = (__bf16)x;
+  const float r1 = x - (float)x1;
+  const __bf16 x2 = (__bf16)r1;
+  const float r2 = r1 - (float)x2;
+  const __bf16 x3 = (__bf16)r2;
+  a = __builtin_bit_cast(uint16_t, x1);
+  b = __builtin_bit_cast(uint16_t, x2);
+  c = __builtin_bit_cast(uint16_t, x3);
+}
+
+// W (N, D) fp32 -> W3 [3][rows_p][Kp] bf16 (rows >= N and k >= D are zero)
+__global__ __launch_bounds__(256) void head_split_w_kernel(const float* __restrict__ W, int N, int D, int rows_p, int Kp, uint16_t* __restrict__ W3) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows_p * Kp) return;
+  const int n = i / Kp, k = i - n * Kp;
+  const float v = (n < N && k < D) ? W[(size_t)n * D + k] : 0.f;
+  uint16_t a, b, c;
+  split3(v, a, b, c);
+  W3[i] = a;
+  W3[(size_t)rows_p * Kp + i] = b;
+  W3[2 * (size_t)rows_p * Kp + i] = c;
+}
+
+template <int NT>
+__global__ __launch_bounds__(256, 3) void head3_kernel(const float* __restrict__ feats, const uint16_t* __restrict__ W3, int Kp,
+                                                       const float* __restrict__ bias, const float* __restrict__ linears,
+                                                       const float* __restrict__ stats, int rows, int F, int D, int N, int act,
+                                                       float* __restrict__ predicted, float* __restrict__ offset, int vec_io) {
+  constexpr int kAPlane = kHM * kH3P, kWPlane = NT * 32 * kH3P;      // bytes per plane
+  constexpr int kStage = 3 * (kAPlane + kWPlane);
+  constexpr int kEpi = 4 * kHHalf * (NT * 32) * 4;
+  __shared__ __attribute__((aligned(16))) char smem3[kStage > kEpi ? kStage : kEpi];
+  char* As = smem3;
+  char* Ws = smem3 + 3 * kAPlane;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int row0 = blockIdx.x * kHM;
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  const size_t wplane = (size_t)NT * 32 * Kp;
+  for (int k0 = 0; k0 < Kp; k0 += kH3K) {
+    __syncthreads();
+    // ---- features: item = (row, 4-float piece): 128 x 4 = 512 items; CMVN in fp32, then the three-term split, 8 B per plane
+#pragma unroll
+    for (int rep = 0; rep < 2; ++rep) {
+      const int it = tid + 256 * rep;
+      const int r = it >> 2, c = it & 3;
+      const int row = row0 + r, k = k0 + 4 * c;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < rows && k < D) {
+        const float* src = feats + (size_t)row * D + k;
+        if (k + 3 < D) {
+          v = *reinterpret_cast<const float4*>(src);
+        } else {
+          v.x = src[0];
+          if (k + 1 < D) v.y = src[1];
+          if (k + 2 < D) v.z = src[2];
+        }
+        if (stats) {
+          const float* sp = stats + ((size_t)(row / F) * D + k) * 2;           // (mean, 1 / (std + eps)) pairs
+          if (k + 3 < D) {
+            const float4 s0 = *reinterpret_cast<const float4*>(sp), s1 = *reinterpret_cast<const float4*>(sp + 4);
+            v = make_float4((v.x - s0.x) * s0.y, (v.y - s0.z) * s0.w, (v.z - s1.x) * s1.y, (v.w - s1.z) * s1.w);
+          } else {
+            v.x = (v.x - sp[0]) * sp[1];
+            if (k + 1 < D) v.y = (v.y - sp[2]) * sp[3];
+            if (k + 2 < D) v.z = (v.z - sp[4]) * sp[5];
+          }
+        }
+      }
+      uint16_t p0[4], p1[4], p2[4];
+      split3(v.x, p0[0], p1[0], p2[0]);
+      split3(v.y, p0[1], p1[1], p2[1]);
+      split3(v.z, p0[2], p1[2], p2[2]);
+      split3(v.w, p0[3], p1[3], p2[3]);
+      char* d = As + r * kH3P + c * 8;
+      *reinterpret_cast<uint2*>(d) = make_uint2(p0[0] | ((uint32_t)p0[1] << 16), p0[2] | ((uint32_t)p0[3] << 16));
+      *reinterpret_cast<uint2*>(d + kAPlane) = make_uint2(p1[0] | ((uint32_t)p1[1] << 16), p1[2] | ((uint32_t)p1[3] << 16));
+      *reinterpret_cast<uint2*>(d + 2 * kAPlane) = make_uint2(p2[0] | ((uint32_t)p2[1] << 16), p2[2] | ((uint32_t)p2[3] << 16));
+    }
+    // ---- weights: item = (plane, output row, 16-B half): 3 x NT * 32 x 2
+    for (int it = tid; it < 3 * NT * 32 * 2; it += 256) {
+      const int p = it / (NT * 32 * 2), rem = it - p * (NT * 32 * 2);
+      const int n = rem >> 1, h = rem & 1;
+      const uint4 v = *reinterpret_cast<const uint4*>(W3 + p * wplane + (size_t)n * Kp + k0 + 8 * h);
+      *reinterpret_cast<uint4*>(Ws + p * kWPlane + n * kH3P + 16 * h) = v;
+    }
+    __syncthreads();
+    const char* ap = As + (wave * 32 + (lane & 31)) * kH3P + 16 * (lane >> 5);
+    const char* wp = Ws + (lane & 31) * kH3P + 16 * (lane >> 5);
+    const h3_bf16x8 a0 = *reinterpret_cast<const h3_bf16x8*>(ap), a1 = *reinterpret_cast<const h3_bf16x8*>(ap + kAPlane),
+                    a2 = *reinterpret_cast<const h3_bf16x8*>(ap + 2 * kAPlane);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const char* wt = wp + t * 32 * kH3P;
+      const h3_bf16x8 w0 = *reinterpret_cast<const h3_bf16x8*>(wt), w1 = *reinterpret_cast<const h3_bf16x8*>(wt + kWPlane),
+                      w2 = *reinterpret_cast<const h3_bf16x8*>(wt + 2 * kWPlane);
+      // smallest terms first
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, w0, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, w2, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, w1, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, w0, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, w1, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, w0, acc[t], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue: as head_kernel (same accumulator map)
+  __syncthreads();
+  float* Es = reinterpret_cast<float*>(smem3) + wave * (kHHalf * NT * 32);
+  float bn[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int n = t * 32 + (lane & 31);
+    bn[t] = (bias && n < N) ? bias[n] : 0.f;
+  }
+#pragma unroll
+  for (int h = 0; h < 32 / kHHalf; ++h) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int n = t * 32 + (lane & 31);
+      if (n < N) {
+#pragma unroll
+        for (int r8 = 0; r8 < kHHalf / 2; ++r8) {
+          const int r = (kHHalf / 2) * h + r8;
+          const int rl = (r & 3) + (kHHalf == 16 ? 8 * ((r >> 2) & 1) : 0) + 4 * (lane >> 5);
+          Es[rl * N + n] = apply_act(acc[t][r] + bn[t], act);
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const int rbase = row0 + wave * 32 + kHHalf * h;
+    const int nrow = min(kHHalf, rows - rbase);
+    if (nrow > 0) {
+      const int cnt = nrow * N;
+      const size_t g = (size_t)rbase * N;
+      if (vec_io) {
+        const int nvec = cnt >> 2;
+        for (int i = lane; i < nvec; i += 64) {
+          const float4 o = *reinterpret_cast<const float4*>(Es + 4 * i);
+          if (offset) *reinterpret_cast<float4*>(offset + g + 4 * i) = o;
+          if (predicted) {
+            float4 p = o;
+            if (linears) {
+              const float4 l = *reinterpret_cast<const float4*>(linears + g + 4 * i);
+              p = make_float4(o.x * l.x, o.y * l.y, o.z * l.z, o.w * l.w);
+            }
+            *reinterpret_cast<float4*>(predicted + g + 4 * i) = p;
+          }
+        }
+        for (int i = 4 * nvec + lane; i < cnt; i += 64) {
+          const float o = Es[i];
+          if (offset) offset[g + i] = o;
+          if (predicted) predicted[g + i] = linears ? linears[g + i] * o : o;
+        }
+      } else {
+        for (int i = lane; i < cnt; i += 64) {
+          const float o = Es[i];
+          if (offset) offset[g + i] = o;
+          if (predicted) predicted[g + i] = linears ? linears[g + i] * o : o;
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  }
+}
+
 }  // namespace se
 
 // internal (not part of the public header): column statistics shared with head_bwd.hip
@@ -241,8 +434,21 @@ extern "C" int se_head_colstats_f32(const float* feats, int B, int F, int D, flo
 
 extern "C" size_t se_head_workspace_bytes(int B, int F, int D, int N) {
   (void)F;
-  // [stats: B*D*2 floats][bwd scratch: g_pre (B*F*N) is NOT kept here; see se_head_linear_bwd_f32]
-  return (size_t)B * D * 2 * sizeof(float) + 256;
+  // [stats: B*D*2 floats][three-term bf16 split of the weights: 3 planes x ceil32(N) x ceil16(D) bf16][bwd scratch: g_pre (B*F*N) is NOT kept
+  // here; see se_head_linear_bwd_f32]
+  const size_t rows_p = (size_t)((N + 31) / 32) * 32, Kp = (size_t)((D + 15) / 16) * 16;
+  return (((size_t)B * D * 2 * sizeof(float) + 255) & ~(size_t)255) + 3 * rows_p * Kp * sizeof(uint16_t) + 256;
+}
+
+template <int NT>
+static int launch_head3(const float* feats, const uint16_t* W3, int Kp, const float* bias, const float* linears, const float* stats,
+                        int rows, int F, int D, int N, int act, float* predicted, float* offset, hipStream_t st) {
+  const int vec_io = ((((uintptr_t)predicted | (uintptr_t)offset | (uintptr_t)linears) % 16) == 0) ? 1 : 0;
+  se::ProfScope prof(se::kProfHead, 4.0 * rows * ((double)D + (linears ? N : 0) + (predicted ? N : 0) + (offset ? N : 0)), st);
+  hipLaunchKernelGGL((se::head3_kernel<NT>), dim3((rows + se::kHM - 1) / se::kHM), dim3(256), 0, st, feats, W3, Kp, bias, linears,
+                     stats, rows, F, D, N, act, predicted, offset, vec_io);
+  SE_LAUNCH_CHECK();
+  return SE_OK;
 }
 
 template <int NT>
@@ -264,14 +470,31 @@ extern "C" int se_head_linear_f32(const float* feats, const float* W, const floa
   SE_REQUIRE(B > 0 && B <= 65535 && F >= 2 && D > 0 && N > 0 && N <= 256, "se_head_linear_f32: bad shape B=%d F=%d D=%d N=%d (N <= 256)", B, F, D, N);
   hipStream_t st = se::as_stream(stream);
   float* stats = nullptr;
+  SE_REQUIRE(workspace && workspace_bytes >= se_head_workspace_bytes(B, F, D, N), "se_head_linear_f32: workspace too small");
   if (cmvn) {
-    SE_REQUIRE(workspace && workspace_bytes >= se_head_workspace_bytes(B, F, D, N), "se_head_linear_f32: workspace too small");
     stats = reinterpret_cast<float*>(workspace);
     int rc = se_head_colstats_f32(feats, B, F, D, eps, stats, stream);
     if (rc) return rc;
   }
   const int rows = B * F;
   const int nt = (N + 31) / 32;
+  static const bool fp32_mfma = getenv("SE_AMD_HEAD_F32MFMA") != nullptr;      // developer A/B: the round-3 kernel on v_mfma_f32_32x32x2_f32
+  if (!fp32_mfma) {
+    const int rows_p = nt * 32, Kp = (D + 15) / 16 * 16;
+    uint16_t* W3 = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(workspace) + (((size_t)B * D * 2 * sizeof(float) + 255) & ~(size_t)255));
+    hipLaunchKernelGGL(se::head_split_w_kernel, dim3((rows_p * Kp + 255) / 256), dim3(256), 0, st, W, N, D, rows_p, Kp, W3);
+    SE_LAUNCH_CHECK();
+    switch (nt) {
+      case 1: return launch_head3<1>(feats, W3, Kp, bias, linears, stats, rows, F, D, N, act, predicted, offset, st);
+      case 2: return launch_head3<2>(feats, W3, Kp, bias, linears, stats, rows, F, D, N, act, predicted, offset, st);
+      case 3: return launch_head3<3>(feats, W3, Kp, bias, linears, stats, rows, F, D, N, act, predicted, offset, st);
+      case 4: return launch_head3<4>(feats, W3, Kp, bias, linears, stats, rows, F, D, N, act, predicted, offset, st);
+      case 5: return launch_head3<5>(feats, W3, Kp, bias, linears, stats, rows, F, D, N, act, predicted, offset, st);
+      case 6: return launch_head3<6>(feats, W3, Kp, bias, linears, stats, rows, F, D, N, act, predicted, offset, st);
+      case 7: return launch_head3<7>(feats, W3, Kp, bias, linears, stats, rows, F, D, N, act, predicted, offset, st);
+      default: return launch_head3<8>(feats, W3, Kp, bias, linears, stats, rows, F, D, N, act, predicted, offset, st);
+    }
+  }
   switch (nt) {
     case 1: return launch_head<1>(feats, W, bias, linears, stats, rows, F, D, N, act, predicted, offset, st);
     case 2: return launch_head<2>(feats, W, bias, linears, stats, rows, F, D, N, act, predicted, offset, st);

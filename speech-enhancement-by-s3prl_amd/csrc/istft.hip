@@ -332,7 +332,9 @@ extern "C" int se_istft_tphase_f32(const se_plan* plan, const float* power, cons
   hipStream_t st = se::as_stream(stream);
   if (use2 || log_input) {
     int rc = se_istft2p_tphase_f32(plan, power, tphase, B, F, log_input, wav_out, wav_stride, lengths, sumsq_out, stream);
-    if (rc == SE_OK && ref_sumsq_out) rc = se_masked_sumsq_f32(ref, B, n_out, ref_stride, lengths, ref_sumsq_out, stream);
+    // the reference's sum runs over [0, min(stride, length)) -- as in the default kernel and in masked_normalize_decibel (utils.py:31-46) -- not over
+    // the n_out = hop (F - 1) samples the inverse transform produces: up to hop - 1 samples of the reference lie past that when T % hop != 0
+    if (rc == SE_OK && ref_sumsq_out) rc = se_masked_sumsq_f32(ref, B, std::min(wav_stride, ref_stride), ref_stride, lengths, ref_sumsq_out, stream);
     return rc;
   }
   if (sumsq_out) {      // one clearing launch for both accumulators when they sit side by side

@@ -206,7 +206,7 @@ int resident_workgroups_q(int per_cu) {
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
     else cus = 256;
   }
-  if (const char* e = getenv("SE_AMD_STFT_SLOTS")) return atoi(e);      // developer A/B: e.g. 1000000 = one chunk per workgroup (non-persistent)
+  if (const char* e = getenv("SE_AMD_STFT_SLOTS")) return std::max(1, atoi(e));      // developer A/B: e.g. 1000000 = one chunk per workgroup (non-persistent)
   return cus * per_cu;
 }
 

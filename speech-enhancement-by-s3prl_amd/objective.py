@@ -37,8 +37,13 @@ class _L1Fn(torch.autograd.Function):
         if reduce_fn is None:
             # one launch: sums, count AND the loss come out of the kernel (last-arriving workgroup), no zeroing launch, no division kernels
             loss = torch.empty((), device=lp.device, dtype=torch.float32)
-            _lib.check(lib.se_l1_masked_loss_f32(_lib.ptr(lp), _lib.ptr(tar), _lib.ptr(lens), int(len_div), B, F, K, float(eps), _lib.ptr(_l1_scratch(lp.device, B)),
-                                                 _lib.ptr(sums), _lib.ptr(loss), _lib.ptr(grad), _lib.stream()), 'se_l1_masked_loss_f32')
+            rc = lib.se_l1_masked_loss_f32(_lib.ptr(lp), _lib.ptr(tar), _lib.ptr(lens), int(len_div), B, F, K, float(eps), _lib.ptr(_l1_scratch(lp.device, B)),
+                                           _lib.ptr(sums), _lib.ptr(loss), _lib.ptr(grad), _lib.stream())
+            if rc != 0:
+                # the arrival ticket is reset by the launch's LAST workgroup: after a launch that did not run to completion it may be anything, and a
+                # stale ticket would leave `loss` unwritten on every later call -- start the next call from a fresh zeroed scratch
+                _L1_SCRATCH.clear()
+            _lib.check(rc, 'se_l1_masked_loss_f32')
             ctx.save_for_backward(grad if grad is not None else torch.empty(0), sums)
             return loss
         if len_div:

@@ -289,9 +289,18 @@ class OnlinePreprocessor(nn.Module):
         ob = outs[b] if b >= 0 else {}
         _lib.check(lib.se_stft_tphase_f32(self._plan(dev), _lib.ptr(wavs3), B, C, T, a, g(outs[a], 'linear'), g(outs[a], '_tphase'), g(outs[a], 'mel'),
                                           b, g(ob, 'linear'), g(ob, '_tphase'), g(ob, 'mel'), _lib.stream()), 'se_stft_tphase_f32')
+        # The true atan2 phase is recomputed FROM THE WAVEFORMS on first use, and `wavs3` is the caller's own tensor whenever that was already
+        # contiguous fp32 on the device: the lazy phase is tied to that buffer's contents.  A caller that refills the buffer in place (a static graph
+        # input, wavs.copy_(next_batch)) before reading the phase would get the phase of ANOTHER batch next to this call's `linear` planes: the
+        # version counter recorded here turns that into an error; `lazy_phase = False` restores the eager, self-contained result.
+        ver0 = wavs3._version
         for ch in chans:
             if 'phase' in need[ch]:
                 def materialize(ch=ch):
+                    if wavs3._version != ver0:
+                        raise RuntimeError('LazyPhase: the waveform batch this phase belongs to was modified in place after preprocessor(wavs) returned '
+                                           '(version %d -> %d); read the phase before re-using the input buffer, or set preprocessor.lazy_phase = False'
+                                           % (ver0, wavs3._version))
                     return self._stft_channel(wavs3, ch, {'phase'})['phase'].reshape(*lead, F, K)
                 ph = outs[ch].get('_tphase')
                 outs[ch]['phase'] = LazyPhase((*lead, F, K), dev, materialize, None if ph is None else ph.reshape(*lead, F, K))

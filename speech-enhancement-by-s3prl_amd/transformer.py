@@ -449,10 +449,13 @@ class _Engine:
         """cached weight split (N, 3 Kp) bf16 of an nn.Linear weight (or a row-concatenation of several), re-made when a parameter changes"""
         ws = weight if isinstance(weight, (tuple, list)) else (weight,)
         key = tuple(id(t) for t in ws)
-        ver = tuple(t._version for t in ws) + (ws[0].device,)
+        # validity: storage address + version counter + device of every source tensor (the bf16 path's _ensure scheme): `p.data = other` moves
+        # data_ptr without bumping _version, and an id() can be reused by a new tensor once the old one died -- the weak references below drop the
+        # entry then
+        ver = tuple((t.data_ptr(), t._version, t.device) for t in ws)
         cache = self.__dict__.setdefault('_w3_cache', {})
         hit = cache.get(key)
-        if hit is not None and hit[0] == ver:
+        if hit is not None and hit[0] == ver and all(r() is t for r, t in zip(hit[3], ws)):
             return hit[1], hit[2]
         lib = _lib.load()
         w = torch.cat([t.detach().float() for t in ws], dim=0).contiguous() if len(ws) > 1 else ws[0].detach().float().contiguous()
@@ -460,7 +463,8 @@ class _Engine:
         Kp = (K + 63) // 64 * 64
         out = torch.empty(N, 3 * Kp, device=w.device, dtype=torch.bfloat16)
         _lib.check(lib.se_split3_bf16(_lib.ptr(w), K, N, K, Kp, 1, _lib.ptr(out), _lib.stream()), 'se_split3_bf16')
-        cache[key] = (ver, out, Kp)
+        import weakref
+        cache[key] = (ver, out, Kp, tuple(weakref.ref(t) for t in ws))
         return out, Kp
 
     def _linear3(self, x, weight, bias, M, N, K, act=0, residual=None, out=None):
@@ -492,13 +496,16 @@ class _Engine:
             lengths = torch.empty(B, device=dev, dtype=torch.int32)
             _lib.check(lib.se_valid_lengths_i32(_lib.ptr(feats), B, T, D, _lib.ptr(lengths), _lib.stream()), 'se_valid_lengths_i32')
         M = B * T
-        pe = getattr(self, '_pe32x', None)
-        if pe is None or pe.shape != (M, H) or pe.device != dev:
+        # the (T, H) sinusoid table is what is cached (key: T, H, device); it is tiled to the GEMM's per-output-row residual operand (B T, H) per call.
+        # (The first version cached the TILED table keyed on its shape (B T, H): (B, T) = (4, 500) followed by (2, 1000) hit that entry and added the
+        # positions of the wrong T from the second utterance on -- ADVICE r3.)
+        tab = getattr(self, '_pe32x', None)
+        if tab is None or tab.shape != (T, H) or tab.device != dev:
             pos = torch.arange(T, dtype=torch.float64)[:, None]
             j = torch.arange(H, dtype=torch.float64)[None, :]
             ang = pos / torch.pow(torch.tensor(10000.0, dtype=torch.float64), 2.0 * torch.floor(j / 2.0) / H)
-            tab = torch.where((torch.arange(H) % 2 == 0)[None, :], torch.sin(ang), torch.cos(ang))
-            pe = self._pe32x = tab.float().to(dev).repeat(B, 1).contiguous()      # (B T, H): the GEMM's residual operand is per output row
+            tab = self._pe32x = torch.where((torch.arange(H) % 2 == 0)[None, :], torch.sin(ang), torch.cos(ang)).float().to(dev).contiguous()
+        pe = tab.repeat(B, 1)
         ir = model.input_representations
         w = lambda p: p.detach().contiguous()       # noqa: E731
         x = self._linear3(feats.view(M, D), ir.spec_transform.weight, w(ir.spec_transform.bias), M, H, D, residual=pe)

@@ -158,3 +158,20 @@ def test_mhsa_x3_vs_fp64(gpu, B, T, heads, lens):
     assert torch.isfinite(ctx).all()
     err = (ctx.double() - ref).abs().max().item() / ref.abs().max().item()
     bounded(f'mhsa_x3[{B},{T},{heads}] context max-norm', err, 3e-5)
+
+
+def test_x3_position_table_follows_the_sequence_length(gpu):
+    """the three-term mode cached its positional table TILED to (B T, H) and keyed on that shape, so (B, T) = (2, 2 T') followed by
+    (4, T') -- same B T -- reused the positions of the other T.  The same engine run at both shapes must agree with the fp32 mode each time."""
+    from speech_enhancement_by_s3prl_amd import pipeline
+    cfg = pipeline.make_config(layers=1)
+    ckpt = pipeline.synthetic_checkpoint(cfg, seed=3)
+    up = pipeline.build_upstream(ckpt, gpu)
+    torch.manual_seed(0)
+    for B, T in ((2, 96), (4, 48), (1, 192)):
+        feats = torch.randn(B, T, 80, device=gpu)
+        with torch.no_grad():
+            h3 = up.set_precision('bf16x3')(feats)
+            h32 = up.set_precision('fp32')(feats)
+        assert rel_l2(h3, h32.cpu()) < 3e-5, (B, T, rel_l2(h3, h32.cpu()))
+    up.set_precision('bf16')

@@ -292,3 +292,30 @@ def test_unused_downstream_feature_costs_nothing(P, gpu):
     assert feats[1]._value is None                     # still nothing computed
     assert torch.equal(feats[1] * 1.0, eager[1])       # first use materialises it
     assert feats[1]._value is not None and torch.equal(feats[0], eager[0])
+
+
+def test_lazy_phase_is_tied_to_the_input_buffer(P, gpu):
+    """the lazy phase recomputes atan2 from the caller's waveform buffer: an in-place refill between preprocessor(wavs) and the first read of the
+    phase must be an ERROR (it would be the phase of another batch next to this call's `linear` planes), not a silent wrong answer; a phase
+    read BEFORE the refill, the istft() fast path (which never touches the waveforms again) and the eager mode are unaffected"""
+    torch.manual_seed(11)
+    wavs = (torch.randn(2, 2, 16000) * 0.1).to(gpu)
+    nxt = (torch.randn(2, 2, 16000) * 0.1).to(gpu)
+    P.channel_inp, P.channel_tar = 0, 1
+    f = P(wavs)
+    early = f[5] + 0                                   # read before the refill: fine
+    wav_fast = P.istft(f[2], f[3])                     # the encoded phase word: independent of the buffer
+    wavs.copy_(nxt)
+    with pytest.raises(RuntimeError, match='modified in place'):
+        f[3].materialize()
+    with pytest.raises(RuntimeError, match='modified in place'):
+        f[3] + 0
+    assert torch.equal(P.istft(f[2], f[3]), wav_fast)
+    assert torch.isfinite(early).all()
+    P.lazy_phase = False
+    try:
+        e = P(wavs)
+        wavs.zero_()
+        assert torch.isfinite(e[3]).all() and e[3].abs().max().item() > 1.0      # eager phase: a plain tensor, self-contained
+    finally:
+        P.lazy_phase = True
