@@ -503,12 +503,18 @@ extern "C" int se_mhsa_fwd_stamps_bf16(const uint16_t* qkv, const int32_t* lengt
 #endif
 
 extern "C" int se_mhsa_fwd_prescaled_bf16(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, void* stream) {
-  static int pipe = -1;
-  if (pipe < 0) {
+  static int pipe = -2, min_wgs = 768;
+  if (pipe == -2) {
     const char* e = getenv("SE_AMD_MHSA_PIPE");
-    pipe = e ? atoi(e) : 0;      // measured slower than this file's kernel (169 vs 143 us): see the header of mhsa_pipe.hip
+    pipe = e ? atoi(e) : -1;     // A/B: force one variant (0 = this file's kernel, 1 .. 3, 8, 9, 10, 12, 16: the experiments, all parity-tested)
+    if (const char* m = getenv("SE_AMD_MHSA8_MIN_WGS")) min_wgs = atoi(m);
   }
-  return mhsa_prescaled_launch(qkv, lengths, B, T, heads, ctx, pipe, stream);
+  if (pipe >= 0) return mhsa_prescaled_launch(qkv, lengths, B, T, heads, ctx, pipe, stream);
+  // default (round 4): 8-wave workgroups on one LDS-DMA staged K / V tile, two per CU, half of each SIMD's waves half a tile behind (mhsa8.hip:
+  // mhsaN_fwd_kernel<8, 4, 1>; 107 vs 118 us at B = 32) from 768 such workgroups (1.5 per CU slot pair) on -- B >= 16 at T = 1001; below that this
+  // file's 4-wave workgroups (three per CU, twice as many of them) cover the CUs better (profiles/r04_mhsa_bsweep.txt)
+  const long wgs8 = (long)((T + 255) / 256) * heads * B;
+  return mhsa_prescaled_launch(qkv, lengths, B, T, heads, ctx, wgs8 >= min_wgs ? 10 : 0, stream);
 }
 
 // test / measurement surface: variant 0 = this file's kernel, 1 = the software-pipelined experiment of mhsa_pipe.hip, 2 = two query blocks per wave (mhsa2.hip)

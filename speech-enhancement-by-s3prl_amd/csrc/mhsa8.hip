@@ -328,10 +328,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // Three-slot ring, tile t + 2 issued at the top of tile t, own piece(s) of tile t + 1 awaited (counted vmcnt) in front of the tile's one barrier.
 // WPE = waves per SIMD the register allocation is held to: <8, 2> one 8-wave workgroup per CU, <8, 4> TWO (128 registers; two independent barrier
 // domains), <16, 4> one 16-wave workgroup
-template <int NW, int WPE>
+// STAG = 1: the waves with (wave & 4) != 0 -- one half of every SIMD's residents -- take the tile's barrier in the MIDDLE of their tile (between the
+// softmax and the PV products) instead of at its end: a per-tile barrier otherwise re-aligns all waves of a SIMD at every tile top (they then queue
+// for the matrix pipe together and exponentiate together); with the shifted barrier the two halves run half a tile apart (MI355X_MICROARCH.md, "Two
+// waves per SIMD", item 9).  One more ring slot (4): a late wave still reads V of tile t - 1 after the barrier that lets the early ones start tile t.
+template <int NW, int WPE, int STAG = 0>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void mhsaN_fwd_kernel(
     const uint16_t* __restrict__ qkv, const int32_t* __restrict__ lengths, int T, int H, uint16_t* __restrict__ ctx, float dscale) {
-  __shared__ __attribute__((aligned(16))) char smem[3 * k8Slot];
+  constexpr int kRing = STAG ? 4 : 3;
+  __shared__ __attribute__((aligned(16))) char smem[kRing * k8Slot];
   static_assert(NW == 8 || NW == 16, "8 or 16 waves");
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -419,10 +424,19 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   SE8_BAR();
 
+  const bool late = STAG && (wave & 4) != 0;
+#define SEN_SYNC()                                                                                                            \
+  do {                                                                                                                        \
+    if (!(SE_MHSAN_ABL & 1)) {                                                                                                \
+      if (kt + 2 < nkt) { if (kPer == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); } \
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                   \
+    }                                                                                                                         \
+    if (!(SE_MHSAN_ABL & 2)) SE8_BAR();                                                                                       \
+  } while (0)
   int slot = 0;
   for (int kt = 0; kt < nkt; ++kt) {
     const char* t_s = smem + slot * k8Slot;
-    const int slot1 = slot == 2 ? 0 : slot + 1, slot2 = slot == 0 ? 2 : slot - 1;
+    const int slot1 = slot == kRing - 1 ? 0 : slot + 1, slot2 = slot1 == kRing - 1 ? 0 : slot1 + 1;      // (slot + 1), (slot + 2) mod ring
     if (kt + 2 < nkt && !(SE_MHSAN_ABL & 1)) SEN_DMA(kt + 2, slot2);       // the slot of tile kt - 1: every wave left it before the barrier that ended tile kt - 1
     f32x16 s0, s1;
 #pragma unroll
@@ -432,6 +446,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
       s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[s], s == 0 ? kZero16 : s0, 0, 0, 0);
       s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb_, qf[s], s == 0 ? kZero16 : s1, 0, 0, 0);
     }
+    // barrier positions of the staggered forms: STAG 1: early waves at the tile end, late ones after the softmax; 2: end / after QK^T;
+    // 3: after QK^T / after the softmax
+    if ((STAG == 2 && late) || (STAG == 3 && !late)) SEN_SYNC();
     if ((kt + 1) * kAK > len) {
       const int kbase = kt * kAK + 4 * hh;
 #pragma unroll
@@ -500,6 +517,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
           pf[1][s][j] = (__bf16)s1[8 * s + j];
         }
     }
+    if ((STAG == 1 || STAG == 3) && late) SEN_SYNC();
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -516,11 +534,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
           else o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, pf[kb][s], o1, 0, 0, 0);
         }
     // own piece(s) of tile kt + 1 (issued one tile ago) in LDS: all but the kPer just issued have completed
-    if (!(SE_MHSAN_ABL & 1)) {
-    if (kt + 2 < nkt) { if (kPer == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); }
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    if (!(SE_MHSAN_ABL & 2)) SE8_BAR();
+    if (STAG == 0 || ((STAG == 1 || STAG == 2) && !late)) SEN_SYNC();
     slot = slot1;
   }
 
@@ -546,7 +560,12 @@ int se_mhsaN_fwd_launch(const uint16_t* qkv, const int32_t* lengths, int B, int 
   const int H = heads * se::kHD;
   SE_REQUIRE((double)T * 3.0 * H * 2.0 < 2147483648.0, "se_mhsaN: T * 3 H * 2 = %.0f bytes exceeds the 31-bit DMA offset", (double)T * 3.0 * H * 2.0);
   dim3 grid((T + nw * 32 - 1) / (nw * 32), heads, B);
-  if (nw == 16) hipLaunchKernelGGL((se::mhsaN_fwd_kernel<16, 4>), grid, dim3(1024), 0, st, qkv, lengths, T, H, ctx, never_speculate ? -1.f : 1.f);
+  static const int stag = getenv("SE_AMD_MHSA_STAG") ? atoi(getenv("SE_AMD_MHSA_STAG")) : 1;      // A/B: 0 = every wave's barrier at the tile end; 1 .. 3: the staggered forms
+  if (nw == 16 && stag) hipLaunchKernelGGL((se::mhsaN_fwd_kernel<16, 4, 1>), grid, dim3(1024), 0, st, qkv, lengths, T, H, ctx, never_speculate ? -1.f : 1.f);
+  else if (nw == 8 && wpe == 4 && stag == 2) hipLaunchKernelGGL((se::mhsaN_fwd_kernel<8, 4, 2>), grid, dim3(512), 0, st, qkv, lengths, T, H, ctx, never_speculate ? -1.f : 1.f);
+  else if (nw == 8 && wpe == 4 && stag == 3) hipLaunchKernelGGL((se::mhsaN_fwd_kernel<8, 4, 3>), grid, dim3(512), 0, st, qkv, lengths, T, H, ctx, never_speculate ? -1.f : 1.f);
+  else if (nw == 8 && wpe == 4 && stag) hipLaunchKernelGGL((se::mhsaN_fwd_kernel<8, 4, 1>), grid, dim3(512), 0, st, qkv, lengths, T, H, ctx, never_speculate ? -1.f : 1.f);
+  else if (nw == 16) hipLaunchKernelGGL((se::mhsaN_fwd_kernel<16, 4>), grid, dim3(1024), 0, st, qkv, lengths, T, H, ctx, never_speculate ? -1.f : 1.f);
   else if (wpe == 4) hipLaunchKernelGGL((se::mhsaN_fwd_kernel<8, 4>), grid, dim3(512), 0, st, qkv, lengths, T, H, ctx, never_speculate ? -1.f : 1.f);
   else hipLaunchKernelGGL((se::mhsaN_fwd_kernel<8, 2>), grid, dim3(512), 0, st, qkv, lengths, T, H, ctx, never_speculate ? -1.f : 1.f);
   SE_LAUNCH_CHECK();

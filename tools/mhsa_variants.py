@@ -10,7 +10,7 @@ from speech_enhancement_by_s3prl_amd import _lib as L  # noqa: E402
 
 lib = L.load()
 dev = torch.device('cuda:0')
-B, T, heads = 32, 1001, 12
+B, T, heads = int(os.environ.get('MHSA_B', 32)), int(os.environ.get('MHSA_T', 1001)), 12
 torch.manual_seed(0)
 q = torch.randn(B * T, 3 * 768, device=dev)
 q[:, :768] *= 1.4426950408889634 / 8.0
@@ -31,4 +31,4 @@ for rnd in range(5):
         torch.cuda.synchronize()
         res[v].append(a.elapsed_time(b) / 20 * 1e3)
 tag = os.path.basename(os.environ.get('SE_AMD_LIB', 'libse_amd.so'))
-print(f'{tag:22s} ' + '   '.join(f'v{v}: {sorted(r)[len(r) // 2]:6.1f} us' for v, r in res.items()), flush=True)
+print(f'{tag:22s} B={B:3d} T={T} ' + '   '.join(f'v{v}: {sorted(r)[len(r) // 2]:6.1f} us' for v, r in res.items()), flush=True)
