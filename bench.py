@@ -582,7 +582,30 @@ def main():
     wd = os.environ.get('SE_BENCH_WATCHDOG')          # seconds: every thread's Python stack on stderr if the run is still going then (hang diagnosis)
     if wd:
         import faulthandler
+        import threading
         faulthandler.dump_traceback_later(float(wd), exit=False)
+
+        def _native_threads():
+            # what the NATIVE threads (gloo / RCCL workers, HIP runtime) are doing when the Python stacks say "everybody waits": name, scheduler
+            # state and kernel wait channel of every thread of this process (round 3's four-rank gloo hang had only the Python side on record)
+            lines = []
+            for tid in sorted(os.listdir('/proc/self/task'), key=int):
+                rec = []
+                for f in ('comm', 'wchan'):
+                    try:
+                        rec.append(open(f'/proc/self/task/{tid}/{f}').read().strip() or '-')
+                    except OSError:
+                        rec.append('?')
+                try:
+                    st = [ln.split()[1] for ln in open(f'/proc/self/task/{tid}/status') if ln.startswith('State:')][0]
+                except (OSError, IndexError):
+                    st = '?'
+                lines.append(f'  tid {tid:>8s} {st} {rec[0]:<24s} wchan {rec[1]}')
+            sys.stderr.write(f'[watchdog] rank {os.environ.get("RANK", "0")}: native threads\n' + '\n'.join(lines) + '\n')
+            sys.stderr.flush()
+        t = threading.Timer(float(wd) + 1.0, _native_threads)
+        t.daemon = True
+        t.start()
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)

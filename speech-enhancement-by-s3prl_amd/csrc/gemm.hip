@@ -220,7 +220,7 @@ extern "C" int se_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, int l
     // at B = 1, 1.81 vs 2.61 ms at B = 8 (tools/small_batch_sweep.sh); from B = 16 on the large tiles win again.
     // Round 2, with the 64-deep kernels: the crossover moved down to ~4 000 rows (ms per pass, small / large tiles: B = 4 1.14 / 1.14,
     // B = 5 1.30 / 1.22, B = 6 1.51 / 1.37, B = 8 1.69 / 1.57), so the threshold is 4 096 rows (was 8 192).
-    static int use5 = -1, use6 = 0, small_m = 4096;
+    static int use5 = -1, use6 = 0, small_m = 4096, min_n6 = 1536;
     if (use5 < 0) {
       const char* e5 = getenv("SE_AMD_GEMM5");       // developer switch: 1 = the one-wave-per-SIMD 256 x 256 kernel (gemm5.hip) for the bf16-output wide GEMMs
       use5 = e5 ? atoi(e5) : 0;
@@ -228,9 +228,12 @@ extern "C" int se_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, int l
       use6 = e6 ? atoi(e6) : 1;                      // default since round 2: +5-8 % over gemm3 on every wide shape (profiles/README.md)
       const char* sm = getenv("SE_AMD_GEMM_SMALL_M");   // row count up to which the 128 x 128 kernel is used (kernel benchmarks set 0)
       small_m = sm ? atoi(sm) : 4096;
+      if (const char* mn = getenv("SE_AMD_GEMM6_MIN_N")) min_n6 = atoi(mn);      // A/B: output width from which the 256 x 256 x 64 kernel is used
     }
     if (M <= small_m) return se_gemm2_launch(A, lda, W, ldw, bias, residual_f32, M, N, K, act, out_bf16, out_f32, ldc, vec_ok, 4, stream);
-    if (use6 && N >= 1536) {
+    // round 4: N = 768 outputs with a long reduction (the training path's FFN2 forward and FFN1 input gradient, K = 3072: 190 vs 205 us) also
+    // run faster on the 256 x 256 x 64 kernel in spite of its 1.48-round tile count; at K = 768 the 256 x 128 ping-pong kernel keeps its lead (66 vs 70 us)
+    if (use6 && (N >= min_n6 || (N >= 768 && K >= 1536))) {
       const int rc6 = se_gemm6_launch(A, lda, W, ldw, bias, residual_f32, M, N, K, act, out_bf16, out_f32, ldc, vec_ok, stream);
       if (rc6 <= 0) return rc6;
     }

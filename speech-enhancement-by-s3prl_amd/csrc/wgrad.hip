@@ -9,10 +9,14 @@
 //   staging  : global_load_lds_dwordx4 into a 4-deep ring of 32 KiB stages = 4 dY panels + 4 X panels of [32 m][64 col]
 //              bf16 (128-B rows, the kv_off swizzle of mhsa_tile.h: conflict-free for the tr reads), two stages in flight
 //              behind the one being multiplied; rows past the split's end read a 16-B zero word instead (no tail pass)
-//   fragments: per 16 rows of m, 4 + 2 fragments = 12 tr reads feed 8 MFMAs.  The b64 transposed read runs at half the LDS
-//              rate of ds_read_b128 (measured: ~8 clk per wave instruction), which makes LDS the limiter of this kernel --
-//              hence the 128 x 64 wave tile (1.5 reads per MFMA; the first 64 x 64 version needed 2 and ran LDS-bound at
-//              575 clk per 16-row step against 512 clk of MFMA work)
+//   fragments: per 16 rows of m, 4 + 2 fragments = 12 tr reads feed 8 MFMAs (128 x 64 wave tile: 1.5 reads per MFMA; the first
+//              64 x 64 version needed 2 and took 575 clk per 16-row step against 512 clk of MFMA work).
+//              Round 4 correction: rounds 1-3 read that 575 as "the b64 transposed read runs at half the LDS rate of ds_read_b128
+//              (~8 clk per wave instruction): LDS is this kernel's limiter".  tools/micro/lds_rate.hip measures ds_read_b64_tr_b16
+//              at 2.0-2.1 LDS cycles per wave instruction = 247-250 B/clk/CU, the SAME bytes per clock as ds_read_b128 (4.0 cycles,
+//              256 B/clk/CU) -- the ~8 clk seen from inside one wave is the instruction's issue / return cadence for ONE wave, not
+//              the array's rate.  At 8 waves x 12 reads x 2 cycles = 192 LDS-array cycles per 256-cycle MFMA step the array is
+//              busy, not saturated; what the step waits for is not established (no stamps of this loop since the correction).
 //   split    : the m range is split so that tiles x splits ~ one workgroup per CU; every split writes its own fp32 slab
 //              [N][K] and a slab reduce finishes (deterministic).  Work items are dealt to the XCDs in contiguous ranges
 //              (bijective remap), so the tiles of one split -- which re-read the same dY / X slices -- share an L2.

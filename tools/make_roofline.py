@@ -61,7 +61,7 @@ out = {
     'per_kernel_rocprof': {},
 }
 for key, sub, f in (('gemm6p_qkv', 'gemm6p_bf16_kernel<0', flop['qkv']), ('gemm6p_ffn1_gelu', 'gemm6p_bf16_kernel<3', flop['ffn1']),
-                    ('mhsa_fwd_prescaled', 'mhsa_fwd_kernel<3, 0, 1', flop['mhsa'])):
+                    ('mhsa_fwd_prescaled', 'mhsaN_fwd_kernel<8, 4, 1', flop['mhsa'])):
     us = avg_us(sub)
     if us:
         out['per_kernel_rocprof'][key] = {'avg_us': round(us, 1), 'TFLOPs': round(f / us / 1e6, 1), 'frac_of_2500': round(f / us / 1e6 / 2500.0, 3)}
@@ -85,36 +85,62 @@ for k in ('gemm', 'gemmln', 'mhsa', 'stft'):
             'matrix_pipe_busy': round(v.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) / simd, 3),
             'vector_issue_busy': round(4.0 * v.get('SQ_ACTIVE_INST_VALU', 0.0) / simd, 3),
             'lds_bank_conflict_frac': round(v.get('lds_bank_conflict_frac', 0.0), 3)}
-# ---- the attention forward against its own feed floor ("if >= 0.5 is provably out of reach at d = 64, write issue_floor_frac")
+# ---- the attention forward against its own floors.  Round 4 CORRECTION: the round-3 entry priced ds_read_b128 at 128 B/clk/CU and
+# ds_read_b64_tr_b16 at 64 and concluded "feed floor 0.57 of the matrix rate, >= 0.5 of nominal out of reach".  tools/micro/lds_rate.hip
+# (profiles/r04_micro_lds_rate.txt) measures 256 B/clk/CU for b128 and 247-250 for tr_b16 (MI355X_MICROARCH.md's LDS table), the unit's 8 + 16
+# fragment reads take 64 LDS-array cycles per wave = 256 per CU and unit against 512 matrix cycles, and interleaved with the 16 MFMAs they cost
+# 542 (1 wave per SIMD) / 526 (2) cycles per unit: the LDS feed is NOT the floor (0.95-0.97 of the matrix rate).
 mh = (bench.get('roofline_other_kernels') or {}).get('mhsa_fwd_kernel') or {}
-lds_clk = 8192 / 128.0 + 8192 / 64.0 + 4096 / 128.0       # K fragments (b128: 128 B/clk), V^T fragments (tr_b64: 64 B/clk measured), staging writes
-floor_frac_matrix = 512.0 / (4 * lds_clk)                  # 4 SIMDs share one LDS port: 4 units = 4 x 224 port clocks against 512 matrix clocks
-clock_ratio = 2.0 / 2.38                                   # sustained core clock under MFMA load / the clock of the nominal 2.5 PFLOP/s
+
+
+def _micro(name, pattern, cast=float):
+    try:
+        t = open(os.path.join(root, 'profiles', name)).read()
+    except OSError:
+        return None
+    m = re.search(pattern, t)
+    return cast(m.group(1)) if m else None
+
+
+skel = {f'{w}_per_simd': _micro('r04_micro_attn_skel.txt', r'QK\^T \| softmax \| PV in program order.*?%d/SIMD:\s+(\d+)' % w) for w in (1, 2, 3, 4)}
+skel_p = {f'{w}_per_simd': _micro('r04_micro_attn_skel.txt', r'QK\^T of the next unit issued before.*?%d/SIMD:\s+(\d+)' % w) for w in (1, 2, 3)}
+clock_ratio = 2.0 / 2.4                                    # sustained core clock under MFMA load / the clock of the nominal 2.5 PFLOP/s
+best_skel = min(v for v in list(skel.values()) + list(skel_p.values()) if v) if any(skel.values()) else None
 out['mhsa_fwd_floor'] = {
     'unit': 'one wave, 32 queries x 64 keys, d = 64: 16 v_mfma_f32_32x32x16_bf16 = 512 matrix clocks on its SIMD',
-    'lds_bytes_per_unit': {'k_fragments_b128': 8192, 'v_fragments_tr_b64': 8192, 'staging_writes': 4096},
-    'lds_port_clocks_per_unit': lds_clk,
-    'why': 'every 32x32x16 MFMA takes a fresh 1-KiB A operand (a K or V^T fragment) from LDS while the B operand (Q / P) stays in registers: at the '
-           'matrix peak that is 32 B/clk per SIMD = the whole 128 B/clk LDS port of the CU, and the transposed V^T reads (ds_read_b64_tr_b16) run at '
-           'half that rate (csrc/wgrad.hip header: 8 clk per wave instruction).  With one query block per wave the LDS port, not the matrix pipe, '
-           'is the floor; vector issue (102 instructions per unit, ISA count; >= 340 clocks at the measured multi-wave issue rates of '
-           'profiles/r03_micro_pk_rate.txt) comes third.',
-    'vector_instructions_per_unit': 102,
-    'feed_floor_frac_of_matrix_rate': round(floor_frac_matrix, 3),
-    'issue_floor_frac': round(floor_frac_matrix * clock_ratio, 3),
-    'issue_floor_frac_note': 'fraction of the NOMINAL 2.5 PFLOP/s reachable with the LDS port 100 % busy and nothing else stalling, at the ~2.0 GHz the '
-                             'core clock sustains under MFMA load: >= 0.5 of nominal is out of reach for this tile shape at d = 64',
+    'correction_round4': 'the round-3 LDS-feed floor (0.57 of the matrix rate, ">= 0.5 out of reach") was wrong: it assumed 128 / 64 B/clk/CU for '
+                         'ds_read_b128 / ds_read_b64_tr_b16; measured 256 / 247-250 (profiles/r04_micro_lds_rate.txt)',
+    'lds_feed': {
+        'ds_read_b128_B_per_clk_per_CU': _micro('r04_micro_lds_rate.txt', r'ds_read_b128\s+continuous\s+1 waves/SIMD.*?=\s+([\d.]+) B/clk'),
+        'ds_read_b64_tr_b16_B_per_clk_per_CU': _micro('r04_micro_lds_rate.txt', r'ds_read_b64_tr_b16\s+continuous\s+1 waves/SIMD.*?=\s+([\d.]+) B/clk'),
+        'ds_write_b128_B_per_clk_per_CU': _micro('r04_micro_lds_rate.txt', r'ds_write_b128\s+continuous\s+1 waves/SIMD.*?=\s+([\d.]+) B/clk'),
+        'unit_reads_interleaved_with_mfma_cycles_per_unit': {'1_per_simd': _micro('r04_micro_lds_rate.txt', r'reads interleaved with the MFMAs\s+1 waves/SIMD:\s+([\d.]+)'),
+                                                             '2_per_simd': _micro('r04_micro_lds_rate.txt', r'reads interleaved with the MFMAs\s+2 waves/SIMD:\s+([\d.]+)')},
+        'lds_array_cycles_per_unit_per_CU': 256, 'feed_floor_frac_of_matrix_rate': 0.95,
+    },
+    'compute_skeleton_cycles_per_unit_at_the_simd': {
+        'what': 'tools/micro/attn_skel.hip: the 16 MFMAs + 32 v_exp + 32 adds + 16 packs of a unit with their true dependencies and NO memory traffic',
+        'program_order_QK_softmax_PV': skel, 'next_tile_QK_before_this_softmax': skel_p,
+        'floor_frac_of_matrix_rate': round(512.0 / best_skel, 3) if best_skel else None,
+        'floor_frac_of_nominal': round(512.0 / best_skel * clock_ratio, 3) if best_skel else None,
+        'note': 'what bounds head dim 64 is the vector side of the softmax next to the matrix pipe, not LDS bandwidth: a single wave issues a vector instruction '
+                'every ~5 cycles (8.6 for v_exp), a SIMD with 3-4 waves one every ~2 (profiles/r03_micro_pk_rate.txt), and next to a busy matrix pipe ~9.5 / 12.8 '
+                '(profiles/r03_micro_coissue.txt).  >= 0.5 of nominal needs <= 490 cycles per unit at 2.0 GHz: below what the skeleton itself reaches.',
+    },
+    'stamps': 'profiles/r04_mhsa_stamps.txt: one wave of mhsa.hip alone on its SIMD spends 2 205 cycles per tile (stamped build) for 512 matrix + ~430 softmax-issue '
+              'cycles: K fragment reads in front of QK^T ~300 exposed, matrix results in front of the first exponential ~250, V^T reads inside PV ~160, '
+              'staging + barrier ~230',
     'achieved_frac': mh.get('frac'),
-    'achieved_over_floor': round(mh['frac'] / (floor_frac_matrix * clock_ratio), 3) if mh.get('frac') else None,
-    'measured_restructurings_round3': {
-        'two query blocks per wave (halves the LDS bytes per MFMA; mhsa2.hip, 255 VGPR)': '~130 us (tie)',
-        'interleaved matrix / vector stream, 2 blocks per wave, LDS-DMA ring (mhsa3.hip)': '143-152 us',
-        'LDS-DMA staging, 2 / 3 slots, occupancy 3 / 4 (SE_AMD_MHSA_DMA=1..4)': 'equal or slower',
-        '8-wave workgroups sharing one staged tile (SE_AMD_MHSA_NW=8)': '153-156 vs 136 us',
-        'row sums on the matrix pipe (tools/patches/mhsa_msum.diff)': '141-152 vs 131-139 us',
-        'v_pk_add_f32 row sums': '144-147 vs 135-136 us',
-        's_setprio around the MFMA clusters (-DSE_MHSA_PRIO)': 'tie',
-        'source': 'profiles/r03_mhsa_peaked.txt, profiles/r03_micro_coissue.txt, profiles/r03_mhsa_ablation.txt, DESIGN.md section 6',
+    'achieved_cycles_per_unit_at_2GHz': round(mh['avg_launch_ms'] * 1e-3 * 2.0e9 / 192.0) if mh.get('avg_launch_ms') else None,
+    'measured_restructurings_round4': {
+        'mhsa8.hip: 8 waves, SIMD partners alternating matrix / load segments, 4 barriers per tile (the guide\'s two-waves-per-SIMD layout)': '156-172 us: the load segment '
+        'carries the whole softmax of ONE wave (~1 200 stamped cycles) while its partner has 256 cycles of MFMA (profiles/r04_mhsa_stamps.txt)',
+        'mhsaN<16>: 16 waves free-running on one LDS-DMA staged tile (1 piece per wave and tile), one barrier per tile': '122-125 us',
+        'mhsaN<8>: the same with 8 waves, two workgroups per CU': '115 us',
+        'mhsaN<8, stagger>: + half of each SIMD\'s waves take the tile barrier mid-tile (DEFAULT from 768 workgroups on)': '107-113 us vs 118-127 us for mhsa.hip on the same boxes',
+        'mhsa9.hip: 8 waves, next tile\'s QK^T in front of this tile\'s softmax, K fragments prefetched (256 registers, one workgroup per CU)': '163 us',
+        'ablation of mhsaN<16> (profiles/r04_mhsaN_ablation.txt)': 'staging -9, barrier -10, LDS fragment reads -13, exponentials -11 of 124 us; 87 us with all four removed',
+        'source': 'profiles/r04_mhsa_variants.txt, profiles/r04_mhsa_bsweep.txt, DESIGN.md section 5d',
     },
 }
 json.dump(out, open(os.path.join(root, 'roofline.json'), 'w'), indent=1)
