@@ -35,6 +35,7 @@ constexpr int kWPanels = kWN / 64 + kWK / 64;               // 8
 constexpr int kWStage = kWPanels * kWPanel;                 // 32 KiB
 constexpr int kWStages = 4;
 constexpr int kWLds = kWStages * kWStage;
+constexpr int kWLdsStag = 5 * kWStage;                     // the staggered form's five-stage ring: all 160 KiB
 constexpr int kWDma = kWStage / 1024 / 8;                   // DMA instructions per wave per stage (4)
 
 __device__ uint4 g_wgrad_zero = {0u, 0u, 0u, 0u};
@@ -43,6 +44,11 @@ typedef __attribute__((address_space(3))) void* w_lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* w_glb_ptr_t;
 #define SE_WTR(ptr) __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(ptr))
 
+// STAG = 1 (round 4): waves 4-7 take the step's one barrier in the MIDDLE of their step (between the two 16-row sub-steps), so the two waves of a
+// SIMD run half a step apart instead of re-aligning at every step top (the attention forward gained 7 % that way, mhsa8.hip).  Costs one ring stage:
+// a late wave reads tile t right after barrier t - 1, so every wave certifies its pieces of tile t + 1 -- not t -- before barrier t, and the
+// refill of step t goes to the stage of tile t - 2 (five stages = all 160 KiB).
+template <int STAG>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void wgrad_tn_kernel(
     const uint16_t* __restrict__ dY, int ldy, const uint16_t* __restrict__ X, int ldx, int M, int N, int K, int m_per_split,
     int tiles_k, int tiles, int work, float* __restrict__ partials, unsigned long long* __restrict__ stamps) {
@@ -134,15 +140,32 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   if (nt > 0) SEW_ISSUE(0, 0);
   if (nt > 1) SEW_ISSUE(1, 1);
   if (nt > 2) SEW_ISSUE(2, 2);
+  constexpr int kRing = STAG ? 5 : kWStages;
+  const bool late = STAG && wave >= 4;
+  if (STAG) {
+    // tile 0 certified for everybody (the late half reads it before its first in-loop barrier)
+    if (nt > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (nt > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
   int st = 0;
   for (int t = 0; t < nt; ++t) {
     SEW_STAMP();
-    // this wave's pieces of tile t landed; tiles t+1, t+2 stay in flight
-    if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    SEW_STAMP();
-    __builtin_amdgcn_s_barrier();        // everyone's pieces landed AND everyone finished the stage refilled below
+    if (!STAG) {
+      // this wave's pieces of tile t landed; tiles t+1, t+2 stay in flight
+      if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      SEW_STAMP();
+      __builtin_amdgcn_s_barrier();        // everyone's pieces landed AND everyone finished the stage refilled below
+    } else if (!late) {
+      // early half, barrier t at the step top: its pieces of tile t + 1 landed (issued so far: .. t + 2)
+      if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      SEW_STAMP();
+      __builtin_amdgcn_s_barrier();
+    }
     SEW_STAMP();
     const char* sb = smem + st * kWStage;
 #pragma unroll
@@ -162,10 +185,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         bfr[blk] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
       }
       if (s == 0) {
-        // refill the slot of stage t-1 (free since the barrier above).  Issued here, behind the first step's fragment reads:
-        // every global_load_lds stalls the issuing wave ~110 clk, which now overlaps the LDS pipe serving those reads
+        // refill: tile t + 3 into the slot of stage t - 1 (STAG: t - 2), free since the last barrier this wave passed.  Issued here, behind the first
+        // step's fragment reads: every global_load_lds stalls the issuing wave ~110 clk, which now overlaps the LDS pipe serving those reads
         __builtin_amdgcn_sched_barrier(0);
-        if (t + 3 < nt) SEW_ISSUE(t + 3, (st + 3) & 3);
+        if (t + 3 < nt) { int sn = st + 3; if (sn >= kRing) sn -= kRing; SEW_ISSUE(t + 3, sn); }
         __builtin_amdgcn_sched_barrier(0);
         SEW_STAMP();
       }
@@ -173,8 +196,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+      if (STAG && late && s == 0) {
+        // late half, barrier t in mid-step: its pieces of tile t + 1 landed (issued so far: .. t + 3)
+        __builtin_amdgcn_sched_barrier(0);
+        const int after = (t + 2 < nt ? 1 : 0) + (t + 3 < nt ? 1 : 0);
+        if (after == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (after == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
-    st = (st + 1) & 3;
+    st = st + 1 == kRing ? 0 : st + 1;
   }
   SEW_STAMP();
 #undef SEW_ISSUE
@@ -208,6 +241,12 @@ __global__ __launch_bounds__(256) void wgrad_slab_reduce_kernel(const float* __r
 
 }  // namespace se
 
+static bool wgrad_stag() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("SE_AMD_WGRAD_STAG"); v = e ? atoi(e) : 1; }      // A/B: 0 = every wave's barrier at the step top (four-stage ring)
+  return v != 0;
+}
+
 // dW[N,K] (+)= dY[M,N]^T . X[M,K]; dY / X row-major bf16 (ldy, ldx in elements, multiples of 8; N, K multiples of 8);
 // workspace >= splits * N * K floats.
 extern "C" int se_wgrad_tn_bf16(const uint16_t* dY, int ldy, const uint16_t* X, int ldx, int M, int N, int K, int splits, float* dW,
@@ -221,7 +260,8 @@ extern "C" int se_wgrad_tn_bf16(const uint16_t* dY, int ldy, const uint16_t* X, 
   hipStream_t st = se::as_stream(stream);
   static bool attr_set = false;
   if (!attr_set) {
-    SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::wgrad_tn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, se::kWLds));
+    SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::wgrad_tn_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, se::kWLds));
+    SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::wgrad_tn_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, se::kWLdsStag));
     attr_set = true;
   }
   const int tiles_n = (N + se::kWN - 1) / se::kWN, tiles_k = (K + se::kWK - 1) / se::kWK;
@@ -241,8 +281,10 @@ extern "C" int se_wgrad_tn_bf16(const uint16_t* dY, int ldy, const uint16_t* X, 
   }
   {
     se::ProfScope prof(se::kProfGemm, 2.0 * M * (double)N * K, st);
-    hipLaunchKernelGGL(se::wgrad_tn_kernel, dim3(work), dim3(512), se::kWLds, st, dY, ldy, X, ldx, M, N, K, m_per_split, tiles_k, tiles, work,
-                       partials, stamps);
+    if (wgrad_stag()) hipLaunchKernelGGL(se::wgrad_tn_kernel<1>, dim3(work), dim3(512), se::kWLdsStag, st, dY, ldy, X, ldx, M, N, K, m_per_split, tiles_k, tiles,
+                                         work, partials, stamps);
+    else hipLaunchKernelGGL(se::wgrad_tn_kernel<0>, dim3(work), dim3(512), se::kWLds, st, dY, ldy, X, ldx, M, N, K, m_per_split, tiles_k, tiles, work,
+                            partials, stamps);
     SE_LAUNCH_CHECK();
   }
   const size_t n4 = (size_t)N * K / 4;
@@ -268,14 +310,17 @@ extern "C" int se_wgrad_tn_slabs_bf16(const uint16_t* dY, int ldy, const uint16_
   hipStream_t st = se::as_stream(stream);
   static bool attr_set = false;
   if (!attr_set) {
-    SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::wgrad_tn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, se::kWLds));
+    SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::wgrad_tn_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, se::kWLds));
+    SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::wgrad_tn_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, se::kWLdsStag));
     attr_set = true;
   }
   const int tiles_n = (N + se::kWN - 1) / se::kWN, tiles_k = (K + se::kWK - 1) / se::kWK;
   const int tiles = tiles_n * tiles_k, work = tiles * groups;
   se::ProfScope prof(se::kProfGemm, 2.0 * M * (double)N * K, st);
-  hipLaunchKernelGGL(se::wgrad_tn_kernel, dim3(work), dim3(512), se::kWLds, st, dY, ldy, X, ldx, M, N, K, rows_per_slab, tiles_k, tiles, work,
-                     slabs, (unsigned long long*)nullptr);
+  if (wgrad_stag()) hipLaunchKernelGGL(se::wgrad_tn_kernel<1>, dim3(work), dim3(512), se::kWLdsStag, st, dY, ldy, X, ldx, M, N, K, rows_per_slab, tiles_k, tiles,
+                                       work, slabs, (unsigned long long*)nullptr);
+  else hipLaunchKernelGGL(se::wgrad_tn_kernel<0>, dim3(work), dim3(512), se::kWLds, st, dY, ldy, X, ldx, M, N, K, rows_per_slab, tiles_k, tiles, work,
+                          slabs, (unsigned long long*)nullptr);
   SE_LAUNCH_CHECK();
   return SE_OK;
 }
