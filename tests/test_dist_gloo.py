@@ -64,7 +64,9 @@ def _worker(rank, world, port, q):
     flat = red.reduce()[:W.numel() + b.numel()].clone()
     assert red.active == [True, True, False] and unused.grad is None      # BertAdam's `if p.grad is None: continue` still applies
     gn = torch.nn.utils.clip_grad_norm_([W, b], 1.0)
-    q.put((rank, idx, loss_global, flat, float(gn), W.grad.clone(), b.grad.clone()))
+    # numpy arrays, not tensors: a tensor travels through a multiprocessing queue as a shared-memory file descriptor that the RECEIVER fetches from the
+    # sender over a socket -- if this process has exited by then the parent sees ConnectionResetError (seen once in round 4 on a loaded box)
+    q.put((rank, idx, loss_global, flat.numpy().copy(), float(gn), W.grad.numpy().copy(), b.grad.numpy().copy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -78,6 +80,7 @@ def test_dp2_matches_single_process():
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda r: r[0])
+    res = [(r[0], r[1], r[2], torch.from_numpy(r[3]), r[4], torch.from_numpy(r[5]), torch.from_numpy(r[6])) for r in res]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
