@@ -244,7 +244,6 @@ __global__ __launch_bounds__(256, 2) void head_kernel(const float* __restrict__ 
 // while they are staged (CMVN first, in fp32).  LDS: 16-k chunks, rows at a 48-B pitch (conflict-free ds_read_b128 of 16 consecutive rows):
 // 3 x (128 + NT * 32) x 48 B = 50.7 KB at N = 201 -> 3 workgroups per CU as before.  Epilogue: the kernel above's, unchanged (same C / D map).
 constexpr int kH3K = 16;          // k per chunk
-constexpr int kH3P = 48;          // row pitch of a plane in bytes: 32 B of data (16 bf16) + 16 B
 typedef __attribute__((ext_vector_type(8))) __bf16 h3_bf16x8;
 
 __device__ __forceinline__ void split3(float x, uint16_t& a, uint16_t& b, uint16_t& c) {
@@ -258,32 +257,44 @@ __device__ __forceinline__ void split3(float x, uint16_t& a, uint16_t& b, uint16
   c = __builtin_bit_cast(uint16_t, x3);
 }
 
-// W (N, D) fp32 -> W3 [3][rows_p][Kp] bf16 (rows >= N and k >= D are zero)
+// W (N, D) fp32 -> W3 [chunk = k / 16][plane 0..2][half = (k / 8) & 1][row 0..rows_p) x 8 bf16 (16 B): CHUNK-major, so that the 3 NT KiB a
+// workgroup needs per 16-k chunk are ONE contiguous span -- 1-KiB LDS-DMA pieces with lane-linear source AND destination -- and [half][row] inside,
+// which is also what the fragment reads want: lane l reads row (l & 31), half (l >> 5): 32 rows x 16 B contiguous per half = conflict-free
+// ds_read_b128 without padding.  Rows >= N and k >= D are zero.
 __global__ __launch_bounds__(256) void head_split_w_kernel(const float* __restrict__ W, int N, int D, int rows_p, int Kp, uint16_t* __restrict__ W3) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= rows_p * Kp) return;
   const int n = i / Kp, k = i - n * Kp;
   const float v = (n < N && k < D) ? W[(size_t)n * D + k] : 0.f;
-  uint16_t a, b, c;
-  split3(v, a, b, c);
-  W3[i] = a;
-  W3[(size_t)rows_p * Kp + i] = b;
-  W3[2 * (size_t)rows_p * Kp + i] = c;
+  uint16_t p[3];
+  split3(v, p[0], p[1], p[2]);
+  const int c = k >> 4, h = (k >> 3) & 1, e = k & 7;
+#pragma unroll
+  for (int pl = 0; pl < 3; ++pl) W3[((((size_t)c * 3 + pl) * 2 + h) * rows_p + n) * 8 + e] = p[pl];
 }
 
+// Round 4, second version (the first one staged weights and features through registers per chunk and exposed both latencies twice per chunk:
+// 254 / 313 us): weights by LDS-DMA one chunk ahead (double-buffered, no registers, no address arithmetic: the chunk is one contiguous span),
+// the next chunk's feature rows (+ their CMVN statistics) loaded into registers before this chunk's MFMAs and split / written to LDS at the top of
+// the next one (double-buffered): ONE barrier per chunk, no global latency on the critical path.  LDS 2 x 3 NT KiB + 2 x 12 KiB = 66 KiB at
+// N = 201 -> two workgroups per CU.
 template <int NT>
-__global__ __launch_bounds__(256, 3) void head3_kernel(const float* __restrict__ feats, const uint16_t* __restrict__ W3, int Kp,
+__global__ __launch_bounds__(256, 2) void head3_kernel(const float* __restrict__ feats, const uint16_t* __restrict__ W3, int Kp,
                                                        const float* __restrict__ bias, const float* __restrict__ linears,
                                                        const float* __restrict__ stats, int rows, int F, int D, int N, int act,
                                                        float* __restrict__ predicted, float* __restrict__ offset, int vec_io) {
-  constexpr int kAPlane = kHM * kH3P, kWPlane = NT * 32 * kH3P;      // bytes per plane
-  constexpr int kStage = 3 * (kAPlane + kWPlane);
+  constexpr int kWBuf = 3 * 2 * NT * 32 * 16;                        // bytes of one weight chunk: [plane][half][row] x 16 B
+  constexpr int kABuf = 3 * 2 * kHM * 16;                            // one feature chunk, same layout over the 128 rows
+  constexpr int kStage = 2 * kWBuf + 2 * kABuf;
   constexpr int kEpi = 4 * kHHalf * (NT * 32) * 4;
+  constexpr int kPieces = kWBuf / 1024;                              // 3 NT
   __shared__ __attribute__((aligned(16))) char smem3[kStage > kEpi ? kStage : kEpi];
-  char* As = smem3;
-  char* Ws = smem3 + 3 * kAPlane;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  char* Ws = smem3;
+  char* As = smem3 + 2 * kWBuf;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int row0 = blockIdx.x * kHM;
+  const int nchunk = Kp / kH3K;
 
   f32x16 acc[NT];
 #pragma unroll
@@ -291,64 +302,108 @@ __global__ __launch_bounds__(256, 3) void head3_kernel(const float* __restrict__
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-  const size_t wplane = (size_t)NT * 32 * Kp;
-  for (int k0 = 0; k0 < Kp; k0 += kH3K) {
-    __syncthreads();
-    // ---- features: item = (row, 4-float piece): 128 x 4 = 512 items; CMVN in fp32, then the three-term split, 8 B per plane
+  // ---- weight chunk c -> buffer c & 1: pieces wave, wave + 4, ... of its 3 NT KiB (inline asm: invisible to the compiler's vmcnt bookkeeping;
+  //      the one wait on them is the vmcnt(0) at the top of the chunk that reads them)
+  typedef __attribute__((address_space(3))) char* lds_h_t;
+  const uint32_t lds_w = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(lds_h_t)smem3);
+  const char* wbase = reinterpret_cast<const char*>(W3);
+#define SEH_DMA_W(c)                                                                                                        \
+  do {                                                                                                                      \
+    const char* sb_ = wbase + (size_t)(c) * kWBuf;                                                                          \
+    for (int j_ = wave; j_ < kPieces; j_ += 4) {                                                                            \
+      const uint32_t off_ = (uint32_t)(j_ * 1024 + lane * 16);                                                              \
+      uint32_t keep_;                                                                                                       \
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"  \
+                   : "=&s"(keep_) : "v"(off_), "s"(sb_), "s"(lds_w + (uint32_t)(((c) & 1) * kWBuf + j_ * 1024)) : "memory"); \
+    }                                                                                                                       \
+  } while (0)
+  // ---- feature chunk c: this thread's two items (row, 4-float piece) and their statistics, into registers
+  float4 fv[2], fs0[2], fs1[2];
+#define SEH_LOAD_F(c)                                                                                                       \
+  _Pragma("unroll") for (int rep = 0; rep < 2; ++rep) {                                                                     \
+    const int it = tid + 256 * rep;                                                                                         \
+    const int r = it >> 2, c4 = it & 3;                                                                                     \
+    const int row = row0 + r, k = (c) * kH3K + 4 * c4;                                                                      \
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f), s0 = make_float4(0.f, 1.f, 0.f, 1.f), s1 = s0;                              \
+    if (row < rows && k < D) {                                                                                              \
+      const float* src = feats + (size_t)row * D + k;                                                                       \
+      if (k + 3 < D) {                                                                                                      \
+        v = *reinterpret_cast<const float4*>(src);                                                                          \
+      } else {                                                                                                              \
+        v.x = src[0];                                                                                                       \
+        if (k + 1 < D) v.y = src[1];                                                                                        \
+        if (k + 2 < D) v.z = src[2];                                                                                        \
+      }                                                                                                                     \
+      if (stats) {                                                                                                          \
+        const float* sp = stats + ((size_t)(row / F) * D + k) * 2;           /* (mean, 1 / (std + eps)) pairs */             \
+        if (k + 3 < D) {                                                                                                    \
+          s0 = *reinterpret_cast<const float4*>(sp);                                                                        \
+          s1 = *reinterpret_cast<const float4*>(sp + 4);                                                                    \
+        } else {                                                                                                            \
+          s0.x = sp[0]; s0.y = sp[1];                                                                                       \
+          if (k + 1 < D) { s0.z = sp[2]; s0.w = sp[3]; }                                                                    \
+          if (k + 2 < D) { s1.x = sp[4]; s1.y = sp[5]; }                                                                    \
+        }                                                                                                                   \
+      }                                                                                                                     \
+    }                                                                                                                       \
+    fv[rep] = v; fs0[rep] = s0; fs1[rep] = s1;                                                                              \
+  }
+
+  SEH_DMA_W(0);
+  SEH_LOAD_F(0)
+  // The noisy-power rows a pass multiplies with are loaded ONE PASS AHEAD into registers (round 4): a load inside the store loop costs a full memory
+  // round trip per iteration (load -> use), ~25 of them per wave, with only two or three workgroups per CU to hide it -- that, not the GEMM, was most
+  // of this kernel's time (the matrix work is ~40 us of a 270 us launch).
+  constexpr int kVecIt = (kHHalf * NT * 32 / 4 + 63) / 64;      // float4 items per lane and pass (7 at N <= 224, 8 rows)
+  float4 lin[2][kVecIt];
+  auto load_lin = [&](int h, float4 (&dst)[kVecIt]) {
+    const int rbase = row0 + wave * 32 + kHHalf * h;
+    const int nrow = min(kHHalf, rows - rbase);
+    const int nvec = nrow > 0 ? (nrow * N) >> 2 : 0;
+    const size_t g = (size_t)rbase * N;
+#pragma unroll
+    for (int j = 0; j < kVecIt; ++j) {
+      const int i = lane + 64 * j;
+      dst[j] = (linears && vec_io && i < nvec) ? *reinterpret_cast<const float4*>(linears + g + 4 * i) : make_float4(1.f, 1.f, 1.f, 1.f);
+    }
+  };
+  load_lin(0, lin[0]);      // the first pass's rows travel under the whole K loop
+  for (int c = 0; c < nchunk; ++c) {
+    // everything issued one chunk ago has landed: this wave's pieces of weight chunk c, this thread's feature items of chunk c
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ---- features: CMVN in fp32, the three-term split, 8 B per plane into [plane][half][row]
+    char* Ab = As + (c & 1) * kABuf;
 #pragma unroll
     for (int rep = 0; rep < 2; ++rep) {
       const int it = tid + 256 * rep;
-      const int r = it >> 2, c = it & 3;
-      const int row = row0 + r, k = k0 + 4 * c;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row < rows && k < D) {
-        const float* src = feats + (size_t)row * D + k;
-        if (k + 3 < D) {
-          v = *reinterpret_cast<const float4*>(src);
-        } else {
-          v.x = src[0];
-          if (k + 1 < D) v.y = src[1];
-          if (k + 2 < D) v.z = src[2];
-        }
-        if (stats) {
-          const float* sp = stats + ((size_t)(row / F) * D + k) * 2;           // (mean, 1 / (std + eps)) pairs
-          if (k + 3 < D) {
-            const float4 s0 = *reinterpret_cast<const float4*>(sp), s1 = *reinterpret_cast<const float4*>(sp + 4);
-            v = make_float4((v.x - s0.x) * s0.y, (v.y - s0.z) * s0.w, (v.z - s1.x) * s1.y, (v.w - s1.z) * s1.w);
-          } else {
-            v.x = (v.x - sp[0]) * sp[1];
-            if (k + 1 < D) v.y = (v.y - sp[2]) * sp[3];
-            if (k + 2 < D) v.z = (v.z - sp[4]) * sp[5];
-          }
-        }
-      }
+      const int r = it >> 2, c4 = it & 3;
+      float4 v = fv[rep];
+      const float4 s0 = fs0[rep], s1 = fs1[rep];
+      v = make_float4((v.x - s0.x) * s0.y, (v.y - s0.z) * s0.w, (v.z - s1.x) * s1.y, (v.w - s1.z) * s1.w);      // (0, 1) pairs without CMVN / past D
       uint16_t p0[4], p1[4], p2[4];
       split3(v.x, p0[0], p1[0], p2[0]);
       split3(v.y, p0[1], p1[1], p2[1]);
       split3(v.z, p0[2], p1[2], p2[2]);
       split3(v.w, p0[3], p1[3], p2[3]);
-      char* d = As + r * kH3P + c * 8;
+      char* d = Ab + ((c4 >> 1) * kHM + r) * 16 + (c4 & 1) * 8;
       *reinterpret_cast<uint2*>(d) = make_uint2(p0[0] | ((uint32_t)p0[1] << 16), p0[2] | ((uint32_t)p0[3] << 16));
-      *reinterpret_cast<uint2*>(d + kAPlane) = make_uint2(p1[0] | ((uint32_t)p1[1] << 16), p1[2] | ((uint32_t)p1[3] << 16));
-      *reinterpret_cast<uint2*>(d + 2 * kAPlane) = make_uint2(p2[0] | ((uint32_t)p2[1] << 16), p2[2] | ((uint32_t)p2[3] << 16));
+      *reinterpret_cast<uint2*>(d + 2 * kHM * 16) = make_uint2(p1[0] | ((uint32_t)p1[1] << 16), p1[2] | ((uint32_t)p1[3] << 16));
+      *reinterpret_cast<uint2*>(d + 4 * kHM * 16) = make_uint2(p2[0] | ((uint32_t)p2[1] << 16), p2[2] | ((uint32_t)p2[3] << 16));
     }
-    // ---- weights: item = (plane, output row, 16-B half): 3 x NT * 32 x 2
-    for (int it = tid; it < 3 * NT * 32 * 2; it += 256) {
-      const int p = it / (NT * 32 * 2), rem = it - p * (NT * 32 * 2);
-      const int n = rem >> 1, h = rem & 1;
-      const uint4 v = *reinterpret_cast<const uint4*>(W3 + p * wplane + (size_t)n * Kp + k0 + 8 * h);
-      *reinterpret_cast<uint4*>(Ws + p * kWPlane + n * kH3P + 16 * h) = v;
+    __syncthreads();      // weight chunk c and feature chunk c visible; every wave is past chunk c - 1 (whose buffers are refilled next)
+    if (c + 1 < nchunk) {
+      SEH_DMA_W(c + 1);
+      SEH_LOAD_F(c + 1)
     }
-    __syncthreads();
-    const char* ap = As + (wave * 32 + (lane & 31)) * kH3P + 16 * (lane >> 5);
-    const char* wp = Ws + (lane & 31) * kH3P + 16 * (lane >> 5);
-    const h3_bf16x8 a0 = *reinterpret_cast<const h3_bf16x8*>(ap), a1 = *reinterpret_cast<const h3_bf16x8*>(ap + kAPlane),
-                    a2 = *reinterpret_cast<const h3_bf16x8*>(ap + 2 * kAPlane);
+    const char* ap = Ab + (wave * 32 + (lane & 31)) * 16 + (lane >> 5) * (kHM * 16);
+    const char* wp = Ws + (c & 1) * kWBuf + (lane & 31) * 16 + (lane >> 5) * (NT * 32 * 16);
+    const h3_bf16x8 a0 = *reinterpret_cast<const h3_bf16x8*>(ap), a1 = *reinterpret_cast<const h3_bf16x8*>(ap + 2 * kHM * 16),
+                    a2 = *reinterpret_cast<const h3_bf16x8*>(ap + 4 * kHM * 16);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      const char* wt = wp + t * 32 * kH3P;
-      const h3_bf16x8 w0 = *reinterpret_cast<const h3_bf16x8*>(wt), w1 = *reinterpret_cast<const h3_bf16x8*>(wt + kWPlane),
-                      w2 = *reinterpret_cast<const h3_bf16x8*>(wt + 2 * kWPlane);
+      const char* wt = wp + t * 32 * 16;
+      const h3_bf16x8 w0 = *reinterpret_cast<const h3_bf16x8*>(wt), w1 = *reinterpret_cast<const h3_bf16x8*>(wt + 2 * NT * 32 * 16),
+                      w2 = *reinterpret_cast<const h3_bf16x8*>(wt + 4 * NT * 32 * 16);
       // smallest terms first
       acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, w0, acc[t], 0, 0, 0);
       acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, w2, acc[t], 0, 0, 0);
@@ -358,6 +413,8 @@ __global__ __launch_bounds__(256, 3) void head3_kernel(const float* __restrict__
       acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, w0, acc[t], 0, 0, 0);
     }
   }
+#undef SEH_DMA_W
+#undef SEH_LOAD_F
 
   // ---- epilogue: as head_kernel (same accumulator map)
   __syncthreads();
@@ -370,6 +427,7 @@ __global__ __launch_bounds__(256, 3) void head3_kernel(const float* __restrict__
   }
 #pragma unroll
   for (int h = 0; h < 32 / kHHalf; ++h) {
+    if (h + 1 < 32 / kHHalf) load_lin(h + 1, lin[(h + 1) & 1]);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int n = t * 32 + (lane & 31);
@@ -392,16 +450,16 @@ __global__ __launch_bounds__(256, 3) void head3_kernel(const float* __restrict__
       const size_t g = (size_t)rbase * N;
       if (vec_io) {
         const int nvec = cnt >> 2;
-        for (int i = lane; i < nvec; i += 64) {
-          const float4 o = *reinterpret_cast<const float4*>(Es + 4 * i);
-          if (offset) *reinterpret_cast<float4*>(offset + g + 4 * i) = o;
-          if (predicted) {
-            float4 p = o;
-            if (linears) {
-              const float4 l = *reinterpret_cast<const float4*>(linears + g + 4 * i);
-              p = make_float4(o.x * l.x, o.y * l.y, o.z * l.z, o.w * l.w);
+#pragma unroll
+        for (int j = 0; j < kVecIt; ++j) {
+          const int i = lane + 64 * j;
+          if (i < nvec) {
+            const float4 o = *reinterpret_cast<const float4*>(Es + 4 * i);
+            if (offset) *reinterpret_cast<float4*>(offset + g + 4 * i) = o;
+            if (predicted) {
+              const float4 l = lin[h & 1][j];
+              *reinterpret_cast<float4*>(predicted + g + 4 * i) = make_float4(o.x * l.x, o.y * l.y, o.z * l.z, o.w * l.w);
             }
-            *reinterpret_cast<float4*>(predicted + g + 4 * i) = p;
           }
         }
         for (int i = 4 * nvec + lane; i < cnt; i += 64) {

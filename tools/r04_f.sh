@@ -5,7 +5,7 @@ root=$(cd "$(dirname "$0")/.." && pwd)
 out=$root/gpurun_out/r04f
 mkdir -p "$out"
 cd "$root"
-timeout -k 10 900 python3 -m pytest tests/test_gpu_heads_decode.py tests/test_gpu_objectives.py tests/test_gpu_train_step.py tests/test_gpu_lstm.py tests/test_gpu_scoring.py tests/test_gpu_preprocessor.py tests/test_gpu_encoder_fp32.py tests/test_gpu_fullsize_properties.py -x -q -m gpu > "$out/pytest.log" 2>&1 || { tail -40 "$out/pytest.log"; exit 1; }
+timeout -k 10 900 python3 -m pytest tests/test_gpu_heads_decode.py tests/test_gpu_objectives.py tests/test_gpu_train_step.py tests/test_gpu_lstm.py tests/test_gpu_scoring.py tests/test_gpu_fullsize_properties.py tests/test_gpu_graph.py tests/test_gpu_dropin_sequence.py -x -q -m gpu > "$out/pytest.log" 2>&1 || { tail -40 "$out/pytest.log"; exit 1; }
 tail -3 "$out/pytest.log"
 for feat in mel120 linear201; do
   for old in 0 1; do
