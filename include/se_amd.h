@@ -337,6 +337,21 @@ int se_softmax_rows_f32(float* scores, const int32_t* lengths, int B, int heads,
  * which = 1 -> [w1 | w2 | w1] (nn.Linear weights), so that se_gemm_bf16 on the two outputs with K = 3 Kp sums x1 w1 + x1 w2 + x2 w1 in its fp32
  * accumulators: fp32-operand products to 3 . 2^-18 relative on the bf16 matrix pipe (runner.py:556-575 at the 1e-4 tolerance, 3 x the bf16 cost). */
 int se_split3_bf16(const float* x, long ld, int rows, int cols, int Kp, int which, uint16_t* out, void* stream);
+
+/*
+ * Producers of the three-term operand (round 4): the bf16x3 mode's projections, LayerNorms and attention core hand their fp32 result to the next
+ * projection already split -- [y1 | y1 | y2], row stride 3 Kp, se_split3_bf16's activation layout -- instead of writing fp32 rows that a separate
+ * se_split3_bf16 pass reads back (14 % of that mode's pass).  Same S3PRL rows as the fp32 mode: nn.Linear (+ gelu) of the encoder layers (B2 / B3),
+ * their LayerNorms, the attention core behind model.py:164.
+ *   se_gemm_x3out_bf16      out3 = split(act(A . W^T + bias)); A (M, K) / W (N, K) three-term operands (K = 3 x the layer's depth); act identity / GELU (erf)
+ *   se_layernorm_x3_f32     out_f32 (may be NULL) = LayerNorm(x), out3 = split(LayerNorm(x)); H = 256, 512, 768, 1024
+ *   se_mhsa_fwd_x3_split_f32  se_mhsa_fwd_x3_f32 with the context written as its split (Kp >= heads * 64)
+ */
+int se_gemm_x3out_bf16(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias, int M, int N, int K, int act,
+                       uint16_t* out3, int Kp, void* stream);
+int se_layernorm_x3_f32(const float* x, const float* w, const float* b, int M, int H, float eps, float* out_f32, uint16_t* out3, int Kp,
+                        void* stream);
+int se_mhsa_fwd_x3_split_f32(const float* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx3, int Kp, void* stream);
 /* The attention core of the same mode (csrc/mhsa_x3.hip): ctx (B*T, H) fp32 = softmax(Q K^T / 8 + pad mask) V from the fp32 fused projection
  * qkv (B*T, 3H) = [Q | K | V], flash style on the bf16 matrix pipe with two-term splits of Q, K, V and P (three products each); replaces the
  * materialised scores of the fp32 mode (se_gemm_f32 batched + se_softmax_rows_f32).  heads of 64; buffers 16-B aligned. */

@@ -99,6 +99,9 @@ SIGNATURES = {
                             ctypes.c_long, ctypes.c_long, ctypes.c_long, ctypes.c_long, ctypes.c_long, ctypes.c_long, _P]),
     'se_softmax_rows_f32': (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     'se_split3_bf16': (c_int, [_P, ctypes.c_long, c_int, c_int, c_int, c_int, _P, _P]),
+    'se_gemm_x3out_bf16': (c_int, [_P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, c_int, _P]),
+    'se_layernorm_x3_f32': (c_int, [_P, _P, _P, c_int, c_int, c_float, _P, _P, c_int, _P]),
+    'se_mhsa_fwd_x3_split_f32': (c_int, [_P, _P, c_int, c_int, c_int, _P, c_int, _P]),
     'se_mhsa_fwd_x3_f32': (c_int, [_P, _P, c_int, c_int, c_int, _P, _P]),
     'se_transpose_bf16': (c_int, [_P, c_int, c_int, c_int, _P, c_int, _P]),
     'se_transpose_f32_bf16': (c_int, [_P, c_int, c_int, c_int, _P, c_int, _P]),

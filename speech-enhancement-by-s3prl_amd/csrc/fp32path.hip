@@ -142,7 +142,79 @@ __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x
   }
 }
 
+
+// LayerNorm in fp32 (the arithmetic of encoder.hip: layernorm_kernel) that also writes its output as the three-term activation operand [y1 | y1 | y2]
+// (row stride 3 Kp, zero beyond H only if the caller cleared the buffer: Kp == H in every use) -- round 4: the bf16x3 mode's split pass behind every
+// LayerNorm read the fp32 rows back.  One wave per row, H = 256 NV.
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_x3_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b, int M, float eps,
+                                                           float* __restrict__ out_f32, uint16_t* __restrict__ out3, int Kp) {
+  constexpr int H = 256 * NV;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float* xr = x + (size_t)row * H;
+  float4 v[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const float4*>(xr + (i * 64 + lane) * 4);
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  const float mean = s * (1.0f / H);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+    q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off);
+  const float rstd = 1.0f / sqrtf(q * (1.0f / H) + eps);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    const float4 ww = *reinterpret_cast<const float4*>(w + c), bb = *reinterpret_cast<const float4*>(b + c);
+    float y[4];
+    y[0] = ww.x * (v[i].x * rstd) + bb.x; y[1] = ww.y * (v[i].y * rstd) + bb.y;
+    y[2] = ww.z * (v[i].z * rstd) + bb.z; y[3] = ww.w * (v[i].w * rstd) + bb.w;
+    if (out_f32) *reinterpret_cast<float4*>(out_f32 + (size_t)row * H + c) = make_float4(y[0], y[1], y[2], y[3]);
+    uint16_t hi[4], mid[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const __bf16 h = (__bf16)y[e];
+      hi[e] = __builtin_bit_cast(uint16_t, h);
+      mid[e] = __builtin_bit_cast(uint16_t, (__bf16)(y[e] - (float)h));
+    }
+    const uint2 ph = make_uint2(hi[0] | ((uint32_t)hi[1] << 16), hi[2] | ((uint32_t)hi[3] << 16));
+    const uint2 pm = make_uint2(mid[0] | ((uint32_t)mid[1] << 16), mid[2] | ((uint32_t)mid[3] << 16));
+    uint16_t* o = out3 + (size_t)row * 3 * (size_t)Kp + c;
+    *reinterpret_cast<uint2*>(o) = ph;
+    *reinterpret_cast<uint2*>(o + Kp) = ph;
+    *reinterpret_cast<uint2*>(o + 2 * (size_t)Kp) = pm;
+  }
+}
+
 }  // namespace se
+
+extern "C" int se_layernorm_x3_f32(const float* x, const float* w, const float* b, int M, int H, float eps, float* out_f32, uint16_t* out3, int Kp,
+                                   void* stream) {
+  SE_REQUIRE(x && w && b && out3 && M > 0, "se_layernorm_x3_f32: null argument");
+  SE_REQUIRE(H == 768 || H == 256 || H == 512 || H == 1024, "se_layernorm_x3_f32: built for H = 256, 512, 768, 1024 (got %d)", H);
+  SE_REQUIRE(Kp >= H && Kp % 8 == 0 && (((uintptr_t)x | (uintptr_t)out_f32 | (uintptr_t)out3 | (uintptr_t)w | (uintptr_t)b) % 16) == 0,
+             "se_layernorm_x3_f32: Kp = %d must be >= H, a multiple of 8; buffers 16-B aligned", Kp);
+  hipStream_t st = se::as_stream(stream);
+  const dim3 grid((M + 3) / 4);
+  switch (H) {
+    case 256: hipLaunchKernelGGL((se::layernorm_x3_kernel<1>), grid, dim3(256), 0, st, x, w, b, M, eps, out_f32, out3, Kp); break;
+    case 512: hipLaunchKernelGGL((se::layernorm_x3_kernel<2>), grid, dim3(256), 0, st, x, w, b, M, eps, out_f32, out3, Kp); break;
+    case 768: hipLaunchKernelGGL((se::layernorm_x3_kernel<3>), grid, dim3(256), 0, st, x, w, b, M, eps, out_f32, out3, Kp); break;
+    default: hipLaunchKernelGGL((se::layernorm_x3_kernel<4>), grid, dim3(256), 0, st, x, w, b, M, eps, out_f32, out3, Kp); break;
+  }
+  SE_LAUNCH_CHECK();
+  return SE_OK;
+}
 
 extern "C" int se_split3_bf16(const float* x, long ld, int rows, int cols, int Kp, int which, uint16_t* out, void* stream) {
   SE_REQUIRE(x && out && rows > 0 && cols > 0 && Kp >= cols && Kp % 8 == 0 && ld >= cols, "se_split3_bf16: bad argument (rows=%d cols=%d Kp=%d)", rows, cols, Kp);

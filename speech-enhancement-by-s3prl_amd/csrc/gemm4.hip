@@ -18,11 +18,13 @@
 //              in the (then dead) ring; exact two-pass mean / variance per row (lane group -> wave -> LDS across the 4 column waves);
 //              fp32 and bf16 rows stored straight from registers
 #include <stdlib.h>
+#include "clkprobe.h"
 #include "common.h"
 #include "bf16.h"
 #include "prof.h"
 #include "encoder_impl.h"
 
+SE_CLKPROBE_DECL(clkprobe_gemm7)
 namespace se {
 
 constexpr int k4BM = 128, k4N = 768, k4BK = 32, k4Threads = 512;
@@ -431,6 +433,7 @@ __global__ __launch_bounds__(k4Threads) __attribute__((amdgpu_waves_per_eu(2, 2)
     float* __restrict__ out_f32, uint16_t* __restrict__ out_bf16, int ntiles, int res_mod,
     const uint8_t* __restrict__ res_lo, uint8_t* __restrict__ out_lo) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  SE_CLKPROBE_BEGIN();
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
@@ -574,6 +577,7 @@ __global__ __launch_bounds__(k4Threads) __attribute__((amdgpu_waves_per_eu(2, 2)
   if (!late) __builtin_amdgcn_s_barrier();                  // re-align the two groups
   __syncthreads();                                          // ring is dead: reuse it for the per-column vectors
   ln_epilogue4<GELU, ROUT>(acc, smem, 8192, ln_w, ln_b, eps, M, m0, id, wave, wr, wc, lane, out_f32, out_bf16, out_lo);
+  SE_CLKPROBE_END(clkprobe_gemm7);
 #undef SE7_DMA1
 #undef SE7_DMA_W
 #undef SE7_DMA_A

@@ -18,11 +18,13 @@
 //              The only wait of a K-tile is vmcnt(6) in phase 4 (three half-tiles stay in flight): in-order retirement then guarantees
 //              every half-tile of tile t+1; it is read from the next phase on (one barrier later for the lagging wave group).
 //   epilogue : gemm3's (swapped operands, C^T accumulators, 16-B stores, bias / GELU / fp32 residual fused, compile-time specialised)
+#include "clkprobe.h"
 #include <stdlib.h>
 #include "common.h"
 #include "bf16.h"
 #include "prof.h"
 
+SE_CLKPROBE_DECL(clkprobe_gemm6)
 namespace se {
 
 constexpr int k6BM = 256, k6BN = 256, k6BK = 64, k6Threads = 512;
@@ -52,20 +54,34 @@ __device__ __forceinline__ float act6(float v, int act) {
         rr[j] = *reinterpret_cast<const float4*>(residual + orow + gn);                                                    \
       }                                                                                                                    \
     }                                                                                                                      \
-    uint2 pk[4];                                                                                                           \
+    uint2 pk[4], pm[4];                                                                                                    \
     _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                        \
       const int gn = n0 + wc * 64 + j * 16 + ncol;                                                                         \
       float v0 = acc[i][j][0] + bb[j].x, v1 = acc[i][j][1] + bb[j].y, v2 = acc[i][j][2] + bb[j].z, v3 = acc[i][j][3] + bb[j].w; \
       if constexpr (ACT == SE_ACT_GELU) {                                                                                  \
         /* bf16 output: the transcendental-free polynomial (bf16.h); fp32 output keeps the erf form */                      \
-        const f32x2 ga = (OBF && !OF32) ? gelu_poly2((f32x2){v0, v1}) : gelu_erf2((f32x2){v0, v1});                        \
-        const f32x2 gb = (OBF && !OF32) ? gelu_poly2((f32x2){v2, v3}) : gelu_erf2((f32x2){v2, v3});                        \
+        const f32x2 ga = (OBF && !OF32 && !X3) ? gelu_poly2((f32x2){v0, v1}) : gelu_erf2((f32x2){v0, v1});                 \
+        const f32x2 gb = (OBF && !OF32 && !X3) ? gelu_poly2((f32x2){v2, v3}) : gelu_erf2((f32x2){v2, v3});                 \
         v0 = ga.x; v1 = ga.y; v2 = gb.x; v3 = gb.y;                                                                        \
       } else {                                                                                                             \
         v0 = act6(v0, ACT); v1 = act6(v1, ACT); v2 = act6(v2, ACT); v3 = act6(v3, ACT);                                    \
       }                                                                                                                    \
       if constexpr (RES) { v0 += rr[j].x; v1 += rr[j].y; v2 += rr[j].z; v3 += rr[j].w; }                                   \
       pk[j] = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));                                                        \
+      if constexpr (X3) {                                                                                                  \
+        /* the residual term y2 = bf16(y - y1) of the three-term operand; stored below with the 16-B pair exchange */      \
+        const float r0 = v0 - __uint_as_float(pk[j].x << 16), r1 = v1 - __uint_as_float(pk[j].x & 0xffff0000u);            \
+        const float r2 = v2 - __uint_as_float(pk[j].y << 16), r3 = v3 - __uint_as_float(pk[j].y & 0xffff0000u);            \
+        pm[j] = make_uint2(pack_bf16x2(r0, r1), pack_bf16x2(r2, r3));                                                      \
+        if (PRED) {                                                                                                        \
+          if (mok && gn < N) {                                                                                             \
+            uint16_t* o3 = out_bf16 + orow + gn;                                                                           \
+            *reinterpret_cast<uint2*>(o3) = pk[j];                                                                         \
+            *reinterpret_cast<uint2*>(o3 + ldc / 3) = pk[j];                                                               \
+            *reinterpret_cast<uint2*>(o3 + 2 * (ldc / 3)) = pm[j];                                                         \
+          }                                                                                                                \
+        }                                                                                                                  \
+      } else                                                                                                               \
       if (!(PRED) || (mok && gn < N)) {                                                                                    \
         if constexpr (OF32) *reinterpret_cast<float4*>(out_f32 + orow + gn) = make_float4(v0, v1, v2, v3);                 \
         if constexpr (OBF) {                                                                                               \
@@ -76,27 +92,32 @@ __device__ __forceinline__ float act6(float v, int act) {
     if constexpr (OBF) {                                                                                                   \
       if (!(PRED)) {                                                                                                       \
         /* 16-B stores: lanes l, l ^ 16 trade 4-column pieces of two neighbouring MFMA tiles, so each lane owns 8 consecutive   \
-           bf16 columns and a wave instruction writes 16 rows x 64 contiguous bytes (gemm3.hip) */                          \
-        _Pragma("unroll") for (int p2 = 0; p2 < 2; ++p2) {                                                                 \
-          const uint2 keep = godd ? pk[2 * p2 + 1] : pk[2 * p2];                                                           \
-          const uint2 send = godd ? pk[2 * p2] : pk[2 * p2 + 1];                                                           \
-          uint2 recv;                                                                                                      \
-          recv.x = __shfl_xor(send.x, 16);                                                                                 \
-          recv.y = __shfl_xor(send.y, 16);                                                                                 \
-          const uint4 o16 = godd ? make_uint4(recv.x, recv.y, keep.x, keep.y) : make_uint4(keep.x, keep.y, recv.x, recv.y); \
-          *reinterpret_cast<uint4*>(out_bf16 + orow + n0 + wc * 64 + 16 * (2 * p2 + (godd ? 1 : 0)) + ncol8) = o16;        \
+           bf16 columns and a wave instruction writes 16 rows x 64 contiguous bytes (gemm3.hip); X3: the y1 slice twice, then y2 */ \
+        _Pragma("unroll") for (int sl = 0; sl < (X3 ? 3 : 1); ++sl) {                                                      \
+          _Pragma("unroll") for (int p2 = 0; p2 < 2; ++p2) {                                                               \
+            const uint2 e0 = (X3 && sl == 2) ? pm[2 * p2] : pk[2 * p2], e1 = (X3 && sl == 2) ? pm[2 * p2 + 1] : pk[2 * p2 + 1]; \
+            const uint2 keep = godd ? e1 : e0;                                                                             \
+            const uint2 send = godd ? e0 : e1;                                                                             \
+            uint2 recv;                                                                                                    \
+            recv.x = __shfl_xor(send.x, 16);                                                                               \
+            recv.y = __shfl_xor(send.y, 16);                                                                               \
+            const uint4 o16 = godd ? make_uint4(recv.x, recv.y, keep.x, keep.y) : make_uint4(keep.x, keep.y, recv.x, recv.y); \
+            *reinterpret_cast<uint4*>(out_bf16 + orow + (X3 ? sl * (ldc / 3) : 0) + n0 + wc * 64 + 16 * (2 * p2 + (godd ? 1 : 0)) + ncol8) = o16; \
+          }                                                                                                                \
         }                                                                                                                  \
       }                                                                                                                    \
     }                                                                                                                      \
   }
 
-// ACT: compile-time activation; EF bit 0: fp32 residual, bit 1: bf16 output, bit 2: fp32 output (N % 4 == 0, 16-B rows)
+// ACT: compile-time activation; EF bit 0: fp32 residual, bit 1: bf16 output, bit 2: fp32 output (N % 4 == 0, 16-B rows), bit 3 (with bit 1): the bf16
+// output is the three-term operand [y1 | y1 | y2] of the next bf16x3 projection (row stride ldc = 3 x slice width; exact erf GELU)
 template <int ACT, int EF>
 __global__ __launch_bounds__(k6Threads) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm6_bf16_kernel(
     const uint16_t* __restrict__ A, int lda, const uint16_t* __restrict__ W, int ldw, const float* __restrict__ bias,
     const float* __restrict__ residual, int M, int N, int K, uint16_t* __restrict__ out_bf16, float* __restrict__ out_f32,
     int ldc, int tiles_m, int tiles_n, int group_m) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  SE_CLKPROBE_BEGIN();
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
@@ -246,7 +267,7 @@ __global__ __launch_bounds__(k6Threads) __attribute__((amdgpu_waves_per_eu(2, 2)
   if (!late) __builtin_amdgcn_s_barrier();                 // re-align the two groups (barrier counts must match)
 
   // ---- epilogue: C^T accumulators: col = lane & 15 -> output row, row = 4 (lane >> 4) + r -> 4 consecutive columns
-  constexpr bool RES = EF & 1, OBF = EF & 2, OF32 = EF & 4;
+  constexpr bool RES = EF & 1, OBF = EF & 2, OF32 = EF & 4, X3 = EF & 8;
   const int mrow = lane & 15, ncol = 4 * (lane >> 4);
   float4 bb[4];
 #pragma unroll
@@ -263,6 +284,7 @@ __global__ __launch_bounds__(k6Threads) __attribute__((amdgpu_waves_per_eu(2, 2)
   } else {
     SE6_EPILOGUE_BODY(true)
   }
+  SE_CLKPROBE_END(clkprobe_gemm6);
 #undef SE6_DMA
 #undef SE6_READ_A
 #undef SE6_READ_B
@@ -288,7 +310,8 @@ __global__ __launch_bounds__(k6Threads) __attribute__((amdgpu_waves_per_eu(2, 2)
     const uint16_t* __restrict__ A, int lda, const uint16_t* __restrict__ W, int ldw, const float* __restrict__ bias, int M, int N, int K,
     uint16_t* __restrict__ out_bf16, int ldc, int tiles_m, int tiles_n, int group_m, int late_start) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr bool RES = false, OBF = true, OF32 = false;
+  SE_CLKPROBE_BEGIN();
+  constexpr bool RES = false, OBF = true, OF32 = false, X3 = false;
   const float* residual = nullptr;          // named by the shared epilogue body inside discarded branches only
   float* out_f32 = nullptr;
   (void)residual; (void)out_f32;
@@ -521,6 +544,7 @@ __global__ __launch_bounds__(k6Threads) __attribute__((amdgpu_waves_per_eu(2, 2)
     if (late && has_next) __builtin_amdgcn_s_barrier();    // stagger again
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // no LDS-DMA may outlive the workgroup's LDS allocation
+  SE_CLKPROBE_END(clkprobe_gemm6);
 #undef SE6P_TILE
 #undef SE6P_SET_SRC
 #undef SE6P_DMA
@@ -625,4 +649,20 @@ extern "C" int se_gemm6_launch(const uint16_t* A, int lda, const uint16_t* W, in
   if (!gelu && !res && !obf) return launch6<SE_ACT_IDENTITY, 4>(g);
   if (gelu && !res && !obf) return launch6<SE_ACT_GELU, 4>(g);
   return 1;
+}
+
+// out3 (M, 3 Kp) bf16 = the three-term activation operand [y1 | y1 | y2] of y = act(A . W^T + bias) (se_split3_bf16's layout, which = 0): the bf16x3
+// parity mode's projections hand their result to the next projection in this form instead of writing fp32 and splitting it in another pass
+// (round 4: 14 % of that mode's pass).  A / W are themselves three-term operands ([x1 | x1 | x2] . [w1 | w2 | w1]^T, depth K = 3 x the layer's);
+// act: SE_ACT_IDENTITY or SE_ACT_GELU (exact erf form).
+extern "C" int se_gemm_x3out_bf16(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias, int M, int N, int K, int act,
+                                  uint16_t* out3, int Kp, void* stream) {
+  SE_REQUIRE(A && W && out3, "se_gemm_x3out_bf16: null argument");
+  SE_REQUIRE(M > 0 && N > 0 && N % 4 == 0 && K % se::k6BK == 0 && K >= 2 * se::k6BK, "se_gemm_x3out_bf16: bad shape M=%d N=%d K=%d", M, N, K);
+  SE_REQUIRE(Kp >= N && Kp % 8 == 0 && lda >= K && ldw >= K && lda % 8 == 0 && ldw % 8 == 0, "se_gemm_x3out_bf16: bad leading dimensions");
+  SE_REQUIRE((((uintptr_t)A | (uintptr_t)W | (uintptr_t)out3 | (uintptr_t)bias) % 16) == 0, "se_gemm_x3out_bf16: operands must be 16-B aligned");
+  SE_REQUIRE(act == SE_ACT_IDENTITY || act == SE_ACT_GELU, "se_gemm_x3out_bf16: act %d (identity or GELU)", act);
+  G6Args g{A, lda, W, ldw, bias, nullptr, M, N, K, out3, nullptr, 3 * Kp, se::as_stream(stream)};
+  se::ProfScope prof(se::kProfGemm, 2.0 * M * (double)N * K, g.st);
+  return act == SE_ACT_GELU ? launch6<SE_ACT_GELU, 2 | 8>(g) : launch6<SE_ACT_IDENTITY, 2 | 8>(g);
 }

@@ -416,6 +416,7 @@ int se_mhsa3_fwd_launch(const uint16_t* qkv, const int32_t* lengths, int B, int 
 int se_mhsa8_fwd_launch(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, int never_speculate, hipStream_t st);   // mhsa8.hip
 int se_mhsa9_fwd_launch(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, int never_speculate, hipStream_t st);   // mhsa9.hip
 int se_mhsaN_fwd_launch(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, int never_speculate, int nw, int wpe, hipStream_t st);   // mhsa8.hip
+int se_mhsaP_fwd_launch(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, int never_speculate, int wgs, hipStream_t st);   // mhsa8.hip
 
 static int mhsa_fwd_launch(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, float* lse, float dropout_p,
                            uint64_t seed, uint32_t site, void* stream) {
@@ -462,6 +463,8 @@ static int mhsa_prescaled_launch(const uint16_t* qkv, const int32_t* lengths, in
   static int spec = -1;
   if (spec < 0) { const char* e = getenv("SE_AMD_MHSA_SPEC"); spec = e ? atoi(e) : 1; }      // 0: always the exact online-softmax tile (A/B)
   if (pipe == 12) return se_mhsa9_fwd_launch(qkv, lengths, B, T, heads, ctx, spec ? 0 : 1, se::as_stream(stream));      // 8 waves, software-pipelined over the key tiles (mhsa9.hip)
+  if (pipe == 11 || pipe == 13 || pipe == 14)      // variant 10 as persistent workgroups (mhsa8.hip); 13 / 14: with 8 / 5 workgroups (tests: long item lists, both list forms)
+    return se_mhsaP_fwd_launch(qkv, lengths, B, T, heads, ctx, spec ? 0 : 1, pipe == 11 ? 0 : (pipe == 13 ? 8 : 5), se::as_stream(stream));
   if (pipe == 9 || pipe == 10 || pipe == 16) return se_mhsaN_fwd_launch(qkv, lengths, B, T, heads, ctx, spec ? 0 : 1, pipe == 16 ? 16 : 8, pipe == 9 ? 2 : 4, se::as_stream(stream));   // 8 / 16 free-running waves on one LDS-DMA staged tile (mhsa8.hip)
   if (pipe == 8) return se_mhsa8_fwd_launch(qkv, lengths, B, T, heads, ctx, spec ? 0 : 1, se::as_stream(stream));      // 8-wave alternating segments (mhsa8.hip)
   if (pipe == 3) return se_mhsa3_fwd_launch(qkv, lengths, B, T, heads, ctx, spec ? 0 : 1, se::as_stream(stream));      // interleaved matrix / vector stream, two query blocks per wave (mhsa3.hip)
@@ -520,7 +523,7 @@ extern "C" int se_mhsa_fwd_prescaled_bf16(const uint16_t* qkv, const int32_t* le
 // test / measurement surface: variant 0 = this file's kernel, 1 = the software-pipelined experiment of mhsa_pipe.hip, 2 = two query blocks per wave (mhsa2.hip)
 extern "C" int se_mhsa_fwd_prescaled_variant_bf16(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, int variant,
                                                   void* stream) {
-  SE_REQUIRE((variant >= 0 && variant <= 3) || variant == 8 || variant == 9 || variant == 10 || variant == 12 || variant == 16, "se_mhsa_fwd_prescaled_variant_bf16: variant %d (0 .. 3, 8, 9, 10, 12, 16)", variant);
+  SE_REQUIRE((variant >= 0 && variant <= 3) || (variant >= 8 && variant <= 14) || variant == 16, "se_mhsa_fwd_prescaled_variant_bf16: variant %d (0 .. 3, 8 .. 14, 16)", variant);
   return mhsa_prescaled_launch(qkv, lengths, B, T, heads, ctx, variant, stream);
 }
 

@@ -18,7 +18,9 @@
 // three-slot ring, tile t + 2 issued in L1(t); each wave waits for its own pieces of tile t + 1 with a counted vmcnt at the end of L1(t), and the
 // barrier behind it publishes them before any wave's L2(t).  Tile layout, swizzle and fragment addressing are mhsa.hip's (mhsa_tile.h: kv_off).
 // 256 queries per staged tile halve the staging per query of mhsa.hip; there is no ds_write and no VGPR staging at all.
+#include "clkprobe.h"
 #include <stdlib.h>
+#include <algorithm>
 #include "common.h"
 #include "prof.h"
 #include "bf16.h"
@@ -29,8 +31,17 @@
 #ifndef SE_MHSAN_ABL
 #define SE_MHSAN_ABL 0
 #endif
+// A/B: 1 = speculative exponentials in place + packed row-sum adds (16 v_pk_add_f32 instead of 32 v_add_f32 per tile, 118 instead of 128
+// registers), 0 = separate registers + scalar adds (what ships).  Measured on one box, interleaved (profiles/r04_mhsa_pkadd_ab.txt): the packed form
+// is 9-12 % SLOWER (8 waves 119.8-123.7 vs 110.1-111.3 us, 16 waves 131-134 vs 122-124): on this chip a packed fp32 add is not a cheaper issue
+// than two scalar ones next to a busy matrix pipe, and the in-place chain exp -> add -> pack shortens the distance between dependent instructions
+#ifndef SE_MHSAN_PKADD
+#define SE_MHSAN_PKADD 0
+#endif
 
+SE_CLKPROBE_DECL(clkprobe_mhsa)
 namespace se {
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 constexpr int k8Q = 256;        // query rows per workgroup
 constexpr int k8Slot = 16384;   // one ring slot: K tile (8 KiB) + V tile (8 KiB)
@@ -337,6 +348,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
     const uint16_t* __restrict__ qkv, const int32_t* __restrict__ lengths, int T, int H, uint16_t* __restrict__ ctx, float dscale) {
   constexpr int kRing = STAG ? 4 : 3;
   __shared__ __attribute__((aligned(16))) char smem[kRing * k8Slot];
+  SE_CLKPROBE_BEGIN();
   static_assert(NW == 8 || NW == 16, "8 or 16 waves");
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -439,28 +451,55 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
     const int slot1 = slot == kRing - 1 ? 0 : slot + 1, slot2 = slot1 == kRing - 1 ? 0 : slot1 + 1;      // (slot + 1), (slot + 2) mod ring
     if (kt + 2 < nkt && !(SE_MHSAN_ABL & 1)) SEN_DMA(kt + 2, slot2);       // the slot of tile kt - 1: every wave left it before the barrier that ended tile kt - 1
     f32x16 s0, s1;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const bf16x8 ka = (SE_MHSAN_ABL & 4) ? qf[s] : *reinterpret_cast<const bf16x8*>(t_s + (koff0 ^ (s << 5)));
-      const bf16x8 kb_ = (SE_MHSAN_ABL & 4) ? qf[3 - s] : *reinterpret_cast<const bf16x8*>(t_s + (koff0 ^ (s << 5)) + 4096);
-      s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[s], s == 0 ? kZero16 : s0, 0, 0, 0);
-      s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb_, qf[s], s == 0 ? kZero16 : s1, 0, 0, 0);
-    }
+    // S^T = K Q^T of this tile + the key mask of a ragged last tile.  A macro: the exact path re-issues it when the speculative exponentials (taken in
+    // place, below) failed their range test -- rare, and the K tile is still in its slot
+#define SEN_QK()                                                                                                              \
+    do {                                                                                                                      \
+      _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                                         \
+        const bf16x8 ka = (SE_MHSAN_ABL & 4) ? qf[s] : *reinterpret_cast<const bf16x8*>(t_s + (koff0 ^ (s << 5)));            \
+        const bf16x8 kb_ = (SE_MHSAN_ABL & 4) ? qf[3 - s] : *reinterpret_cast<const bf16x8*>(t_s + (koff0 ^ (s << 5)) + 4096); \
+        s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[s], s == 0 ? kZero16 : s0, 0, 0, 0);                              \
+        s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb_, qf[s], s == 0 ? kZero16 : s1, 0, 0, 0);                             \
+      }                                                                                                                       \
+      if ((kt + 1) * kAK > len) {                                                                                             \
+        const int kbase = kt * kAK + 4 * hh;                                                                                  \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                                      \
+          const int key = kbase + (r & 3) + 8 * (r >> 2);                                                                     \
+          if (key >= len) s0[r] = -INFINITY;                                                                                  \
+          if (key + 32 >= len) s1[r] = -INFINITY;                                                                             \
+        }                                                                                                                     \
+      }                                                                                                                       \
+    } while (0)
+    SEN_QK();
     // barrier positions of the staggered forms: STAG 1: early waves at the tile end, late ones after the softmax; 2: end / after QK^T;
     // 3: after QK^T / after the softmax
     if ((STAG == 2 && late) || (STAG == 3 && !late)) SEN_SYNC();
-    if ((kt + 1) * kAK > len) {
-      const int kbase = kt * kAK + 4 * hh;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = kbase + (r & 3) + 8 * (r >> 2);
-        if (key >= len) s0[r] = -INFINITY;
-        if (key + 32 >= len) s1[r] = -INFINITY;
-      }
-    }
     bf16x8 pf[2][2];
-    bool spec_ok = false;
+    bool spec_ok = false, redo = false;
     if (!slow) {
+#if SE_MHSAN_PKADD
+      // exponentials IN PLACE in the score registers; neighbouring registers of one accumulator block are an aligned pair, so the row sum
+      // takes ONE v_pk_add_f32 per two exponentials (16 instead of 32 adds per tile)
+      f32x2 rs2 = {0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          s0[2 * k + e] = (SE_MHSAN_ABL & 8) ? s0[2 * k + e] * 0.5f + 1.0f : __builtin_amdgcn_exp2f(s0[2 * k + e]);
+          s1[2 * k + e] = (SE_MHSAN_ABL & 8) ? s1[2 * k + e] * 0.5f + 1.0f : __builtin_amdgcn_exp2f(s1[2 * k + e]);
+        }
+        rs2 += f32x2{s0[2 * k], s0[2 * k + 1]};
+        rs2 += f32x2{s1[2 * k], s1[2 * k + 1]};
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          pf[0][s][j] = (__bf16)s0[8 * s + j];
+          pf[1][s][j] = (__bf16)s1[8 * s + j];
+        }
+      const float rs = rs2[0] + rs2[1];
+#else
       float rs0 = 0.f, rs1 = 0.f;
 #pragma unroll
       for (int s = 0; s < 2; ++s)
@@ -474,15 +513,18 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
           pf[1][s][j] = (__bf16)a1;
         }
       const float rs = rs0 + rs1;
+#endif
       const bool bad = !(rs < 0x1p60f) || (kt == 0 && rs < 0x1p-60f);
       if (!__any(bad)) {
         l_run += rs;
         spec_ok = true;
       } else {
         slow = true;
+        redo = true;
       }
     }
     if (!spec_ok) {
+      if (redo && SE_MHSAN_PKADD) SEN_QK();                  // the scores again: the failed speculation exponentiated them in place
       float mx = fmaxf(s0[0], s1[0]);
 #pragma unroll
       for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, s0[r]), s1[r]);
@@ -538,6 +580,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
     slot = slot1;
   }
 
+#undef SEN_QK
+  SE_CLKPROBE_END(clkprobe_mhsa);
   const float l_tot = l_run + __shfl_xor(l_run, 32);
   const float inv = 1.0f / l_tot;
   const int q = q0 + l31;
@@ -551,6 +595,272 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
       *reinterpret_cast<uint2*>(op + 32 + 8 * g) = w1;
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+// mhsaP_fwd_kernel: mhsaN_fwd_kernel<8, 4, 1> as a PERSISTENT workgroup.  The in-kernel clock probe (csrc/clkprobe.h, profiles/r04_clk_probe.txt)
+// put numbers on the launch: a 256-query workgroup lives 56 950 cycles = 30.2 us at the 1.885 GHz the chip holds in this kernel, the 1 536
+// workgroups of the bench shape are exactly three rounds of 2 per CU = 90.6 us, and the launch takes 108 us from the first workgroup's start to
+// the last one's end -- 16 % of the launch is workgroup turnover (dispatch, an empty ring, the first tiles' latency, the drain) between rounds.
+// Here 2 workgroups per CU are launched ONCE and each walks its list of (utterance, head, query tile) items; the K / V tiles of all its items
+// form ONE stream through the four-slot ring (the LDS-DMA look-ahead of two tiles crosses the item boundary, so the ring never drains), the next
+// item's Q fragments are fetched (inline asm, so their place among the counted LDS-DMA operations is fixed) right after the last QK^T of the
+// current item, and nothing but the epilogue's stores separates two items.  Same arithmetic, same tile order per item: bit-identical results.
+// Item order: XCD x (= blockIdx & 7) owns the pairs = x (mod 8); its workgroups take list positions slot, slot + n, slot + 2 n ... of
+// (pair-major, query tile minor), as the dispatcher would have handed them out.
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void mhsaP_fwd_kernel(
+    const uint16_t* __restrict__ qkv, const int32_t* __restrict__ lengths, int T, int H, uint16_t* __restrict__ ctx, float dscale, int nqt, int heads,
+    int pairs) {
+  constexpr int kRing = 4;
+  __shared__ __attribute__((aligned(16))) char smem[kRing * k8Slot];
+  SE_CLKPROBE_BEGIN();
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int ld = 3 * H;
+
+  // ---- this workgroup's item list: positions j0 + i * jstride, i < n_items
+  int j0, jstride, n_items, xcd = -1;
+  {
+    const int w = blockIdx.x, G = gridDim.x;
+    int per;
+    if ((pairs & 7) == 0 && (G & 7) == 0) { xcd = w & 7; j0 = w >> 3; jstride = G >> 3; per = nqt * (pairs >> 3); }
+    else { j0 = w; jstride = G; per = nqt * pairs; }
+    n_items = j0 < per ? (per - j0 + jstride - 1) / jstride : 0;
+  }
+  if (n_items == 0) return;
+#define SEP_DECODE(i, b_, head_, qt_)                                      \
+  do {                                                                     \
+    const int j_ = j0 + (i) * jstride;                                     \
+    const int pr_ = xcd >= 0 ? 8 * (j_ / nqt) + xcd : j_ / nqt;            \
+    qt_ = j_ % nqt; head_ = pr_ % heads; b_ = pr_ / heads;                 \
+  } while (0)
+
+  // ---- the K / V tile stream (all items back to back): cursor (d_i, d_kt), its item's base address and tile count
+  typedef __attribute__((address_space(3))) char* lds_c_t;
+  const int drow = wave * 8 + (lane >> 3);
+  const uint32_t dch = (uint32_t)(((lane & 7) ^ (kv_off(drow, 0) >> 4 & 7)) * 16);
+  const uint32_t dpk = (uint32_t)drow | (dch << 8);
+  const uint32_t lds_piece = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(lds_c_t)smem + wave * 1024);
+  int d_i = 0, d_kt = 0, d_nkt = 0;
+  const char* d_base = nullptr;
+#define SEP_DSETUP()                                                                                  \
+  do {                                                                                                \
+    int b_, head_, qt_;                                                                               \
+    SEP_DECODE(d_i, b_, head_, qt_);                                                                  \
+    (void)qt_;                                                                                        \
+    const int len_ = lengths ? min(max(lengths[b_], 1), T) : T;                                       \
+    d_nkt = (len_ + kAK - 1) / kAK;                                                                   \
+    d_base = reinterpret_cast<const char*>(qkv + (size_t)b_ * T * ld + head_ * kHD);                  \
+  } while (0)
+  SEP_DSETUP();
+  bool iss = false;
+  // one tile of the stream (K piece + V piece of this wave) into ring slot `slot_`; iss = whether the stream still had a tile
+#define SEP_DMA_NEXT(slot_)                                                                                                     \
+  do {                                                                                                                          \
+    iss = d_i < n_items;                                                                                                        \
+    if (iss) {                                                                                                                  \
+      uint32_t dp_ = dpk;                                                                                                       \
+      asm volatile("" : "+v"(dp_));                                                                                             \
+      const uint32_t row_ = (uint32_t)(min(d_kt * kAK + (int)(dp_ & 0xffu), T - 1) * ld);                                       \
+      const uint32_t o0_ = (row_ + (uint32_t)H) * 2u + (dp_ >> 8), o1_ = (row_ + 2u * (uint32_t)H) * 2u + (dp_ >> 8);           \
+      uint32_t keep_;                                                                                                           \
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"      \
+                   : "=&s"(keep_) : "v"(o0_), "s"(d_base), "s"(lds_piece + (uint32_t)((slot_) * k8Slot)) : "memory");           \
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"      \
+                   : "=&s"(keep_) : "v"(o1_), "s"(d_base), "s"(lds_piece + (uint32_t)((slot_) * k8Slot + 8192)) : "memory");    \
+      if (++d_kt == d_nkt) {                                                                                                    \
+        d_kt = 0;                                                                                                               \
+        if (++d_i < n_items) SEP_DSETUP();                                                                                      \
+      }                                                                                                                         \
+    }                                                                                                                           \
+  } while (0)
+
+  // ---- item 0: Q fragments first (plain loads, older than every LDS-DMA), then the stream's first two tiles
+  int b, head, qt;
+  SEP_DECODE(0, b, head, qt);
+  bf16x8 qf[4];
+  {
+    const int q = min(qt * k8Q + wave * 32 + l31, T - 1);
+    const uint16_t* qp = qkv + ((size_t)b * T + q) * ld + head * kHD + 8 * hh;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
+  }
+  SEP_DMA_NEXT(0);
+  SEP_DMA_NEXT(1);
+  if (iss) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  SE8_BAR();
+
+  const f32x16 kZero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  constexpr float kDefer = 8.f;
+  const int koff0 = kv_off(l31, hh);
+  const int tq = (lane & 15) >> 2, tp = lane & 3, g1 = (lane >> 4) & 1;
+  int voff[2][2];
+#pragma unroll
+  for (int dblk = 0; dblk < 2; ++dblk) {
+    const int dcol = dblk * 32 + 16 * g1 + 4 * tp;
+    voff[dblk][0] = 8192 + kv_off(4 * hh + tq, dcol >> 3) + (dcol & 7) * 2;
+    voff[dblk][1] = 8192 + kv_off(4 * hh + tq + 8, dcol >> 3) + (dcol & 7) * 2;
+  }
+  const bool late = (wave & 4) != 0;
+  // the tile's barrier: this wave's pieces of the NEXT stream tile (issued one tile ago) have landed when all but the operations issued since
+  // -- this tile's LDS-DMA pair (iss) and the four Q loads of the next item (qpre) -- are complete
+#define SEP_SYNC()                                                                                                            \
+  do {                                                                                                                        \
+    if (iss) { if (qpre) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); } \
+    else { if (qpre) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } \
+    SE8_BAR();                                                                                                                \
+  } while (0)
+
+  int slot = 0;
+  for (int it = 0; it < n_items; ++it) {
+    if (it > 0) SEP_DECODE(it, b, head, qt);
+    const int q0 = qt * k8Q + wave * 32;
+    const int len = lengths ? min(max(lengths[b], 1), T) : T;
+    const int nkt = (len + kAK - 1) / kAK;
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+    float m_run = 0.f, l_run = 0.f;
+    bool slow = dscale < 0.f;
+    bool qpre = false;
+    for (int kt = 0; kt < nkt; ++kt) {
+      const char* t_s = smem + slot * k8Slot;
+      const int slot1 = (slot + 1) & 3, slot2 = (slot + 2) & 3;
+      SEP_DMA_NEXT(slot2);                 // the slot of stream tile t - 2: every wave left it before the barrier(s) that ended tile t - 1
+      f32x16 s0, s1;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const bf16x8 ka = *reinterpret_cast<const bf16x8*>(t_s + (koff0 ^ (s << 5)));
+        const bf16x8 kb_ = *reinterpret_cast<const bf16x8*>(t_s + (koff0 ^ (s << 5)) + 4096);
+        s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[s], s == 0 ? kZero16 : s0, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb_, qf[s], s == 0 ? kZero16 : s1, 0, 0, 0);
+      }
+      if (kt == nkt - 1 && it + 1 < n_items) {
+        // the item's last QK^T is issued: its Q registers take the next item's fragments (waited for with vmcnt(0) behind this tile)
+        int nb, nh, nq;
+        SEP_DECODE(it + 1, nb, nh, nq);
+        const char* sb = reinterpret_cast<const char*>(qkv + (size_t)nb * T * ld + nh * kHD);       // scalar base of the item; lane part below
+        // the lane id re-derived HERE (mbcnt): a hoisted address pair, or `lane` itself, is a register the tile loop does not have -- it was spilled,
+        // and its reload's vmcnt(0) waited for the LDS-DMA just issued
+        int lq;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lq));
+        const uint32_t vo = (uint32_t)(min(nq * k8Q + wave * 32 + (lq & 31), T - 1) * ld + 8 * (lq >> 5)) * 2u;
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(qf[0]) : "v"(vo), "s"(sb) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:32" : "=v"(qf[1]) : "v"(vo), "s"(sb) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:64" : "=v"(qf[2]) : "v"(vo), "s"(sb) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:96" : "=v"(qf[3]) : "v"(vo), "s"(sb) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        qpre = true;
+      }
+      if ((kt + 1) * kAK > len) {
+        const int kbase = kt * kAK + 4 * hh;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kbase + (r & 3) + 8 * (r >> 2);
+          if (key >= len) s0[r] = -INFINITY;
+          if (key + 32 >= len) s1[r] = -INFINITY;
+        }
+      }
+      bf16x8 pf[2][2];
+      bool spec_ok = false;
+      if (!slow) {
+        float rs0 = 0.f, rs1 = 0.f;
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float a0 = __builtin_amdgcn_exp2f(s0[8 * s + j]);
+            const float a1 = __builtin_amdgcn_exp2f(s1[8 * s + j]);
+            rs0 += a0;
+            rs1 += a1;
+            pf[0][s][j] = (__bf16)a0;
+            pf[1][s][j] = (__bf16)a1;
+          }
+        const float rs = rs0 + rs1;
+        const bool bad = !(rs < 0x1p60f) || (kt == 0 && rs < 0x1p-60f);
+        if (!__any(bad)) {
+          l_run += rs;
+          spec_ok = true;
+        } else {
+          slow = true;
+        }
+      }
+      if (!spec_ok) {
+        float mx = fmaxf(s0[0], s1[0]);
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, s0[r]), s1[r]);
+        {
+          const auto sw_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+          mx = fmaxf(__uint_as_float(sw_[0]), __uint_as_float(sw_[1]));
+        }
+        float m_new = ((mx - m_run) > kDefer) ? mx : m_run;
+        if (kt == 0 && mx < -64.f) m_new = mx;
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        const float mc = -m_new;
+        float rs0 = 0.f, rs1 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float a0 = __builtin_amdgcn_exp2f(s0[r] + mc);
+          const float a1 = __builtin_amdgcn_exp2f(s1[r] + mc);
+          rs0 += a0;
+          rs1 += a1;
+          s0[r] = a0; s1[r] = a1;
+        }
+        l_run = fmaf(l_run, alpha, rs0 + rs1);
+        m_run = m_new;
+        if (__any(alpha != 1.0f)) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            pf[0][s][j] = (__bf16)s0[8 * s + j];
+            pf[1][s][j] = (__bf16)s1[8 * s + j];
+          }
+      }
+      if (late) SEP_SYNC();
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int dblk = 0; dblk < 2; ++dblk) {
+            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                (__attribute__((address_space(3))) bf16x4*)(t_s + voff[dblk][0] + kb * 4096 + s * 2048));
+            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                (__attribute__((address_space(3))) bf16x4*)(t_s + voff[dblk][1] + kb * 4096 + s * 2048));
+            const bf16x8 va = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            if (dblk == 0) o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, pf[kb][s], o0, 0, 0, 0);
+            else o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, pf[kb][s], o1, 0, 0, 0);
+          }
+      if (!late) SEP_SYNC();
+      slot = slot1;
+    }
+    if (qpre) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the next item's Q fragments are in their registers
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.0f / l_tot;
+    const int q = q0 + l31;
+    if (q < T) {
+      uint16_t* op = ctx + ((size_t)b * T + q) * H + head * kHD + 4 * hh;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        uint2 w0 = make_uint2(pack_bf16x2(o0[4 * g] * inv, o0[4 * g + 1] * inv), pack_bf16x2(o0[4 * g + 2] * inv, o0[4 * g + 3] * inv));
+        uint2 w1 = make_uint2(pack_bf16x2(o1[4 * g] * inv, o1[4 * g + 1] * inv), pack_bf16x2(o1[4 * g + 2] * inv, o1[4 * g + 3] * inv));
+        *reinterpret_cast<uint2*>(op + 8 * g) = w0;
+        *reinterpret_cast<uint2*>(op + 32 + 8 * g) = w1;
+      }
+    }
+  }
+  SE_CLKPROBE_END(clkprobe_mhsa);
+#undef SEP_SYNC
+#undef SEP_DMA_NEXT
+#undef SEP_DSETUP
+#undef SEP_DECODE
 }
 
 }  // namespace se
@@ -568,6 +878,31 @@ int se_mhsaN_fwd_launch(const uint16_t* qkv, const int32_t* lengths, int B, int 
   else if (nw == 16) hipLaunchKernelGGL((se::mhsaN_fwd_kernel<16, 4>), grid, dim3(1024), 0, st, qkv, lengths, T, H, ctx, never_speculate ? -1.f : 1.f);
   else if (wpe == 4) hipLaunchKernelGGL((se::mhsaN_fwd_kernel<8, 4>), grid, dim3(512), 0, st, qkv, lengths, T, H, ctx, never_speculate ? -1.f : 1.f);
   else hipLaunchKernelGGL((se::mhsaN_fwd_kernel<8, 2>), grid, dim3(512), 0, st, qkv, lengths, T, H, ctx, never_speculate ? -1.f : 1.f);
+  SE_LAUNCH_CHECK();
+  return SE_OK;
+}
+
+// variant 11: mhsaP_fwd_kernel -- two persistent workgroups per CU (SE_AMD_MHSAP_WGS overrides the grid for A/B); variants 13 / 14: 8 / 5 workgroups
+int se_mhsaP_fwd_launch(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, int never_speculate, int wgs, hipStream_t st) {
+  const int H = heads * se::kHD;
+  SE_REQUIRE((double)T * 3.0 * H * 2.0 < 2147483648.0, "se_mhsaP: T * 3 H * 2 = %.0f bytes exceeds the 31-bit DMA offset", (double)T * 3.0 * H * 2.0);
+  static int want = 0;
+  if (want == 0) {
+    if (const char* e = getenv("SE_AMD_MHSAP_WGS")) want = std::max(1, atoi(e));
+    else {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      SE_HIP(hipGetDevice(&dev));
+      SE_HIP(hipGetDeviceProperties(&prop, dev));
+      want = 2 * std::max(8, prop.multiProcessorCount & ~7);      // 64 KiB of LDS and 128 registers per lane: exactly two resident per CU
+    }
+  }
+  const int nqt = (T + se::k8Q - 1) / se::k8Q;
+  const long items = (long)nqt * heads * B;
+  SE_REQUIRE(items < 2147483647L, "se_mhsaP: %ld work items", items);
+  int grid = (int)std::min<long>(wgs > 0 ? wgs : want, items);       // wgs > 0: the tests' short grids (many items per workgroup, both list forms)
+  if (grid >= 8) grid &= ~7;                    // whole XCD rounds (the kernel's XCD-aware list needs gridDim % 8 == 0)
+  hipLaunchKernelGGL(se::mhsaP_fwd_kernel, dim3(grid), dim3(512), 0, st, qkv, lengths, T, H, ctx, never_speculate ? -1.f : 1.f, nqt, heads, heads * B);
   SE_LAUNCH_CHECK();
   return SE_OK;
 }

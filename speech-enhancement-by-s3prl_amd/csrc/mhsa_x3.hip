@@ -41,7 +41,8 @@ constexpr int kXBuf = 4 * kXTile;            // K_h, K_l, V_h, V_l: 32 KiB per b
 }  // namespace
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void mhsa_x3_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ lengths,
-                                                                                                int T, int H, float* __restrict__ ctx) {
+                                                                                                int T, int H, float* __restrict__ ctx,
+                                                                                                uint16_t* __restrict__ ctx3, int Kp) {
   __shared__ __attribute__((aligned(16))) char smem[2 * kXBuf];      // 64 KiB
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -233,13 +234,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const float l_tot = l_run + __shfl_xor(l_run, 32);
   const float inv = 1.0f / l_tot;
   const int q = q0 + l31;
-  if (q < T) {
+  if (q < T && ctx) {
     float* op = ctx + ((size_t)b * T + q) * H + head * kHD + 4 * hh;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       *reinterpret_cast<float4*>(op + 8 * g) = make_float4(o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
       *reinterpret_cast<float4*>(op + 32 + 8 * g) = make_float4(o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
     }
+  }
+  if (q < T && ctx3) {
+    // round 4: the context leaves as the three-term operand [c1 | c1 | c2] of the output projection (se_split3_bf16's activation layout, row stride
+    // 3 Kp) -- the separate split pass read the fp32 tensor back and wrote this
+    uint16_t* op = ctx3 + ((size_t)b * T + q) * 3 * (size_t)Kp + head * kHD + 4 * hh;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int blk = 0; blk < 2; ++blk) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (blk ? o1[4 * g + e] : o0[4 * g + e]) * inv;
+        uint16_t hi[4], mid[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const __bf16 h = (__bf16)v[e];
+          hi[e] = __builtin_bit_cast(uint16_t, h);
+          mid[e] = __builtin_bit_cast(uint16_t, (__bf16)(v[e] - (float)h));
+        }
+        const uint2 ph = make_uint2(hi[0] | ((uint32_t)hi[1] << 16), hi[2] | ((uint32_t)hi[3] << 16));
+        const uint2 pm = make_uint2(mid[0] | ((uint32_t)mid[1] << 16), mid[2] | ((uint32_t)mid[3] << 16));
+        uint16_t* o = op + 32 * blk + 8 * g;
+        *reinterpret_cast<uint2*>(o) = ph;
+        *reinterpret_cast<uint2*>(o + Kp) = ph;
+        *reinterpret_cast<uint2*>(o + 2 * (size_t)Kp) = pm;
+      }
   }
 }
 
@@ -251,7 +278,18 @@ extern "C" int se_mhsa_fwd_x3_f32(const float* qkv, const int32_t* lengths, int 
   SE_REQUIRE((((uintptr_t)qkv | (uintptr_t)ctx) % 16) == 0, "se_mhsa_fwd_x3_f32: buffers must be 16-B aligned");
   const int H = heads * se::kHD;
   dim3 grid((T + se::kAQ - 1) / se::kAQ, heads, B);
-  hipLaunchKernelGGL(se::mhsa_x3_kernel, grid, dim3(256), 0, se::as_stream(stream), qkv, lengths, T, H, ctx);
+  hipLaunchKernelGGL(se::mhsa_x3_kernel, grid, dim3(256), 0, se::as_stream(stream), qkv, lengths, T, H, ctx, (uint16_t*)nullptr, 0);
+  SE_LAUNCH_CHECK();
+  return SE_OK;
+}
+
+extern "C" int se_mhsa_fwd_x3_split_f32(const float* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx3, int Kp, void* stream) {
+  SE_REQUIRE(qkv && ctx3, "se_mhsa_fwd_x3_split_f32: null argument");
+  SE_REQUIRE(B > 0 && B <= 65535 && T > 0 && heads > 0 && heads <= 65535, "se_mhsa_fwd_x3_split_f32: bad shape B=%d T=%d heads=%d", B, T, heads);
+  const int H = heads * se::kHD;
+  SE_REQUIRE(Kp >= H && Kp % 8 == 0 && (((uintptr_t)qkv | (uintptr_t)ctx3) % 16) == 0, "se_mhsa_fwd_x3_split_f32: Kp = %d must be >= %d, a multiple of 8, buffers 16-B aligned", Kp, H);
+  dim3 grid((T + se::kAQ - 1) / se::kAQ, heads, B);
+  hipLaunchKernelGGL(se::mhsa_x3_kernel, grid, dim3(256), 0, se::as_stream(stream), qkv, lengths, T, H, (float*)nullptr, ctx3, Kp);
   SE_LAUNCH_CHECK();
   return SE_OK;
 }

@@ -509,6 +509,55 @@ class _Engine:
         ir = model.input_representations
         w = lambda p: p.detach().contiguous()       # noqa: E731
         x = self._linear3(feats.view(M, D), ir.spec_transform.weight, w(ir.spec_transform.bias), M, H, D, residual=pe)
+        # Round 4: from here on every producer hands the NEXT projection its three-term operand [y1 | y1 | y2] directly (se_layernorm_x3_f32,
+        # se_mhsa_fwd_x3_split_f32, se_gemm_x3out_bf16) -- the separate se_split3_bf16 passes (4 per layer, 14 % of the pass) only remain in front
+        # of the input projection.  H and I are multiples of 64, so the slice width Kp equals the layer width.
+        chained = H % 64 == 0 and I % 64 == 0 and H in (256, 512, 768, 1024)
+        if not chained:
+            return self._encode_x3_unchained(model, x, ir, lengths, B, T, H, heads, I, M)
+        x3 = torch.empty(M, 3 * H, device=dev, dtype=torch.bfloat16)
+        c3 = torch.empty(M, 3 * H, device=dev, dtype=torch.bfloat16)
+        h3 = torch.empty(M, 3 * I, device=dev, dtype=torch.bfloat16)
+        qkv = torch.empty(M, 3 * H, device=dev, dtype=torch.float32)
+        a = torch.empty(M, H, device=dev, dtype=torch.float32)
+        xa = torch.empty(M, H, device=dev, dtype=torch.float32)
+        xb = torch.empty(M, H, device=dev, dtype=torch.float32)
+
+        def ln3(src, ln, dst):
+            _lib.check(lib.se_layernorm_x3_f32(_lib.ptr(src), _lib.ptr(ln.weight.detach()), _lib.ptr(ln.bias.detach()), M, H, float(ln.variance_epsilon),
+                                               _lib.ptr(dst), _lib.ptr(x3), H, _lib.stream()), 'se_layernorm_x3_f32')
+
+        def gemm3(a3, K3, w3, bias, N, act=0, residual=None, out=None):
+            _lib.check(lib.se_gemm_bf16(_lib.ptr(a3), K3, _lib.ptr(w3), K3, _lib.ptr(bias), _lib.ptr(residual), M, N, K3, int(act), None, _lib.ptr(out), N,
+                                        _lib.stream()), 'se_gemm_bf16')
+
+        ln3(x, ir.LayerNorm, xa)
+        x = xa
+        for layer in model.encoder.layer:
+            att = layer.attention
+            qb = torch.cat([att.self.query.bias.detach(), att.self.key.bias.detach(), att.self.value.bias.detach()]).float().contiguous()
+            wq, _ = self._w3((att.self.query.weight, att.self.key.weight, att.self.value.weight))
+            gemm3(x3, 3 * H, wq, qb, 3 * H, out=qkv)
+            # flash attention on two-term splits of Q, K, V and P (csrc/mhsa_x3.hip): no (B, heads, T, T) score tensor; the context leaves split
+            _lib.check(lib.se_mhsa_fwd_x3_split_f32(_lib.ptr(qkv), _lib.ptr(lengths), B, T, heads, _lib.ptr(c3), H, _lib.stream()), 'se_mhsa_fwd_x3_split_f32')
+            wo, _ = self._w3(att.output.dense.weight)
+            gemm3(c3, 3 * H, wo, w(att.output.dense.bias), H, residual=x, out=a)
+            x = xb if x is xa else xa
+            ln3(a, att.output.LayerNorm, x)
+            w1, _ = self._w3(layer.intermediate.dense.weight)
+            _lib.check(lib.se_gemm_x3out_bf16(_lib.ptr(x3), 3 * H, _lib.ptr(w1), 3 * H, _lib.ptr(w(layer.intermediate.dense.bias)), M, I, 3 * H,
+                                              _lib.SE_ACT['GELU'], _lib.ptr(h3), I, _lib.stream()), 'se_gemm_x3out_bf16')
+            w2, _ = self._w3(layer.output.dense.weight)
+            gemm3(h3, 3 * I, w2, w(layer.output.dense.bias), H, residual=x, out=a)
+            x = xb if x is xa else xa
+            ln3(a, layer.output.LayerNorm, x)
+        return x.view(B, T, H)
+
+    def _encode_x3_unchained(self, model, x, ir, lengths, B, T, H, heads, I, M):
+        """encode_x3 for widths the fused producers are not built for: every projection splits its own input (the round-3 form)"""
+        lib = _lib.load()
+        dev = x.device
+        w = lambda p: p.detach().contiguous()       # noqa: E731
         x = self._ln32(x, ir.LayerNorm, M, H)
         qkv = torch.empty(M, 3 * H, device=dev, dtype=torch.float32)
         ctx = torch.empty(M, H, device=dev, dtype=torch.float32)
@@ -516,7 +565,6 @@ class _Engine:
             att = layer.attention
             qb = torch.cat([att.self.query.bias.detach(), att.self.key.bias.detach(), att.self.value.bias.detach()]).float().contiguous()
             self._linear3(x, (att.self.query.weight, att.self.key.weight, att.self.value.weight), qb, M, 3 * H, H, out=qkv)
-            # flash attention on two-term splits of Q, K, V and P (csrc/mhsa_x3.hip): no (B, heads, T, T) score tensor
             _lib.check(lib.se_mhsa_fwd_x3_f32(_lib.ptr(qkv), _lib.ptr(lengths), B, T, heads, _lib.ptr(ctx), _lib.stream()), 'se_mhsa_fwd_x3_f32')
             a = self._linear3(ctx, att.output.dense.weight, w(att.output.dense.bias), M, H, H, residual=x)
             x = self._ln32(a, att.output.LayerNorm, M, H)

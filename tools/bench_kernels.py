@@ -206,12 +206,16 @@ def bench_mhsa():
     # the selectable variants side by side, interleaved (0 = mhsa.hip, 8 = mhsa8.hip: 8-wave alternating segments)
     ctx3 = torch.empty_like(ctx)
     runs = {f'variant {v}': (lambda v=v: L.check(lib.se_mhsa_fwd_prescaled_variant_bf16(L.ptr(q2), None, B, T, heads, L.ptr(ctx3), v, L.stream()), 'mhsa-v'))
-            for v in (0, 8, 9, 10, 12, 16)}
+            for v in (0, 8, 9, 10, 11, 12, 16)}
     for k, (mn, md) in interleaved(runs, rounds=5, iters=20).items():
         print(f'mhsa prescaled {k}: {mn*1e3:8.1f} us (min) {md*1e3:8.1f} us (median)   {4.0*B*heads*T*T*64/md/1e9:8.1f} TF/s', flush=True)
     runs['variant 8']()
     d8 = (ctx3.float() - ctx2.float()).abs().max().item() / ctx2.float().abs().max().item()
     print(f'mhsa variant 8 vs variant 0: max diff {d8:.2e}', flush=True)
+    ctx4 = torch.empty_like(ctx)
+    L.check(lib.se_mhsa_fwd_prescaled_variant_bf16(L.ptr(q2), None, B, T, heads, L.ptr(ctx3), 10, L.stream()), 'mhsa-v')
+    L.check(lib.se_mhsa_fwd_prescaled_variant_bf16(L.ptr(q2), None, B, T, heads, L.ptr(ctx4), 11, L.stream()), 'mhsa-v')
+    print(f'mhsa variant 11 (persistent) vs variant 10: bit-identical {bool((ctx3.view(torch.int16) == ctx4.view(torch.int16)).all().item())}', flush=True)
 
 
 def bench_mhsa_peaked():
