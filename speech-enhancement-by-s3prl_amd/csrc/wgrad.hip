@@ -20,6 +20,7 @@
 //   split    : the m range is split so that tiles x splits ~ one workgroup per CU; every split writes its own fp32 slab
 //              [N][K] and a slab reduce finishes (deterministic).  Work items are dealt to the XCDs in contiguous ranges
 //              (bijective remap), so the tiles of one split -- which re-read the same dY / X slices -- share an L2.
+#include "clkprobe.h"
 #include <stdlib.h>
 #include <algorithm>
 #include "common.h"
@@ -27,6 +28,7 @@
 #include "bf16.h"
 #include "mhsa_tile.h"
 
+SE_CLKPROBE_DECL(clkprobe_wgrad)
 namespace se {
 
 constexpr int kWN = 256, kWK = 256, kWM = 32;
@@ -53,6 +55,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const uint16_t* __restrict__ dY, int ldy, const uint16_t* __restrict__ X, int ldx, int M, int N, int K, int m_per_split,
     int tiles_k, int tiles, int work, float* __restrict__ partials, unsigned long long* __restrict__ stamps) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  SE_CLKPROBE_BEGIN();
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave >> 2, wk = wave & 3;
@@ -95,13 +98,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
   const uint16_t* zero = reinterpret_cast<const uint16_t*>(&g_wgrad_zero);
   const int piece_off = (wave >> 2) * kWPanel + (wave & 3) * 1024;
+  // LDS-DMA by inline asm (M0 = the wave-uniform LDS destination): through __builtin_amdgcn_global_load_lds the compiler orders every later
+  // ds_read behind the DMA with s_waitcnt vmcnt(0) -- rounds 1-4 shipped exactly that in front of each step's first fragment read, so the
+  // counted waits below never applied and the "three stages in flight" were one (found with the clock probe: 2.2 GHz in-kernel, 0.39 of the
+  // matrix rate at that clock = stalled, not power-bound; the step took 2 200 cycles for 1 024 of MFMA)
+  const uint32_t lds_piece = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(w_lds_ptr_t)smem + (uint32_t)piece_off);
 #define SEW_ISSUE(t, st)                                                                                        \
   do {                                                                                                          \
     const int m = m_begin + (t) * kWM + row;                                                                    \
-    char* sb = smem + (st) * kWStage + piece_off;                                                               \
     _Pragma("unroll") for (int i = 0; i < kWDma; ++i) {                                                         \
       const uint16_t* p = (m < m_end && col_ok[i]) ? src[i] + (size_t)m * ld[i] : zero;                         \
-      __builtin_amdgcn_global_load_lds((w_glb_ptr_t)p, (w_lds_ptr_t)(sb + 2 * i * kWPanel), 16, 0, 0);          \
+      uint32_t keep_;                                                                                           \
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" \
+                   : "=&s"(keep_) : "v"(p), "s"(lds_piece + (uint32_t)((st) * kWStage + 2 * i * kWPanel)) : "memory"); \
     }                                                                                                           \
   } while (0)
 
@@ -209,6 +218,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     st = st + 1 == kRing ? 0 : st + 1;
   }
+  SE_CLKPROBE_END(clkprobe_wgrad);
   SEW_STAMP();
 #undef SEW_ISSUE
 

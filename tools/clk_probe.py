@@ -80,10 +80,36 @@ run('attention forward, persistent (mhsaP) B=32 T=1001', 'clkprobe_mhsa',
     lambda: L.check(lib.se_mhsa_fwd_prescaled_variant_bf16(L.ptr(qkv), None, B, T, heads, L.ptr(ctx), 11, L.stream()), 'mhsa'), 4.0 * B * heads * T * T * 64)
 
 x = torch.randn(M, 3072, device=dev).bfloat16()
-for (N, K, act, lab) in ((2304, 768, 0, 'QKV projection'), (3072, 768, 3, 'FFN1 + GELU')):
+for (N, K, act, lab) in ((2304, 768, 0, 'QKV projection'), (3072, 768, 3, 'FFN1 + GELU'), (3072, 768, 0, 'FFN1 shape WITHOUT the GELU'), (2304, 768, 3, 'QKV shape WITH a GELU')):
     w = (torch.randn(N, K, device=dev) * 0.03).bfloat16()
     bias = torch.randn(N, device=dev)
     out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
     xa = x[:, :K].contiguous()
     run(f'{lab} (gemm6 persistent) M={M} N={N} K={K}', 'clkprobe_gemm6',
         lambda: L.check(lib.se_gemm_bf16(L.ptr(xa), K, L.ptr(w), K, L.ptr(bias), None, M, N, K, act, L.ptr(out), None, N, L.stream()), 'gemm'), 2.0 * M * N * K)
+
+# the row-complete projections on the 24-bit residual stream (gemm7_res_ln_kernel, 128 x 768 tiles, one per CU)
+N = 768
+for K, lab in ((768, 'attention-output projection + residual + LN'), (3072, 'FFN2 + residual + LN')):
+    A = torch.randn(M, K, device=dev).bfloat16()
+    W = (torch.randn(N, K, device=dev) * 0.05).bfloat16()
+    bias, res = torch.randn(N, device=dev), torch.randn(M, N, device=dev).bfloat16()
+    nlo = lib.se_gemm_res24_lo_bytes(M)
+    rlo = torch.zeros(nlo, device=dev, dtype=torch.uint8)
+    lw, lb = torch.ones(N, device=dev), torch.zeros(N, device=dev)
+    o16 = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    olo = torch.empty(nlo, device=dev, dtype=torch.uint8)
+    scratch = torch.zeros(lib.se_gemm_res24_scratch_bytes(), device=dev, dtype=torch.uint8)
+    run(f'{lab} (gemm7) M={M} K={K}', 'clkprobe_gemm7',
+        lambda: L.check(lib.se_gemm_res24_ln_bf16(L.ptr(A), K, L.ptr(W), K, L.ptr(bias), L.ptr(res), L.ptr(rlo), L.ptr(lw), L.ptr(lb), 1e-12, M, N, K, None,
+                                                  L.ptr(o16), L.ptr(olo), 7, L.ptr(scratch), L.stream()), 'res24'), 2.0 * M * N * K)
+
+# the weight-gradient kernel (wgrad_tn_kernel: dW = dY^T X on row-major operands, split over the 32 032 rows; the slab reduce rides along)
+for (N, K, lab) in ((3072, 768, 'FFN1'), (768, 3072, 'FFN2'), (2304, 768, 'QKV')):
+    dY = torch.randn(M, N, device=dev).bfloat16()
+    X = torch.randn(M, K, device=dev).bfloat16()
+    dW = torch.empty(N, K, device=dev)
+    splits = max(1, min(32, 256 // (((N + 255) // 256) * ((K + 255) // 256))))
+    ws2 = torch.empty(splits * N * K, device=dev)
+    run(f'weight gradient {lab} (wgrad_tn, {splits} row splits) N={N} K={K}', 'clkprobe_wgrad',
+        lambda: L.check(lib.se_wgrad_tn_bf16(L.ptr(dY), N, L.ptr(X), K, M, N, K, splits, L.ptr(dW), 0, L.ptr(ws2), ws2.numel() * 4, L.stream()), 'wtn'), 2.0 * M * N * K)
