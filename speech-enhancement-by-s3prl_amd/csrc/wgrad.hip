@@ -150,6 +150,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   if (nt > 1) SEW_ISSUE(1, 1);
   if (nt > 2) SEW_ISSUE(2, 2);
   constexpr int kRing = STAG ? 5 : kWStages;
+  constexpr bool PIPE = STAG == 2;      // STAG 2: the staggered form with the refill in front of the reads and counted LDS waits
   const bool late = STAG && wave >= 4;
   if (STAG) {
     // tile 0 certified for everybody (the late half reads it before its first in-loop barrier)
@@ -177,43 +178,84 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     SEW_STAMP();
     const char* sb = smem + st * kWStage;
+#define SEW_READ(af_, bfr_, sb_, s_)                                                                            \
+    do {                                                                                                        \
+      _Pragma("unroll") for (int blk = 0; blk < 4; ++blk) {                                                     \
+        const int off = a_base + (blk >> 1) * kWPanel + (s_) * 2048;                                            \
+        const bf16x4 lo = SE_WTR((sb_) + off + toff[blk & 1][0]);                                               \
+        const bf16x4 hi = SE_WTR((sb_) + off + toff[blk & 1][1]);                                               \
+        af_[blk] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};                            \
+      }                                                                                                         \
+      _Pragma("unroll") for (int blk = 0; blk < 2; ++blk) {                                                     \
+        const bf16x4 lo = SE_WTR((sb_) + b_base + (s_) * 2048 + toff[blk][0]);                                  \
+        const bf16x4 hi = SE_WTR((sb_) + b_base + (s_) * 2048 + toff[blk][1]);                                  \
+        bfr_[blk] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};                           \
+      }                                                                                                         \
+    } while (0)
+#define SEW_MMA(af_, bfr_)                                                                                      \
+    do {                                                                                                        \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                             \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                           \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af_[i], bfr_[j], acc[i][j], 0, 0, 0);             \
+    } while (0)
+#define SEW_REFILL()                                                                                            \
+    do {                                                                                                        \
+      /* refill: tile t + 3 into the slot of stage t - 1 (STAG: t - 2), free since the last barrier this wave passed.  Issued behind the sub-step's \
+         fragment reads: every global_load_lds stalls the issuing wave ~110 clk, which overlaps the LDS pipe serving those reads */ \
+      __builtin_amdgcn_sched_barrier(0);                                                                        \
+      if (t + 3 < nt) { int sn = st + 3; if (sn >= kRing) sn -= kRing; SEW_ISSUE(t + 3, sn); }                  \
+      __builtin_amdgcn_sched_barrier(0);                                                                        \
+      SEW_STAMP();                                                                                              \
+    } while (0)
+#define SEW_LATE_BARRIER()                                                                                      \
+    do {                                                                                                        \
+      if (STAG && late) {                                                                                       \
+        /* late half, barrier t in mid-step: its pieces of tile t + 1 landed (issued so far: .. t + 3) */       \
+        __builtin_amdgcn_sched_barrier(0);                                                                      \
+        const int after = (t + 2 < nt ? 1 : 0) + (t + 3 < nt ? 1 : 0);                                          \
+        if (after == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                        \
+        else if (after == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                   \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                   \
+        __builtin_amdgcn_s_barrier();                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                                      \
+      }                                                                                                         \
+    } while (0)
+    if constexpr (!PIPE) {
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      bf16x8 af[4], bfr[2];
-#pragma unroll
-      for (int blk = 0; blk < 4; ++blk) {
-        const int off = a_base + (blk >> 1) * kWPanel + s * 2048;
-        const bf16x4 lo = SE_WTR(sb + off + toff[blk & 1][0]);
-        const bf16x4 hi = SE_WTR(sb + off + toff[blk & 1][1]);
-        af[blk] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      for (int s = 0; s < 2; ++s) {
+        bf16x8 af[4], bfr[2];
+        SEW_READ(af, bfr, sb, s);
+        if (s == 0) SEW_REFILL();
+        SEW_MMA(af, bfr);
+        if (s == 0) SEW_LATE_BARRIER();
       }
+    } else {
+      // STAG 2 (A/B, not the default: a tie with STAG 1, FFN 174-181 / 158-161 us against 175-178 / 163-168, fine-tune step 19.75 against 19.52 ms):
+      // the refill is issued IN FRONT of the sub-step's reads and the X fragments are requested first, so nothing stands between the reads and the
+      // MFMAs and the compiler can count the LDS returns (lgkmcnt(n)) instead of draining them: the first MFMA pair starts when 4 of 6 fragments are in.
+      // Measured against two other orders on one box (profiles/r04_wgrad_stag2.txt): BOTH sub-steps' 24 reads at the step top, one wait per 16 MFMAs:
+      // 12 % SLOWER (FFN 195 / 177 us against 170 / 158) -- the wait gets longer, not rarer; the next sub-step's reads under this one's MFMAs (a software
+      // pipeline) does not survive the compiler: its s_waitcnt lgkmcnt(0) before a block's first MFMA also waits for reads issued just before it, and
+      // pinning reads between MFMAs with sched_barrier / sched_group_barrier sent the register allocator to 256 registers + 163 spills.
 #pragma unroll
-      for (int blk = 0; blk < 2; ++blk) {
-        const bf16x4 lo = SE_WTR(sb + b_base + s * 2048 + toff[blk][0]);
-        const bf16x4 hi = SE_WTR(sb + b_base + s * 2048 + toff[blk][1]);
-        bfr[blk] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-      }
-      if (s == 0) {
-        // refill: tile t + 3 into the slot of stage t - 1 (STAG: t - 2), free since the last barrier this wave passed.  Issued here, behind the first
-        // step's fragment reads: every global_load_lds stalls the issuing wave ~110 clk, which now overlaps the LDS pipe serving those reads
-        __builtin_amdgcn_sched_barrier(0);
-        if (t + 3 < nt) { int sn = st + 3; if (sn >= kRing) sn -= kRing; SEW_ISSUE(t + 3, sn); }
-        __builtin_amdgcn_sched_barrier(0);
-        SEW_STAMP();
-      }
+      for (int s = 0; s < 2; ++s) {
+        if (s == 0) SEW_REFILL();
+        bf16x8 af[4], bfr[2];
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+        for (int blk = 0; blk < 2; ++blk) {
+          const bf16x4 lo = SE_WTR(sb + b_base + s * 2048 + toff[blk][0]);
+          const bf16x4 hi = SE_WTR(sb + b_base + s * 2048 + toff[blk][1]);
+          bfr[blk] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-      if (STAG && late && s == 0) {
-        // late half, barrier t in mid-step: its pieces of tile t + 1 landed (issued so far: .. t + 3)
-        __builtin_amdgcn_sched_barrier(0);
-        const int after = (t + 2 < nt ? 1 : 0) + (t + 3 < nt ? 1 : 0);
-        if (after == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (after == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
+        for (int blk = 0; blk < 4; ++blk) {
+          const int off = a_base + (blk >> 1) * kWPanel + s * 2048;
+          const bf16x4 lo = SE_WTR(sb + off + toff[blk & 1][0]);
+          const bf16x4 hi = SE_WTR(sb + off + toff[blk & 1][1]);
+          af[blk] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+        SEW_MMA(af, bfr);
+        if (s == 0) SEW_LATE_BARRIER();
       }
     }
     st = st + 1 == kRing ? 0 : st + 1;
@@ -221,6 +263,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   SE_CLKPROBE_END(clkprobe_wgrad);
   SEW_STAMP();
 #undef SEW_ISSUE
+#undef SEW_READ
+#undef SEW_MMA
+#undef SEW_REFILL
+#undef SEW_LATE_BARRIER
 
   // ---- epilogue: acc[i][j][r] = dW[n0 + 128 wn + 32 i + (r&3) + 8 (r>>2) + 4 hh][k0 + 64 wk + 32 j + l31]
   float* out = partials + (size_t)split * N * K;
@@ -251,10 +297,12 @@ __global__ __launch_bounds__(256) void wgrad_slab_reduce_kernel(const float* __r
 
 }  // namespace se
 
-static bool wgrad_stag() {
+static int wgrad_stag() {
   static int v = -1;
-  if (v < 0) { const char* e = getenv("SE_AMD_WGRAD_STAG"); v = e ? atoi(e) : 1; }      // A/B: 0 = every wave's barrier at the step top (four-stage ring)
-  return v != 0;
+  // A/B: 0 = every wave's barrier at the step top (four-stage ring), 1 = waves 4-7 half a step behind (five stages), 2 = 1 with the
+  // refill in front of the sub-step's reads, X fragments first (counted lgkmcnt waits)
+  if (v < 0) { const char* e = getenv("SE_AMD_WGRAD_STAG"); v = e ? atoi(e) : 1; if (v < 0 || v > 2) v = 1; }
+  return v;
 }
 
 // dW[N,K] (+)= dY[M,N]^T . X[M,K]; dY / X row-major bf16 (ldy, ldx in elements, multiples of 8; N, K multiples of 8);
@@ -272,6 +320,7 @@ extern "C" int se_wgrad_tn_bf16(const uint16_t* dY, int ldy, const uint16_t* X, 
   if (!attr_set) {
     SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::wgrad_tn_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, se::kWLds));
     SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::wgrad_tn_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, se::kWLdsStag));
+    SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::wgrad_tn_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, se::kWLdsStag));
     attr_set = true;
   }
   const int tiles_n = (N + se::kWN - 1) / se::kWN, tiles_k = (K + se::kWK - 1) / se::kWK;
@@ -291,7 +340,9 @@ extern "C" int se_wgrad_tn_bf16(const uint16_t* dY, int ldy, const uint16_t* X, 
   }
   {
     se::ProfScope prof(se::kProfGemm, 2.0 * M * (double)N * K, st);
-    if (wgrad_stag()) hipLaunchKernelGGL(se::wgrad_tn_kernel<1>, dim3(work), dim3(512), se::kWLdsStag, st, dY, ldy, X, ldx, M, N, K, m_per_split, tiles_k, tiles,
+    if (wgrad_stag() == 2) hipLaunchKernelGGL(se::wgrad_tn_kernel<2>, dim3(work), dim3(512), se::kWLdsStag, st, dY, ldy, X, ldx, M, N, K, m_per_split, tiles_k,
+                                              tiles, work, partials, stamps);
+    else if (wgrad_stag()) hipLaunchKernelGGL(se::wgrad_tn_kernel<1>, dim3(work), dim3(512), se::kWLdsStag, st, dY, ldy, X, ldx, M, N, K, m_per_split, tiles_k, tiles,
                                          work, partials, stamps);
     else hipLaunchKernelGGL(se::wgrad_tn_kernel<0>, dim3(work), dim3(512), se::kWLds, st, dY, ldy, X, ldx, M, N, K, m_per_split, tiles_k, tiles, work,
                             partials, stamps);
@@ -322,12 +373,15 @@ extern "C" int se_wgrad_tn_slabs_bf16(const uint16_t* dY, int ldy, const uint16_
   if (!attr_set) {
     SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::wgrad_tn_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, se::kWLds));
     SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::wgrad_tn_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, se::kWLdsStag));
+    SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::wgrad_tn_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, se::kWLdsStag));
     attr_set = true;
   }
   const int tiles_n = (N + se::kWN - 1) / se::kWN, tiles_k = (K + se::kWK - 1) / se::kWK;
   const int tiles = tiles_n * tiles_k, work = tiles * groups;
   se::ProfScope prof(se::kProfGemm, 2.0 * M * (double)N * K, st);
-  if (wgrad_stag()) hipLaunchKernelGGL(se::wgrad_tn_kernel<1>, dim3(work), dim3(512), se::kWLdsStag, st, dY, ldy, X, ldx, M, N, K, rows_per_slab, tiles_k, tiles,
+  if (wgrad_stag() == 2) hipLaunchKernelGGL(se::wgrad_tn_kernel<2>, dim3(work), dim3(512), se::kWLdsStag, st, dY, ldy, X, ldx, M, N, K, rows_per_slab, tiles_k, tiles,
+                                       work, slabs, (unsigned long long*)nullptr);
+  else if (wgrad_stag()) hipLaunchKernelGGL(se::wgrad_tn_kernel<1>, dim3(work), dim3(512), se::kWLdsStag, st, dY, ldy, X, ldx, M, N, K, rows_per_slab, tiles_k, tiles,
                                        work, slabs, (unsigned long long*)nullptr);
   else hipLaunchKernelGGL(se::wgrad_tn_kernel<0>, dim3(work), dim3(512), se::kWLds, st, dY, ldy, X, ldx, M, N, K, rows_per_slab, tiles_k, tiles, work,
                           slabs, (unsigned long long*)nullptr);
