@@ -20,6 +20,18 @@
 
 namespace se {
 
+// 4-B-per-lane LDS-DMA by inline asm (M0 = the wave-uniform LDS destination; lane l lands at +4 l).  NOT __builtin_amdgcn_global_load_lds: through the
+// builtin the compiler orders every later LDS read behind the DMA with s_waitcnt vmcnt(0), and __syncthreads() carries a vmcnt(0) of its own -- both
+// kernels below waited out the full latency of the piece they had just issued, once per time step (found in round 4 with tools/isa_wait_lint.py after
+// the same pattern in wgrad.hip).  The step barrier is therefore SE_L_BAR: LDS writes drained (lgkmcnt), global stores and DMA left in flight.
+#define SE_L_DMA4(gptr_, lds_u32_)                                                                                          \
+  do {                                                                                                                      \
+    uint32_t keep_;                                                                                                         \
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"         \
+                 : "=&s"(keep_) : "v"(gptr_), "s"(lds_u32_) : "memory");                                                    \
+  } while (0)
+#define SE_L_BAR() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
 constexpr int kLH = 256, kLG = 1024;
 constexpr int kLFrag = 64;                                               // A-fragments per lane
 constexpr int kLRegF = 46, kLRegB = 47;                                  // of them in registers (forward / backward); the rest in LDS
@@ -74,12 +86,13 @@ __global__ __launch_bounds__(kLThreads) __attribute__((amdgpu_waves_per_eu(2, 2)
   typedef const __attribute__((address_space(1))) void* glbp_t;
   const size_t seq = ((size_t)dir * B + b) * T;
   const float* xrow0 = xproj + seq * kLG + 128 * wave + lane;
+  const uint32_t xring_u = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(ldsp_t)xring + (uint32_t)wave * 512u);
 #define SE_L_DMA(step)                                                                                                     \
   do {                                                                                                                      \
     const int t_ = reverse ? T - 1 - (step) : (step);                                                                       \
-    char* d_ = reinterpret_cast<char*>(xring) + ((step) % 3) * 4096 + wave * 512;                                           \
-    __builtin_amdgcn_global_load_lds((glbp_t)(xrow0 + (size_t)t_ * kLG), (ldsp_t)(d_), 4, 0, 0);                            \
-    __builtin_amdgcn_global_load_lds((glbp_t)(xrow0 + (size_t)t_ * kLG + 64), (ldsp_t)(d_ + 256), 4, 0, 0);                 \
+    const uint32_t d_ = xring_u + (uint32_t)(((step) % 3) * 4096);                                                          \
+    SE_L_DMA4(xrow0 + (size_t)t_ * kLG, d_);                                                                                \
+    SE_L_DMA4(xrow0 + (size_t)t_ * kLG + 64, d_ + 256u);                                                                    \
   } while (0)
 
   bf16x8 wreg[kLReg];
@@ -156,7 +169,7 @@ __global__ __launch_bounds__(kLThreads) __attribute__((amdgpu_waves_per_eu(2, 2)
       hs[((s + 1) & 1) * kLH + u] = hb16;
       h_out[((size_t)b * T + t) * (ndir * kLH) + dir * kLH + u] = hb16;
     }
-    __syncthreads();
+    SE_L_BAR();            // LDS writes of this step visible; stores and the DMA just issued stay in flight
   }
 }
 
@@ -198,16 +211,17 @@ __global__ __launch_bounds__(kLThreads) __attribute__((amdgpu_waves_per_eu(2, 2)
   const float* g_src = gates + seq * kLG + 128 * wave + lane;
   const float* c_src = c_saved + seq * kLH + 64 * (wave & 3) + lane;
   const float* d_src = dh_out + (size_t)b * T * ld_dh + dir * kLH + 64 * (wave & 3) + lane;
+  const uint32_t ring_u = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(ldsp_t)ring);
 #define SE_LB_DMA(step)                                                                                                     \
   do {                                                                                                                      \
     const int t_ = reverse ? (step) : T - 1 - (step);                                                                       \
-    char* r_ = ring + ((step) % 3) * 6144;                                                                                  \
-    __builtin_amdgcn_global_load_lds((glbp_t)(g_src + (size_t)t_ * kLG), (ldsp_t)(r_ + wave * 512), 4, 0, 0);                \
-    __builtin_amdgcn_global_load_lds((glbp_t)(g_src + (size_t)t_ * kLG + 64), (ldsp_t)(r_ + wave * 512 + 256), 4, 0, 0);     \
+    const uint32_t r_ = ring_u + (uint32_t)(((step) % 3) * 6144);                                                           \
+    SE_L_DMA4(g_src + (size_t)t_ * kLG, r_ + (uint32_t)wave * 512u);                                                        \
+    SE_L_DMA4(g_src + (size_t)t_ * kLG + 64, r_ + (uint32_t)wave * 512u + 256u);                                            \
     const int sn_ = (step) + 1 < T ? (step) + 1 : (step);          /* the ring row of step s carries c of step s+1 = c_{t-1} */     \
     const int tn_ = reverse ? sn_ : T - 1 - sn_;                                                                            \
-    if (wave < 4) __builtin_amdgcn_global_load_lds((glbp_t)(c_src + (size_t)tn_ * kLH), (ldsp_t)(r_ + 4096 + wave * 256), 4, 0, 0); \
-    else __builtin_amdgcn_global_load_lds((glbp_t)(d_src + (size_t)t_ * ld_dh), (ldsp_t)(r_ + 5120 + (wave - 4) * 256), 4, 0, 0);  \
+    if (wave < 4) SE_L_DMA4(c_src + (size_t)tn_ * kLH, r_ + 4096u + (uint32_t)wave * 256u);                                 \
+    else SE_L_DMA4(d_src + (size_t)t_ * ld_dh, r_ + 5120u + (uint32_t)(wave - 4) * 256u);                                   \
   } while (0)
 
   bf16x8 wreg[kLReg];
@@ -264,7 +278,7 @@ __global__ __launch_bounds__(kLThreads) __attribute__((amdgpu_waves_per_eu(2, 2)
       uint16_t* op = dgates_out + (seq + t) * kLG + u;
       op[0] = bi; op[kLH] = bff; op[2 * kLH] = bg; op[3 * kLH] = bo;
     }
-    __syncthreads();
+    SE_L_BAR();            // LDS writes of this step visible; stores and the DMA just issued stay in flight
     // dh_{t-1}[k] = sum_j W_hh[j][k] dgates[j]: two partial accumulators per row tile (same accumulator every fourth MFMA)
     f32x4 acc[2][2];
     const uint16_t* dv = dcur + 8 * lg;
