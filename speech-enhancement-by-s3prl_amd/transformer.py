@@ -21,6 +21,8 @@ import warnings
 import numpy as np
 import weakref
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -531,6 +533,17 @@ class _Engine:
             _lib.check(lib.se_gemm_bf16(_lib.ptr(a3), K3, _lib.ptr(w3), K3, _lib.ptr(bias), _lib.ptr(residual), M, N, K3, int(act), None, _lib.ptr(out), N,
                                         _lib.stream()), 'se_gemm_bf16')
 
+        # row-complete projection + residual + LayerNorm in ONE launch (csrc/gemm4.hip: the LayerNorm runs in fp32 on the accumulators), then the split of
+        # its fp32 rows: for the attention-output projection (N = H = 768, K = 3 H) the 256 x 256-tile GEMM fills its second round of tiles to 48 %
+        # and ran at 0.4 PFLOP/s; SE_AMD_X3_ROWLN (A/B): bit 0 = attention output, bit 1 = FFN output
+        rowln = int(os.environ.get('SE_AMD_X3_ROWLN', '3')) if H == 768 else 0
+
+        def gemm_ln3(a3, K3, w3, bias, residual, ln, dst):
+            _lib.check(lib.se_gemm_res_ln_bf16(_lib.ptr(a3), K3, _lib.ptr(w3), K3, _lib.ptr(bias), _lib.ptr(residual), _lib.ptr(ln.weight.detach()),
+                                               _lib.ptr(ln.bias.detach()), float(ln.variance_epsilon), M, H, K3, _lib.ptr(dst), None, _lib.stream()),
+                       'se_gemm_res_ln_bf16')
+            _lib.check(lib.se_split3_bf16(_lib.ptr(dst), H, M, H, H, 0, _lib.ptr(x3), _lib.stream()), 'se_split3_bf16')
+
         ln3(x, ir.LayerNorm, xa)
         x = xa
         for layer in model.encoder.layer:
@@ -541,16 +554,24 @@ class _Engine:
             # flash attention on two-term splits of Q, K, V and P (csrc/mhsa_x3.hip): no (B, heads, T, T) score tensor; the context leaves split
             _lib.check(lib.se_mhsa_fwd_x3_split_f32(_lib.ptr(qkv), _lib.ptr(lengths), B, T, heads, _lib.ptr(c3), H, _lib.stream()), 'se_mhsa_fwd_x3_split_f32')
             wo, _ = self._w3(att.output.dense.weight)
-            gemm3(c3, 3 * H, wo, w(att.output.dense.bias), H, residual=x, out=a)
-            x = xb if x is xa else xa
-            ln3(a, att.output.LayerNorm, x)
+            xn = xb if x is xa else xa
+            if rowln & 1:
+                gemm_ln3(c3, 3 * H, wo, w(att.output.dense.bias), x, att.output.LayerNorm, xn)
+            else:
+                gemm3(c3, 3 * H, wo, w(att.output.dense.bias), H, residual=x, out=a)
+                ln3(a, att.output.LayerNorm, xn)
+            x = xn
             w1, _ = self._w3(layer.intermediate.dense.weight)
             _lib.check(lib.se_gemm_x3out_bf16(_lib.ptr(x3), 3 * H, _lib.ptr(w1), 3 * H, _lib.ptr(w(layer.intermediate.dense.bias)), M, I, 3 * H,
                                               _lib.SE_ACT['GELU'], _lib.ptr(h3), I, _lib.stream()), 'se_gemm_x3out_bf16')
             w2, _ = self._w3(layer.output.dense.weight)
-            gemm3(h3, 3 * I, w2, w(layer.output.dense.bias), H, residual=x, out=a)
-            x = xb if x is xa else xa
-            ln3(a, layer.output.LayerNorm, x)
+            xn = xb if x is xa else xa
+            if rowln & 2:
+                gemm_ln3(h3, 3 * I, w2, w(layer.output.dense.bias), x, layer.output.LayerNorm, xn)
+            else:
+                gemm3(h3, 3 * I, w2, w(layer.output.dense.bias), H, residual=x, out=a)
+                ln3(a, layer.output.LayerNorm, xn)
+            x = xn
         return x.view(B, T, H)
 
     def _encode_x3_unchained(self, model, x, ir, lengths, B, T, H, heads, I, M):
