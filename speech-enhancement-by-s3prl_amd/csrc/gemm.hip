@@ -198,6 +198,8 @@ extern "C" int se_gemm6_launch(const uint16_t* A, int lda, const uint16_t* W, in
                                int M, int N, int K, int act, uint16_t* out_bf16, float* out_f32, int ldc, int vec_ok, void* stream);
 extern "C" int se_gemm5_launch(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias, const float* residual_f32,
                                int M, int N, int K, int act, uint16_t* out_bf16, float* out_f32, int ldc, int vec_ok, void* stream);
+extern "C" int se_gemm7_plain_launch(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias, const float* residual_f32, int M, int K,
+                                     uint16_t* out_bf16, float* out_f32, void* stream);      // gemm4.hip
 static int g_gemm_variant = -1;   // -1: read SE_AMD_GEMM once (1 = register-staged 128x128 kernel of this file, 2 = gemm2.hip lockstep, 3 = gemm2.hip ping-pong, 4 = gemm2.hip 128x128 x 2 workgroups / CU, 5 = gemm3.hip 256x256 [default])
 
 extern "C" int se_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias,
@@ -233,6 +235,16 @@ extern "C" int se_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, int l
     if (M <= small_m) return se_gemm2_launch(A, lda, W, ldw, bias, residual_f32, M, N, K, act, out_bf16, out_f32, ldc, vec_ok, 4, stream);
     // round 4: N = 768 outputs with a long reduction (the training path's FFN2 forward and FFN1 input gradient, K = 3072: 190 vs 205 us) also
     // run faster on the 256 x 256 x 64 kernel in spite of its 1.48-round tile count; at K = 768 the 256 x 128 ping-pong kernel keeps its lead (66 vs 70 us)
+    // round 4 (later), A/B only: SE_AMD_GEMM7_PLAIN=1 sends N = 768 with K >= 1536 to the row-complete kernel without its LayerNorm (gemm4.hip: 251 tiles
+    // of 128 x 768 = ONE round, where 256 x 256 tiles make 1.48).  Measured on one box, interleaved (profiles/r04_gemm7_plain.txt): the fine-tune step
+    // 19.55 / 19.66 ms against 19.44 / 19.48 -- every CU streams the whole weight matrix and all of them write their fp32 rows at the same moment, which
+    // costs what the fuller round wins.  Off.
+    static int plain7 = -1;
+    if (plain7 < 0) { const char* e = getenv("SE_AMD_GEMM7_PLAIN"); plain7 = e ? atoi(e) : 0; }
+    if (plain7 && N == 768 && ldc == 768 && K >= 1536 && act == SE_ACT_IDENTITY && vec_ok) {
+      const int rc7 = se_gemm7_plain_launch(A, lda, W, ldw, bias, residual_f32, M, K, out_bf16, out_f32, stream);
+      if (rc7 <= 0) return rc7;
+    }
     if (use6 && (N >= min_n6 || (N >= 768 && K >= 1536))) {
       const int rc6 = se_gemm6_launch(A, lda, W, ldw, bias, residual_f32, M, N, K, act, out_bf16, out_f32, ldc, vec_ok, stream);
       if (rc6 <= 0) return rc6;

@@ -100,7 +100,7 @@ __device__ __forceinline__ uint32_t enc24_lo4(float y0, float y1, float y2, floa
 #endif
 
 // acc[i][t] <- bias (+ residual): fp32 rows, or the 24-bit (bf16 hi row-major + int8 lo tile-major) stream, or a (T, 768) table indexed row % res_mod
-template <int GELU, int RIN>
+template <int GELU, int RIN, int LN = 1>
 __device__ __forceinline__ void acc_init4(f32x4 (&acc)[4][12], const float* __restrict__ bias, const float* __restrict__ residual,
                                           const uint8_t* __restrict__ res_lo, int M, int m0, int id, int wave, int wr, int lane, int col0, int res_mod) {
   const int mrow = lane & 15;
@@ -113,7 +113,7 @@ __device__ __forceinline__ void acc_init4(f32x4 (&acc)[4][12], const float* __re
     const float* rp = residual + (size_t)(res_mod > 0 ? gm % res_mod : gm) * k4N + col0;      // res_mod = T: a (T, 768) positional table as the residual
 #pragma unroll
     for (int t = 0; t < 12; ++t) {
-      if (GELU) {
+      if (GELU || (!LN && !residual)) {      // LN = 0: the plain projection; its residual is optional
         acc[i][t] = (f32x4){bb[t].x, bb[t].y, bb[t].z, bb[t].w};
       } else if (RIN) {
         const uint2 h4 = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(residual) + (size_t)gm * k4N + col0 + 16 * t);
@@ -130,7 +130,7 @@ __device__ __forceinline__ void acc_init4(f32x4 (&acc)[4][12], const float* __re
 
 // (optional gelu) + LayerNorm on the accumulators (which hold A.W^T + bias + residual) + the stores.  Called with every wave past its last
 // ring access (the caller's __syncthreads): the ring is dead, its first 6 KiB take ln_w / ln_b, `red_off` + 4 KiB the row partial sums.
-template <int GELU, int ROUT>
+template <int GELU, int ROUT, int LN = 1>
 __device__ __forceinline__ void ln_epilogue4(f32x4 (&acc)[4][12], char* smem, int red_off, const float* __restrict__ ln_w, const float* __restrict__ ln_b,
                                              float eps, int M, int m0, int id, int wave, int wr, int wc, int lane, float* __restrict__ out_f32,
                                              uint16_t* __restrict__ out_bf16, uint8_t* __restrict__ out_lo) {
@@ -146,50 +146,52 @@ __device__ __forceinline__ void ln_epilogue4(f32x4 (&acc)[4][12], char* smem, in
         acc[i][t] = (f32x4){ga.x, ga.y, gb.x, gb.y};
       }
   }
-  // ---- epilogue: LayerNorm on the accumulators (which already hold A.W^T + bias + residual)
+  // ---- epilogue: LayerNorm on the accumulators (which already hold A.W^T + bias + residual); LN = 0: the accumulators are the result
   float* colv = reinterpret_cast<float*>(smem);             // [2][768]: ln_w, ln_b staged in the dead ring
-  for (int c = tid; c < k4N; c += k4Threads) {
-    colv[c] = ln_w[c];
-    colv[k4N + c] = ln_b[c];
-  }
-  float* red = reinterpret_cast<float*>(smem + red_off);   // [pass][wr][wc][64]
-  // pass 1: row means
   float mean[4], rstd[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    float s = 0.f;
-#pragma unroll
-    for (int t = 0; t < 12; ++t) s += (acc[i][t][0] + acc[i][t][1]) + (acc[i][t][2] + acc[i][t][3]);
-    s += __shfl_xor(s, 16);
-    s += __shfl_xor(s, 32);
-    if (cq == 0) red[(wr * 4 + wc) * 64 + i * 16 + mrow] = s;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const float* rp = red + wr * 256 + i * 16 + mrow;
-    mean[i] = (rp[0] + rp[64] + rp[128] + rp[192]) * (1.0f / k4N);
-  }
-  // pass 2: variance around the mean (exact two-pass, as the stand-alone LayerNorm kernel)
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    float q = 0.f;
-#pragma unroll
-    for (int t = 0; t < 12; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float d = acc[i][t][r] - mean[i];
-        q = fmaf(d, d, q);
-      }
-    q += __shfl_xor(q, 16);
-    q += __shfl_xor(q, 32);
-    if (cq == 0) red[512 + (wr * 4 + wc) * 64 + i * 16 + mrow] = q;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const float* rp = red + 512 + wr * 256 + i * 16 + mrow;
-    rstd[i] = 1.0f / sqrtf((rp[0] + rp[64] + rp[128] + rp[192]) * (1.0f / k4N) + eps);
+  if constexpr (LN) {
+    for (int c = tid; c < k4N; c += k4Threads) {
+      colv[c] = ln_w[c];
+      colv[k4N + c] = ln_b[c];
+    }
+    float* red = reinterpret_cast<float*>(smem + red_off);   // [pass][wr][wc][64]
+    // pass 1: row means
+  #pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float s = 0.f;
+  #pragma unroll
+      for (int t = 0; t < 12; ++t) s += (acc[i][t][0] + acc[i][t][1]) + (acc[i][t][2] + acc[i][t][3]);
+      s += __shfl_xor(s, 16);
+      s += __shfl_xor(s, 32);
+      if (cq == 0) red[(wr * 4 + wc) * 64 + i * 16 + mrow] = s;
+    }
+    __syncthreads();
+  #pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float* rp = red + wr * 256 + i * 16 + mrow;
+      mean[i] = (rp[0] + rp[64] + rp[128] + rp[192]) * (1.0f / k4N);
+    }
+    // pass 2: variance around the mean (exact two-pass, as the stand-alone LayerNorm kernel)
+  #pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float q = 0.f;
+  #pragma unroll
+      for (int t = 0; t < 12; ++t)
+  #pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float d = acc[i][t][r] - mean[i];
+          q = fmaf(d, d, q);
+        }
+      q += __shfl_xor(q, 16);
+      q += __shfl_xor(q, 32);
+      if (cq == 0) red[512 + (wr * 4 + wc) * 64 + i * 16 + mrow] = q;
+    }
+    __syncthreads();
+  #pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float* rp = red + 512 + wr * 256 + i * 16 + mrow;
+      rstd[i] = 1.0f / sqrtf((rp[0] + rp[64] + rp[128] + rp[192]) * (1.0f / k4N) + eps);
+    }
   }
   // normalise + store (stores only in this loop; the per-column vectors come from LDS)
   const bool interior = m0 + k4BM <= M;
@@ -201,17 +203,20 @@ __device__ __forceinline__ void ln_epilogue4(f32x4 (&acc)[4][12], char* smem, in
     const size_t o = (size_t)min(gm, M - 1) * k4N + col0;
     const size_t orow8 = (size_t)min(gm, M - 1) * k4N + wc * 192 + 4 * (cq & ~1);      // first of this lane's 8 consecutive bf16 columns
     uint2 pk_prev = make_uint2(0u, 0u);
-    const float nmr = -mean[i] * rstd[i];
+    const float nmr = LN ? -mean[i] * rstd[i] : 0.f;
 #pragma unroll
     for (int t = 0; t < 12; ++t) {
       if ((t & 3) == 0) __builtin_amdgcn_sched_barrier(0);
-      const float4 lw = *reinterpret_cast<const float4*>(colv + col0 + 16 * t);
-      const float4 lb = *reinterpret_cast<const float4*>(colv + k4N + col0 + 16 * t);
-      // xhat = acc * rstd - mean * rstd as ONE fma (the per-row product is formed once), then lw * xhat + lb: two instructions per element
-      const float y0 = fmaf(lw.x, fmaf(acc[i][t][0], rstd[i], nmr), lb.x);
-      const float y1 = fmaf(lw.y, fmaf(acc[i][t][1], rstd[i], nmr), lb.y);
-      const float y2 = fmaf(lw.z, fmaf(acc[i][t][2], rstd[i], nmr), lb.z);
-      const float y3 = fmaf(lw.w, fmaf(acc[i][t][3], rstd[i], nmr), lb.w);
+      float y0 = acc[i][t][0], y1 = acc[i][t][1], y2 = acc[i][t][2], y3 = acc[i][t][3];
+      if constexpr (LN) {
+        const float4 lw = *reinterpret_cast<const float4*>(colv + col0 + 16 * t);
+        const float4 lb = *reinterpret_cast<const float4*>(colv + k4N + col0 + 16 * t);
+        // xhat = acc * rstd - mean * rstd as ONE fma (the per-row product is formed once), then lw * xhat + lb: two instructions per element
+        y0 = fmaf(lw.x, fmaf(y0, rstd[i], nmr), lb.x);
+        y1 = fmaf(lw.y, fmaf(y1, rstd[i], nmr), lb.y);
+        y2 = fmaf(lw.z, fmaf(y2, rstd[i], nmr), lb.z);
+        y3 = fmaf(lw.w, fmaf(y3, rstd[i], nmr), lb.w);
+      }
       if (!ROUT && ok && out_f32) *reinterpret_cast<float4*>(out_f32 + o + 16 * t) = make_float4(y0, y1, y2, y3);
       if (out_bf16) {
         // 16-B bf16 stores (as gemm3.hip): lanes l, l ^ 16 trade 4-column pieces of the MFMA tile pair (t - 1, t), so a lane owns 8
@@ -426,7 +431,7 @@ __global__ __launch_bounds__(k4Threads) __attribute__((amdgpu_waves_per_eu(2, 2)
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int k7WSlot = 256 * 128, k7ASlot = 128 * 128, k7ABase = 4 * k7WSlot, k7Lds = 4 * k7WSlot + 2 * k7ASlot;     // 32 KiB, 16 KiB, 160 KiB
 
-template <int GELU, int RIN, int ROUT, int INM = 0>
+template <int GELU, int RIN, int ROUT, int INM = 0, int LN = 1>
 __global__ __launch_bounds__(k4Threads) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm7_res_ln_kernel(
     const uint16_t* __restrict__ A, int lda, const uint16_t* __restrict__ W, int ldw, const float* __restrict__ bias,
     const float* __restrict__ residual, const float* __restrict__ ln_w, const float* __restrict__ ln_b, float eps, int M, int K,
@@ -492,7 +497,7 @@ __global__ __launch_bounds__(k4Threads) __attribute__((amdgpu_waves_per_eu(2, 2)
   const int cq = lane >> 4;
   const int col0 = wc * 192 + 4 * cq;
   f32x4 acc[4][12];
-  acc_init4<GELU, RIN>(acc, bias, residual, res_lo, M, m0, id, wave, wr, lane, col0, res_mod);
+  acc_init4<GELU, RIN, LN>(acc, bias, residual, res_lo, M, m0, id, wave, wr, lane, col0, res_mod);
   // every accumulator is COMPLETE here (opaque uses): with the integer codec the compiler otherwise left residual loads pending into the K loop
   // and protected the hand-issued LDS-DMA operands with s_waitcnt vmcnt(1) / vmcnt(0) INSIDE it -- which drains the DMA ring every K-tile
   // (K = 3072: 214 instead of 170 us per launch)
@@ -576,7 +581,7 @@ __global__ __launch_bounds__(k4Threads) __attribute__((amdgpu_waves_per_eu(2, 2)
   }
   if (!late) __builtin_amdgcn_s_barrier();                  // re-align the two groups
   __syncthreads();                                          // ring is dead: reuse it for the per-column vectors
-  ln_epilogue4<GELU, ROUT>(acc, smem, 8192, ln_w, ln_b, eps, M, m0, id, wave, wr, wc, lane, out_f32, out_bf16, out_lo);
+  ln_epilogue4<GELU, ROUT, LN>(acc, smem, 8192, ln_w, ln_b, eps, M, m0, id, wave, wr, wc, lane, out_f32, out_bf16, out_lo);
   SE_CLKPROBE_END(clkprobe_gemm7);
 #undef SE7_DMA1
 #undef SE7_DMA_W
@@ -671,6 +676,27 @@ static int gemm4_launch(const uint16_t* A, int lda, const uint16_t* W, int ldw, 
     default: SE4_LAUNCH(6, 1, 0, 0, 0); break;
   }
 #undef SE4_LAUNCH
+  SE_LAUNCH_CHECK();
+  return SE_OK;
+}
+
+// The row-complete kernel WITHOUT its LayerNorm (round 4): out = A[M,K] . W[768,K]^T (+ bias) (+ residual_f32) as fp32 and / or bf16 rows.  For N = 768
+// the 256 x 256-tile kernels run 378 tiles = a second round filled to 48 %; 251 row tiles of 128 x 768 are one full round.  Called by se_gemm_bf16
+// (csrc/gemm.hip) for the training path's FFN-output forward and the FFN1 / QKV input gradients (K = 3072 / 2304).  Returns 1 when the shape is not its own.
+extern "C" int se_gemm7_plain_launch(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias, const float* residual_f32, int M, int K,
+                                     uint16_t* out_bf16, float* out_f32, void* stream) {
+  if (!(K % 64 == 0 && K >= 128 && (size_t)M * lda < (1u << 31) && (size_t)se::k4N * ldw < (1u << 31))) return 1;
+  if ((((uintptr_t)A | (uintptr_t)W | (uintptr_t)residual_f32 | (uintptr_t)out_f32 | (uintptr_t)out_bf16 | (uintptr_t)bias) % 16) != 0) return 1;
+  static bool attr_set = false;
+  if (!attr_set) {
+    SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::gemm7_res_ln_kernel<0, 0, 0, 1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, se::k7Lds));
+    attr_set = true;
+  }
+  const int ntiles = (M + se::k4BM - 1) / se::k4BM;
+  hipStream_t st = se::as_stream(stream);
+  se::ProfScope prof(se::kProfGemm, 2.0 * M * (double)se::k4N * K, st);
+  hipLaunchKernelGGL((se::gemm7_res_ln_kernel<0, 0, 0, 1, 0>), dim3(ntiles), dim3(se::k4Threads), se::k7Lds, st, A, lda, W, ldw, bias, residual_f32,
+                     (const float*)nullptr, (const float*)nullptr, 0.f, M, K, out_f32, out_bf16, ntiles, 0, (const uint8_t*)nullptr, (uint8_t*)nullptr);
   SE_LAUNCH_CHECK();
   return SE_OK;
 }

@@ -57,6 +57,49 @@ def test_gemm_vs_torch(gpu, M, N, K):
     assert (o32.double() - refg).abs().max().item() < 3e-5 * refg.abs().max().item() + 1e-4
 
 
+@pytest.mark.parametrize('K', [1536, 2304, 3072])
+@pytest.mark.parametrize('M', [4100, 4224])
+def test_gemm_n768_row_complete_plain(gpu, M, K):
+    """the row-complete kernel without its LayerNorm (gemm4.hip: se_gemm7_plain_launch, an A/B path of se_gemm_bf16 for N = 768, K >= 1536 --
+    SE_AMD_GEMM7_PLAIN=1; measured a tie and off by default, so the test calls it directly): every operand combination (bias / residual present
+    or not, fp32 / bf16 / both outputs), a ragged last row tile (4100 = 32 x 128 + 4) and a full one; an exact-integer case catches layout slips."""
+    import ctypes
+    L = _lib()
+    lib = L.load()
+    fn = lib.se_gemm7_plain_launch
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+
+    def plain(A, W, bias=None, residual=None, out='f32'):
+        o32 = torch.empty(M, 768, device=gpu, dtype=torch.float32) if out in ('f32', 'both') else None
+        o16 = torch.empty(M, 768, device=gpu, dtype=torch.bfloat16) if out in ('bf16', 'both') else None
+        L.check(fn(L.ptr(A), K, L.ptr(W), K, L.ptr(bias), L.ptr(residual), M, K, L.ptr(o16), L.ptr(o32), L.stream()), 'se_gemm7_plain_launch')
+        return o32, o16
+
+    torch.manual_seed(M + K)
+    N = 768
+    A = torch.randn(M, K, device=gpu).bfloat16()
+    W = (torch.randn(N, K, device=gpu) * 0.05).bfloat16()
+    bias = torch.randn(N, device=gpu)
+    res = torch.randn(M, N, device=gpu)
+    base = A.float().double() @ W.float().double().T
+    for use_bias, use_res, out in [(True, True, 'f32'), (False, True, 'both'), (False, False, 'bf16'), (True, False, 'both'), (False, True, 'bf16')]:
+        ref = base + (bias.double() if use_bias else 0.0) + (res.double() if use_res else 0.0)
+        o32, o16 = plain(A, W, bias if use_bias else None, res if use_res else None, out)
+        scale = ref.abs().max().item()
+        if o32 is not None:
+            assert (o32.double() - ref).abs().max().item() < 2e-5 * scale + 1e-5 * math.sqrt(K)
+        if o16 is not None:
+            assert (o16.double() - ref).abs().max().item() < 8e-3 * scale
+    # exact: A rows are unit vectors (row m selects column m % K of W^T), W small integers
+    Ai = torch.zeros(M, K, device=gpu)
+    Ai[torch.arange(M, device=gpu), torch.arange(M, device=gpu) % K] = 1.0
+    Wi = ((torch.arange(N * K, device=gpu).reshape(N, K) * 7) % 61 - 30).float()
+    o32, _ = plain(Ai.bfloat16(), Wi.bfloat16())
+    assert torch.equal(o32, Wi.T[torch.arange(M, device=gpu) % K])
+
+
 def mhsa_ref(qkv, lengths, B, T, heads):
     H = heads * 64
     x = qkv.float().view(B, T, 3, heads, 64).permute(2, 0, 3, 1, 4).double()    # (3, B, h, T, 64)
