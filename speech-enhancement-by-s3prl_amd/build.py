@@ -66,13 +66,24 @@ def build(force=False, jobs=None, verbose=True):
         return LIB
     os.makedirs(OBJ, exist_ok=True)
     cc = _hipcc()
+    # a failed rebuild must not leave the PREVIOUS library behind as if it were this tree's (it travels to the GPU box with the snapshot, and a
+    # `build.py | tail` in a shell line hides the failure: round 4 measured two "A/B"s on a stale library that way): the stamp goes first, and
+    # the library with it if a compile or the link fails -- loading then fails loudly
+    for stale in (stamp,):
+        if os.path.exists(stale):
+            os.remove(stale)
+
+    def _fail(msg):
+        if os.path.exists(LIB):
+            os.remove(LIB)
+        raise RuntimeError(msg)
 
     def compile_one(src):
         obj = os.path.join(OBJ, os.path.basename(src)[:-4] + '.o')
         cmd = [cc] + FLAGS + FILE_FLAGS.get(os.path.basename(src), []) + ['-c', src, '-o', obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
-            raise RuntimeError('hipcc failed: ' + ' '.join(cmd) + '\n' + r.stdout + r.stderr)
+            _fail('hipcc failed: ' + ' '.join(cmd) + '\n' + r.stdout + r.stderr)
         return obj, r.stderr
 
     jobs = jobs or min(len(srcs), os.cpu_count() or 4)
@@ -85,7 +96,7 @@ def build(force=False, jobs=None, verbose=True):
     cmd = [cc, '-shared', '-fPIC', f'--offload-arch={ARCH}', '-o', LIB] + objs
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
-        raise RuntimeError('link failed: ' + ' '.join(cmd) + '\n' + r.stdout + r.stderr)
+        _fail('link failed: ' + ' '.join(cmd) + '\n' + r.stdout + r.stderr)
     with open(stamp, 'w') as f:
         f.write(dig)
     if verbose:

@@ -235,12 +235,12 @@ extern "C" int se_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, int l
     if (M <= small_m) return se_gemm2_launch(A, lda, W, ldw, bias, residual_f32, M, N, K, act, out_bf16, out_f32, ldc, vec_ok, 4, stream);
     // round 4: N = 768 outputs with a long reduction (the training path's FFN2 forward and FFN1 input gradient, K = 3072: 190 vs 205 us) also
     // run faster on the 256 x 256 x 64 kernel in spite of its 1.48-round tile count; at K = 768 the 256 x 128 ping-pong kernel keeps its lead (66 vs 70 us)
-    // round 4 (later), A/B only: SE_AMD_GEMM7_PLAIN=1 sends N = 768 with K >= 1536 to the row-complete kernel without its LayerNorm (gemm4.hip: 251 tiles
-    // of 128 x 768 = ONE round, where 256 x 256 tiles make 1.48).  Measured on one box, interleaved (profiles/r04_gemm7_plain.txt): the fine-tune step
-    // 19.55 / 19.66 ms against 19.44 / 19.48 -- every CU streams the whole weight matrix and all of them write their fp32 rows at the same moment, which
-    // costs what the fuller round wins.  Off.
+    // round 4 (later): N = 768 with K >= 1536 goes to the row-complete kernel without its LayerNorm (gemm4.hip: 251 tiles of 128 x 768 = ONE round,
+    // where 256 x 256 tiles make 1.48).  Same box, interleaved (profiles/r04_revalidate.txt): fine-tune step 18.59 / 18.70 -> 18.30 / 18.28 ms.
+    // SE_AMD_GEMM7_PLAIN=0 restores the 256 x 256 x 64 kernel.  (A first "A/B" of this switch read 19.55 against 19.44 ms -- both arms had run a stale
+    // library whose rebuild had failed behind a `| tail`; build.py now deletes the library when a rebuild fails.)
     static int plain7 = -1;
-    if (plain7 < 0) { const char* e = getenv("SE_AMD_GEMM7_PLAIN"); plain7 = e ? atoi(e) : 0; }
+    if (plain7 < 0) { const char* e = getenv("SE_AMD_GEMM7_PLAIN"); plain7 = e ? atoi(e) : 1; }
     if (plain7 && N == 768 && ldc == 768 && K >= 1536 && act == SE_ACT_IDENTITY && vec_ok) {
       const int rc7 = se_gemm7_plain_launch(A, lda, W, ldw, bias, residual_f32, M, K, out_bf16, out_f32, stream);
       if (rc7 <= 0) return rc7;

@@ -27,8 +27,9 @@ namespace se {
 #define SE_L_DMA4(gptr_, lds_u32_)                                                                                          \
   do {                                                                                                                      \
     uint32_t keep_;                                                                                                         \
+    const uint32_t l_ = __builtin_amdgcn_readfirstlane(lds_u32_);      /* (step % 3) is computed on the vector unit */             \
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"         \
-                 : "=&s"(keep_) : "v"(gptr_), "s"(lds_u32_) : "memory");                                                    \
+                 : "=&s"(keep_) : "v"(gptr_), "s"(l_) : "memory");                                                          \
   } while (0)
 #define SE_L_BAR() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
@@ -83,7 +84,6 @@ __global__ __launch_bounds__(kLThreads) __attribute__((amdgpu_waves_per_eu(2, 2)
   // xproj rows arrive by LDS-DMA three steps ahead (no VGPRs, no exposed HBM latency: as register prefetches one step ahead they
   // cost 0.4 us per step).  Wave w fetches floats 128 w .. 128 w + 127 of a row with two 256-B pieces.
   typedef __attribute__((address_space(3))) void* ldsp_t;
-  typedef const __attribute__((address_space(1))) void* glbp_t;
   const size_t seq = ((size_t)dir * B + b) * T;
   const float* xrow0 = xproj + seq * kLG + 128 * wave + lane;
   const uint32_t xring_u = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(ldsp_t)xring + (uint32_t)wave * 512u);
@@ -205,7 +205,6 @@ __global__ __launch_bounds__(kLThreads) __attribute__((amdgpu_waves_per_eu(2, 2)
   // on -- which is why a row carries c_{t-1} (c_t is the previous step's c_{t-1}, kept in a register)
   char* ring = smem + kLWBytes + 2 * kLG * 2;                              // [3][6144]
   typedef __attribute__((address_space(3))) void* ldsp_t;
-  typedef const __attribute__((address_space(1))) void* glbp_t;
   const size_t seq = ((size_t)dir * B + b) * T;
   // wave w: gate floats 128 w .. + 127 (two 256-B pieces) and one 256-B piece of c (waves 0-3) or dh (waves 4-7)
   const float* g_src = gates + seq * kLG + 128 * wave + lane;

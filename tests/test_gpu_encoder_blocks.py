@@ -60,8 +60,8 @@ def test_gemm_vs_torch(gpu, M, N, K):
 @pytest.mark.parametrize('K', [1536, 2304, 3072])
 @pytest.mark.parametrize('M', [4100, 4224])
 def test_gemm_n768_row_complete_plain(gpu, M, K):
-    """the row-complete kernel without its LayerNorm (gemm4.hip: se_gemm7_plain_launch, an A/B path of se_gemm_bf16 for N = 768, K >= 1536 --
-    SE_AMD_GEMM7_PLAIN=1; measured a tie and off by default, so the test calls it directly): every operand combination (bias / residual present
+    """the row-complete kernel without its LayerNorm (gemm4.hip: se_gemm7_plain_launch, se_gemm_bf16's path for N = 768, K >= 1536 past the
+    small-batch threshold; called directly so that SE_AMD_GEMM7_PLAIN cannot route around it): every operand combination (bias / residual present
     or not, fp32 / bf16 / both outputs), a ragged last row tile (4100 = 32 x 128 + 4) and a full one; an exact-integer case catches layout slips."""
     import ctypes
     L = _lib()
