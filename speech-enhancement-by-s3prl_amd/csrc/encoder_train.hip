@@ -17,6 +17,8 @@
 #include "bf16.h"
 #include "dropout.h"
 
+extern "C" int se_gemm6_dual_gelu_launch(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias, int M, int N, int K, uint16_t* out_pre,
+                                         uint16_t* out_act, int ldc, void* stream);      // gemm6.hip
 namespace se {
 
 // Training-forward LayerNorm with the BERT dropout sites around it (one wave per row, H = 256 NV):
@@ -288,8 +290,15 @@ extern "C" int se_encoder_fwd_train_bf16(const se_encoder* enc, const float* fea
       SE_TRY(se::launch_layernorm(a.pre1, nullptr, 1, y.aln_w, y.aln_b, M, H, eps, x_f32, a.x1_bf, st));
     }
     // B3 (the pre-activation is kept for gelu')
-    SE_TRY(se_gemm_bf16(a.x1_bf, H, y.ff1_w, H, y.ff1_b, nullptr, M, I, H, SE_ACT_IDENTITY, a.hpre, nullptr, I, stream));
-    SE_TRY(se_gelu_bf16(a.hpre, Mz * I, a.h, stream));
+    {
+      // pre-activation (kept for the backward pass) and its GELU from ONE launch when the shape is the persistent kernel's (gemm6.hip)
+      const int rc_dual = se_gemm6_dual_gelu_launch(a.x1_bf, H, y.ff1_w, H, y.ff1_b, M, I, H, a.hpre, a.h, I, stream);
+      if (rc_dual < 0) return rc_dual;
+      if (rc_dual > 0) {
+        SE_TRY(se_gemm_bf16(a.x1_bf, H, y.ff1_w, H, y.ff1_b, nullptr, M, I, H, SE_ACT_IDENTITY, a.hpre, nullptr, I, stream));
+        SE_TRY(se_gelu_bf16(a.hpre, Mz * I, a.h, stream));
+      }
+    }
     if (drop) {
       SE_TRY(se_gemm_bf16(a.h, I, y.ff2_w, I, y.ff2_b, nullptr, M, H, I, SE_ACT_IDENTITY, nullptr, tmp, H, stream));
       SE_TRY(launch_ln_train(tmp, nullptr, 1, x_f32, y.oln_w, y.oln_b, M, H, eps, a.pre2, last ? hidden : x_f32, last ? nullptr : s.l[i + 1].x0_bf,

@@ -68,6 +68,15 @@ __device__ __forceinline__ float act6(float v, int act) {
       }                                                                                                                    \
       if constexpr (RES) { v0 += rr[j].x; v1 += rr[j].y; v2 += rr[j].z; v3 += rr[j].w; }                                   \
       pk[j] = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));                                                        \
+      if constexpr (DUAL) {                                                                                                \
+        /* second output at out_bf16 + dual_off: gelu (erf form) of the bf16-ROUNDED value -- what se_gelu_bf16 computes from the stored rows */ \
+        const f32x2 da = gelu_erf2((f32x2){__uint_as_float(pk[j].x << 16), __uint_as_float(pk[j].x & 0xffff0000u)});       \
+        const f32x2 db = gelu_erf2((f32x2){__uint_as_float(pk[j].y << 16), __uint_as_float(pk[j].y & 0xffff0000u)});       \
+        pm[j] = make_uint2(pack_bf16x2(da.x, da.y), pack_bf16x2(db.x, db.y));                                              \
+        if (PRED) {                                                                                                        \
+          if (mok && gn < N) *reinterpret_cast<uint2*>(out_bf16 + dual_off + orow + gn) = pm[j];                           \
+        }                                                                                                                  \
+      }                                                                                                                    \
       if constexpr (X3) {                                                                                                  \
         /* the residual term y2 = bf16(y - y1) of the three-term operand; stored below with the 16-B pair exchange */      \
         const float r0 = v0 - __uint_as_float(pk[j].x << 16), r1 = v1 - __uint_as_float(pk[j].x & 0xffff0000u);            \
@@ -93,16 +102,17 @@ __device__ __forceinline__ float act6(float v, int act) {
       if (!(PRED)) {                                                                                                       \
         /* 16-B stores: lanes l, l ^ 16 trade 4-column pieces of two neighbouring MFMA tiles, so each lane owns 8 consecutive   \
            bf16 columns and a wave instruction writes 16 rows x 64 contiguous bytes (gemm3.hip); X3: the y1 slice twice, then y2 */ \
-        _Pragma("unroll") for (int sl = 0; sl < (X3 ? 3 : 1); ++sl) {                                                      \
+        _Pragma("unroll") for (int sl = 0; sl < (X3 ? 3 : DUAL ? 2 : 1); ++sl) {                                           \
           _Pragma("unroll") for (int p2 = 0; p2 < 2; ++p2) {                                                               \
-            const uint2 e0 = (X3 && sl == 2) ? pm[2 * p2] : pk[2 * p2], e1 = (X3 && sl == 2) ? pm[2 * p2 + 1] : pk[2 * p2 + 1]; \
+            const bool second = (X3 && sl == 2) || (DUAL && sl == 1);                                                      \
+            const uint2 e0 = second ? pm[2 * p2] : pk[2 * p2], e1 = second ? pm[2 * p2 + 1] : pk[2 * p2 + 1];               \
             const uint2 keep = godd ? e1 : e0;                                                                             \
             const uint2 send = godd ? e0 : e1;                                                                             \
             uint2 recv;                                                                                                    \
             recv.x = __shfl_xor(send.x, 16);                                                                               \
             recv.y = __shfl_xor(send.y, 16);                                                                               \
             const uint4 o16 = godd ? make_uint4(recv.x, recv.y, keep.x, keep.y) : make_uint4(keep.x, keep.y, recv.x, recv.y); \
-            *reinterpret_cast<uint4*>(out_bf16 + orow + (X3 ? sl * (ldc / 3) : 0) + n0 + wc * 64 + 16 * (2 * p2 + (godd ? 1 : 0)) + ncol8) = o16; \
+            *reinterpret_cast<uint4*>(out_bf16 + orow + (X3 ? sl * (ldc / 3) : (DUAL && sl == 1) ? dual_off : 0) + n0 + wc * 64 + 16 * (2 * p2 + (godd ? 1 : 0)) + ncol8) = o16; \
           }                                                                                                                \
         }                                                                                                                  \
       }                                                                                                                    \
@@ -267,7 +277,9 @@ __global__ __launch_bounds__(k6Threads) __attribute__((amdgpu_waves_per_eu(2, 2)
   if (!late) __builtin_amdgcn_s_barrier();                 // re-align the two groups (barrier counts must match)
 
   // ---- epilogue: C^T accumulators: col = lane & 15 -> output row, row = 4 (lane >> 4) + r -> 4 consecutive columns
-  constexpr bool RES = EF & 1, OBF = EF & 2, OF32 = EF & 4, X3 = EF & 8;
+  constexpr bool RES = EF & 1, OBF = EF & 2, OF32 = EF & 4, X3 = EF & 8, DUAL = false;
+  constexpr long long dual_off = 0;
+  (void)dual_off;
   const int mrow = lane & 15, ncol = 4 * (lane >> 4);
   float4 bb[4];
 #pragma unroll
@@ -305,13 +317,16 @@ __global__ __launch_bounds__(k6Threads) __attribute__((amdgpu_waves_per_eu(2, 2)
 //     other's main loops instead of all CUs writing at once.
 // Tile order: XCD x (= blockIdx & 7) owns a contiguous id range (gemm6's grouped order); its workgroups take ids start + slot + 32 i.
 // ------------------------------------------------------------------------------------------------------------------
-template <int ACT, int INM = 0>
+// DUAL_ = 1 (training forward of FFN1, ACT = identity): the tile is stored twice -- the pre-activation at out_bf16 and its GELU at out_bf16 + dual_off
+// (elements) -- so that the activation is not a second launch that re-reads the rows it has just written
+template <int ACT, int INM = 0, int DUAL_ = 0>
 __global__ __launch_bounds__(k6Threads) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm6p_bf16_kernel(
     const uint16_t* __restrict__ A, int lda, const uint16_t* __restrict__ W, int ldw, const float* __restrict__ bias, int M, int N, int K,
-    uint16_t* __restrict__ out_bf16, int ldc, int tiles_m, int tiles_n, int group_m, int late_start) {
+    uint16_t* __restrict__ out_bf16, int ldc, int tiles_m, int tiles_n, int group_m, int late_start, long long dual_off) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   SE_CLKPROBE_BEGIN();
-  constexpr bool RES = false, OBF = true, OF32 = false, X3 = false;
+  constexpr bool RES = false, OBF = true, OF32 = false, X3 = false, DUAL = DUAL_ != 0;
+  (void)dual_off;
   const float* residual = nullptr;          // named by the shared epilogue body inside discarded branches only
   float* out_f32 = nullptr;
   (void)residual; (void)out_f32;
@@ -612,13 +627,13 @@ int launch6p(const G6Args& g) {
   const int grid = std::min(n_cu, (tiles_m * tiles_n + 7) & ~7);
   if (inm == 2)
     hipLaunchKernelGGL((se::gemm6p_bf16_kernel<ACT, 2>), dim3(grid), dim3(se::k6Threads), se::k6Lds + g.N * 4, g.st, g.A, g.lda, g.W, g.ldw, g.bias, g.M, g.N,
-                       g.K, g.out_bf16, g.ldc, tiles_m, tiles_n, group_m, late_start);
+                       g.K, g.out_bf16, g.ldc, tiles_m, tiles_n, group_m, late_start, 0LL);
   else if (inm)
     hipLaunchKernelGGL((se::gemm6p_bf16_kernel<ACT, 1>), dim3(grid), dim3(se::k6Threads), se::k6Lds + g.N * 4, g.st, g.A, g.lda, g.W, g.ldw, g.bias, g.M, g.N,
-                       g.K, g.out_bf16, g.ldc, tiles_m, tiles_n, group_m, late_start);
+                       g.K, g.out_bf16, g.ldc, tiles_m, tiles_n, group_m, late_start, 0LL);
   else
     hipLaunchKernelGGL((se::gemm6p_bf16_kernel<ACT, 0>), dim3(grid), dim3(se::k6Threads), se::k6Lds + g.N * 4, g.st, g.A, g.lda, g.W, g.ldw, g.bias, g.M, g.N,
-                       g.K, g.out_bf16, g.ldc, tiles_m, tiles_n, group_m, late_start);
+                       g.K, g.out_bf16, g.ldc, tiles_m, tiles_n, group_m, late_start, 0LL);
   SE_LAUNCH_CHECK();
   return SE_OK;
 }
@@ -649,6 +664,46 @@ extern "C" int se_gemm6_launch(const uint16_t* A, int lda, const uint16_t* W, in
   if (!gelu && !res && !obf) return launch6<SE_ACT_IDENTITY, 4>(g);
   if (gelu && !res && !obf) return launch6<SE_ACT_GELU, 4>(g);
   return 1;
+}
+
+// y = A . W^T + bias as bf16 rows at out_pre AND gelu(y) (erf form, of the bf16-rounded y) at out_act, one launch of the persistent kernel: the
+// training forward of the FFN's first projection, which keeps the pre-activation for the backward pass (encoder_train.hip; was se_gemm_bf16 +
+// se_gelu_bf16).  Returns 1 when the shape is not the persistent kernel's (the caller then runs the two launches).
+extern "C" int se_gemm6_dual_gelu_launch(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias, int M, int N, int K, uint16_t* out_pre,
+                                         uint16_t* out_act, int ldc, void* stream) {
+  if (!(N % se::k6BN == 0 && N <= 8192 && K % se::k6BK == 0 && (K / se::k6BK) % 2 == 0 && K >= 4 * se::k6BK && (ldc % 8) == 0 && ldc >= N &&
+        lda >= K && ldw >= K && lda % 8 == 0 && ldw % 8 == 0 && (size_t)M * lda < (1u << 31) && (size_t)N * ldw < (1u << 31) &&
+        (size_t)((M + se::k6BM - 1) / se::k6BM) * (N / se::k6BN) > 256 &&
+        (((uintptr_t)A | (uintptr_t)W | (uintptr_t)out_pre | (uintptr_t)out_act | (uintptr_t)bias) % 16) == 0))
+    return 1;
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("SE_AMD_GEMM6_DUAL"); on = e ? atoi(e) : 1; }      // A/B: 0 = two launches
+  if (!on) return 1;
+  const int tiles_m = (M + se::k6BM - 1) / se::k6BM, tiles_n = N / se::k6BN;
+  static int group_m = 0, n_cu = 0, late_start = 0;
+  static bool attr_set = false;
+  if (!attr_set) {
+    const char* gm = getenv("SE_AMD_GEMM_GROUPM");
+    group_m = gm ? atoi(gm) : 4;
+    if (group_m < 1) group_m = 1;
+    const char* ls = getenv("SE_AMD_GEMM6P_LATE");
+    late_start = ls ? atoi(ls) : 2;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    SE_HIP(hipGetDevice(&dev));
+    SE_HIP(hipGetDeviceProperties(&prop, dev));
+    n_cu = prop.multiProcessorCount & ~7;
+    if (n_cu < 8) n_cu = 8;
+    SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::gemm6p_bf16_kernel<SE_ACT_IDENTITY, 2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, se::k6Lds + 32768));
+    attr_set = true;
+  }
+  hipStream_t st = se::as_stream(stream);
+  se::ProfScope prof(se::kProfGemm, 2.0 * M * (double)N * K, st);
+  const int grid = std::min(n_cu, (tiles_m * tiles_n + 7) & ~7);
+  hipLaunchKernelGGL((se::gemm6p_bf16_kernel<SE_ACT_IDENTITY, 2, 1>), dim3(grid), dim3(se::k6Threads), se::k6Lds + N * 4, st, A, lda, W, ldw, bias, M, N, K, out_pre,
+                     ldc, tiles_m, tiles_n, group_m, late_start, (long long)(out_act - out_pre));
+  SE_LAUNCH_CHECK();
+  return SE_OK;
 }
 
 // out3 (M, 3 Kp) bf16 = the three-term activation operand [y1 | y1 | y2] of y = act(A . W^T + bias) (se_split3_bf16's layout, which = 0): the bf16x3
