@@ -233,6 +233,20 @@ extern "C" int se_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, int l
       if (const char* mn = getenv("SE_AMD_GEMM6_MIN_N")) min_n6 = atoi(mn);      // A/B: output width from which the 256 x 256 x 64 kernel is used
     }
     if (M <= small_m) return se_gemm2_launch(A, lda, W, ldw, bias, residual_f32, M, N, K, act, out_bf16, out_f32, ldc, vec_ok, 4, stream);
+    // A/B (SE_AMD_GEMM_TAILSPLIT=1): the persistent 256 x 256 kernel deals tiles_m x tiles_n tiles to 256 workgroups; when the count is r + f rounds with a
+    // small fraction f (QKV at B = 32: 1 134 tiles = 4.43 rounds, 110 workgroups own five tiles and 146 four), the last rows go to the 128 x 128
+    // two-workgroups-per-CU kernel instead: whole rounds of large tiles, then one round of small ones
+    static int tailsplit = -1;
+    if (tailsplit < 0) { const char* e = getenv("SE_AMD_GEMM_TAILSPLIT"); tailsplit = e ? atoi(e) : 0; }
+    if (tailsplit && use6 && N >= min_n6 && N % 256 == 0 && out_bf16 && !out_f32 && !residual_f32) {
+      const int tiles_n = N / 256, tiles_m = (M + 255) / 256, tiles = tiles_m * tiles_n, rounds = tiles / 256, rest = tiles - rounds * 256;
+      const int m1 = (rounds * 256 / tiles_n) * 256;                     // rows of the whole rounds
+      if (rounds >= 3 && rest > 0 && rest <= 160 && m1 > 0 && M - m1 > 0 && M - m1 <= small_m) {
+        const int rc1 = se_gemm_bf16(A, lda, W, ldw, bias, nullptr, m1, N, K, act, out_bf16, nullptr, ldc, stream);
+        if (rc1 != SE_OK) return rc1;
+        return se_gemm2_launch(A + (size_t)m1 * lda, lda, W, ldw, bias, nullptr, M - m1, N, K, act, out_bf16 + (size_t)m1 * ldc, nullptr, ldc, vec_ok, 4, stream);
+      }
+    }
     // round 4: N = 768 outputs with a long reduction (the training path's FFN2 forward and FFN1 input gradient, K = 3072: 190 vs 205 us) also
     // run faster on the 256 x 256 x 64 kernel in spite of its 1.48-round tile count; at K = 768 the 256 x 128 ping-pong kernel keeps its lead (66 vs 70 us)
     // round 4 (later): N = 768 with K >= 1536 goes to the row-complete kernel without its LayerNorm (gemm4.hip: 251 tiles of 128 x 768 = ONE round,
