@@ -346,12 +346,17 @@ int se_split3_bf16(const float* x, long ld, int rows, int cols, int Kp, int whic
  *   se_gemm_x3out_bf16      out3 = split(act(A . W^T + bias)); A (M, K) / W (N, K) three-term operands (K = 3 x the layer's depth); act identity / GELU (erf)
  *   se_layernorm_x3_f32     out_f32 (may be NULL) = LayerNorm(x), out3 = split(LayerNorm(x)); H = 256, 512, 768, 1024
  *   se_mhsa_fwd_x3_split_f32  se_mhsa_fwd_x3_f32 with the context written as its split (Kp >= heads * 64)
+ *   se_gemm_res_ln_x3_bf16  the row-complete projection + residual + LayerNorm launch of the bf16 path (se_gemm_res_ln_bf16, N = 768) on three-term
+ *                           operands: out_f32 = LayerNorm(A . W^T + bias + residual_f32) (the next residual), out3 (M, 3 x 768) = its split --
+ *                           the attention-output and FFN-output dense + LayerNorm of model.py's encoder layers in one launch
  */
 int se_gemm_x3out_bf16(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias, int M, int N, int K, int act,
                        uint16_t* out3, int Kp, void* stream);
 int se_layernorm_x3_f32(const float* x, const float* w, const float* b, int M, int H, float eps, float* out_f32, uint16_t* out3, int Kp,
                         void* stream);
 int se_mhsa_fwd_x3_split_f32(const float* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx3, int Kp, void* stream);
+int se_gemm_res_ln_x3_bf16(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias, const float* residual_f32, const float* ln_w,
+                           const float* ln_b, float eps, int M, int N, int K, float* out_f32, uint16_t* out3, void* stream);
 /* The attention core of the same mode (csrc/mhsa_x3.hip): ctx (B*T, H) fp32 = softmax(Q K^T / 8 + pad mask) V from the fp32 fused projection
  * qkv (B*T, 3H) = [Q | K | V], flash style on the bf16 matrix pipe with two-term splits of Q, K, V and P (three products each); replaces the
  * materialised scores of the fp32 mode (se_gemm_f32 batched + se_softmax_rows_f32).  heads of 64; buffers 16-B aligned. */

@@ -102,6 +102,7 @@ SIGNATURES = {
     'se_gemm_x3out_bf16': (c_int, [_P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, c_int, _P]),
     'se_layernorm_x3_f32': (c_int, [_P, _P, _P, c_int, c_int, c_float, _P, _P, c_int, _P]),
     'se_mhsa_fwd_x3_split_f32': (c_int, [_P, _P, c_int, c_int, c_int, _P, c_int, _P]),
+    'se_gemm_res_ln_x3_bf16': (c_int, [_P, c_int, _P, c_int, _P, _P, _P, _P, c_float, c_int, c_int, c_int, _P, _P, _P]),
     'se_mhsa_fwd_x3_f32': (c_int, [_P, _P, c_int, c_int, c_int, _P, _P]),
     'se_transpose_bf16': (c_int, [_P, c_int, c_int, c_int, _P, c_int, _P]),
     'se_transpose_f32_bf16': (c_int, [_P, c_int, c_int, c_int, _P, c_int, _P]),

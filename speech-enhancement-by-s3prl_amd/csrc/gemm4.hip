@@ -130,7 +130,8 @@ __device__ __forceinline__ void acc_init4(f32x4 (&acc)[4][12], const float* __re
 
 // (optional gelu) + LayerNorm on the accumulators (which hold A.W^T + bias + residual) + the stores.  Called with every wave past its last
 // ring access (the caller's __syncthreads): the ring is dead, its first 6 KiB take ln_w / ln_b, `red_off` + 4 KiB the row partial sums.
-template <int GELU, int ROUT, int LN = 1>
+// X3OUT: out_bf16 is the NEXT bf16x3 projection's three-slice operand [y1 | y1 | y2] (row stride 3 x 768; se_split3_bf16's layout), beside the fp32 rows
+template <int GELU, int ROUT, int LN = 1, int X3OUT = 0>
 __device__ __forceinline__ void ln_epilogue4(f32x4 (&acc)[4][12], char* smem, int red_off, const float* __restrict__ ln_w, const float* __restrict__ ln_b,
                                              float eps, int M, int m0, int id, int wave, int wr, int wc, int lane, float* __restrict__ out_f32,
                                              uint16_t* __restrict__ out_bf16, uint8_t* __restrict__ out_lo) {
@@ -201,8 +202,8 @@ __device__ __forceinline__ void ln_epilogue4(f32x4 (&acc)[4][12], char* smem, in
     const int gm = m0 + wr * 64 + i * 16 + mrow;
     const bool ok = interior || gm < M;
     const size_t o = (size_t)min(gm, M - 1) * k4N + col0;
-    const size_t orow8 = (size_t)min(gm, M - 1) * k4N + wc * 192 + 4 * (cq & ~1);      // first of this lane's 8 consecutive bf16 columns
-    uint2 pk_prev = make_uint2(0u, 0u);
+    const size_t orow8 = (size_t)min(gm, M - 1) * (X3OUT ? 3 * k4N : k4N) + wc * 192 + 4 * (cq & ~1);      // first of this lane's 8 consecutive bf16 columns
+    uint2 pk_prev = make_uint2(0u, 0u), pm_prev = make_uint2(0u, 0u);
     const float nmr = LN ? -mean[i] * rstd[i] : 0.f;
 #pragma unroll
     for (int t = 0; t < 12; ++t) {
@@ -225,6 +226,10 @@ __device__ __forceinline__ void ln_epilogue4(f32x4 (&acc)[4][12], char* smem, in
         if (ROUT)      // tile-major lo bytes: rows past M are written too (the buffer covers whole tiles) and never read as real rows
           *reinterpret_cast<uint32_t*>(out_lo + ((((size_t)id * 8 + wave) * 4 + i) * 12 + t) * 256 + lane * 4) =
               enc24_lo4(y0, y1, y2, y3, pk);
+        uint2 pm = make_uint2(0u, 0u);
+        if constexpr (X3OUT)        // the residual term y2 = bf16(y - y1)
+          pm = make_uint2(pack_bf16x2(y0 - __uint_as_float(pk.x << 16), y1 - __uint_as_float(pk.x & 0xffff0000u)),
+                          pack_bf16x2(y2 - __uint_as_float(pk.y << 16), y3 - __uint_as_float(pk.y & 0xffff0000u)));
         if (t & 1) {
           const uint2 keep = godd ? pk : pk_prev, send = godd ? pk_prev : pk;
           uint2 recv;
@@ -232,8 +237,18 @@ __device__ __forceinline__ void ln_epilogue4(f32x4 (&acc)[4][12], char* smem, in
           recv.y = __shfl_xor(send.y, 16);
           const uint4 o16 = godd ? make_uint4(recv.x, recv.y, keep.x, keep.y) : make_uint4(keep.x, keep.y, recv.x, recv.y);
           if (ok) *reinterpret_cast<uint4*>(out_bf16 + orow8 + 16 * (godd ? t : t - 1)) = o16;
+          if constexpr (X3OUT) {
+            if (ok) *reinterpret_cast<uint4*>(out_bf16 + orow8 + k4N + 16 * (godd ? t : t - 1)) = o16;
+            const uint2 keepm = godd ? pm : pm_prev, sendm = godd ? pm_prev : pm;
+            uint2 recvm;
+            recvm.x = __shfl_xor(sendm.x, 16);
+            recvm.y = __shfl_xor(sendm.y, 16);
+            const uint4 o16m = godd ? make_uint4(recvm.x, recvm.y, keepm.x, keepm.y) : make_uint4(keepm.x, keepm.y, recvm.x, recvm.y);
+            if (ok) *reinterpret_cast<uint4*>(out_bf16 + orow8 + 2 * k4N + 16 * (godd ? t : t - 1)) = o16m;
+          }
         }
         pk_prev = pk;
+        pm_prev = pm;
       }
     }
   }
@@ -431,7 +446,7 @@ __global__ __launch_bounds__(k4Threads) __attribute__((amdgpu_waves_per_eu(2, 2)
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int k7WSlot = 256 * 128, k7ASlot = 128 * 128, k7ABase = 4 * k7WSlot, k7Lds = 4 * k7WSlot + 2 * k7ASlot;     // 32 KiB, 16 KiB, 160 KiB
 
-template <int GELU, int RIN, int ROUT, int INM = 0, int LN = 1>
+template <int GELU, int RIN, int ROUT, int INM = 0, int LN = 1, int X3OUT = 0>
 __global__ __launch_bounds__(k4Threads) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm7_res_ln_kernel(
     const uint16_t* __restrict__ A, int lda, const uint16_t* __restrict__ W, int ldw, const float* __restrict__ bias,
     const float* __restrict__ residual, const float* __restrict__ ln_w, const float* __restrict__ ln_b, float eps, int M, int K,
@@ -581,7 +596,7 @@ __global__ __launch_bounds__(k4Threads) __attribute__((amdgpu_waves_per_eu(2, 2)
   }
   if (!late) __builtin_amdgcn_s_barrier();                  // re-align the two groups
   __syncthreads();                                          // ring is dead: reuse it for the per-column vectors
-  ln_epilogue4<GELU, ROUT, LN>(acc, smem, 8192, ln_w, ln_b, eps, M, m0, id, wave, wr, wc, lane, out_f32, out_bf16, out_lo);
+  ln_epilogue4<GELU, ROUT, LN, X3OUT>(acc, smem, 8192, ln_w, ln_b, eps, M, m0, id, wave, wr, wc, lane, out_f32, out_bf16, out_lo);
   SE_CLKPROBE_END(clkprobe_gemm7);
 #undef SE7_DMA1
 #undef SE7_DMA_W
@@ -697,6 +712,33 @@ extern "C" int se_gemm7_plain_launch(const uint16_t* A, int lda, const uint16_t*
   se::ProfScope prof(se::kProfGemm, 2.0 * M * (double)se::k4N * K, st);
   hipLaunchKernelGGL((se::gemm7_res_ln_kernel<0, 0, 0, 1, 0>), dim3(ntiles), dim3(se::k4Threads), se::k7Lds, st, A, lda, W, ldw, bias, residual_f32,
                      (const float*)nullptr, (const float*)nullptr, 0.f, M, K, out_f32, out_bf16, ntiles, 0, (const uint8_t*)nullptr, (uint8_t*)nullptr);
+  SE_LAUNCH_CHECK();
+  return SE_OK;
+}
+
+// bf16x3 parity mode: x = LayerNorm(A . W^T + bias + residual_f32) as fp32 rows (the next residual) AND as the next projection's three-slice operand
+// out3 (M, 3 x 768) = [x1 | x1 | x2] from the same launch (A / W are three-slice operands themselves, K = 3 x the layer's width); was
+// se_gemm_res_ln_bf16 + se_split3_bf16.  N = 768 only; returns SE_ERR_UNSUPPORTED otherwise.
+extern "C" int se_gemm_res_ln_x3_bf16(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias, const float* residual_f32, const float* ln_w,
+                                      const float* ln_b, float eps, int M, int N, int K, float* out_f32, uint16_t* out3, void* stream) {
+  SE_REQUIRE(A && W && residual_f32 && ln_w && ln_b && out_f32 && out3, "se_gemm_res_ln_x3_bf16: null argument");
+  if (N != se::k4N || K % 64 != 0 || K < 128 || (size_t)M * lda >= (1u << 31) || (size_t)se::k4N * ldw >= (1u << 31)) {
+    se::set_error("se_gemm_res_ln_x3_bf16: N = 768, K a multiple of 64 (>= 128), 31-bit operand offsets");
+    return SE_ERR_UNSUPPORTED;
+  }
+  SE_REQUIRE(M > 0 && lda >= K && ldw >= K && lda % 8 == 0 && ldw % 8 == 0, "se_gemm_res_ln_x3_bf16: bad leading dimensions");
+  SE_REQUIRE((((uintptr_t)A | (uintptr_t)W | (uintptr_t)residual_f32 | (uintptr_t)out_f32 | (uintptr_t)out3 | (uintptr_t)bias | (uintptr_t)ln_w |
+               (uintptr_t)ln_b) % 16) == 0, "se_gemm_res_ln_x3_bf16: pointers must be 16-B aligned");
+  static bool attr_set = false;
+  if (!attr_set) {
+    SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::gemm7_res_ln_kernel<0, 0, 0, 1, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, se::k7Lds));
+    attr_set = true;
+  }
+  const int ntiles = (M + se::k4BM - 1) / se::k4BM;
+  hipStream_t st = se::as_stream(stream);
+  se::ProfScope prof(se::kProfGemm, 2.0 * M * (double)se::k4N * K, st);
+  hipLaunchKernelGGL((se::gemm7_res_ln_kernel<0, 0, 0, 1, 1, 1>), dim3(ntiles), dim3(se::k4Threads), se::k7Lds, st, A, lda, W, ldw, bias, residual_f32, ln_w, ln_b,
+                     eps, M, K, out_f32, out3, ntiles, 0, (const uint8_t*)nullptr, (uint8_t*)nullptr);
   SE_LAUNCH_CHECK();
   return SE_OK;
 }

@@ -535,10 +535,16 @@ class _Engine:
 
         # row-complete projection + residual + LayerNorm in ONE launch (csrc/gemm4.hip: the LayerNorm runs in fp32 on the accumulators), then the split of
         # its fp32 rows: for the attention-output projection (N = H = 768, K = 3 H) the 256 x 256-tile GEMM fills its second round of tiles to 48 %
-        # and ran at 0.4 PFLOP/s; SE_AMD_X3_ROWLN (A/B): bit 0 = attention output, bit 1 = FFN output
-        rowln = int(os.environ.get('SE_AMD_X3_ROWLN', '3')) if H == 768 else 0
+        # and ran at 0.4 PFLOP/s; SE_AMD_X3_ROWLN (A/B): bit 0 = attention output, bit 1 = FFN output, bit 2 = the split from the same launch
+        rowln_env = os.environ.get('SE_AMD_X3_ROWLN')      # set: used as is (A/B, tests); unset: on from 160 row tiles (128 rows each, one per CU) = B >= 21 at T = 1001 (profiles/r04_x3_rowln_batch.txt)
+        rowln = 0 if H != 768 else (int(rowln_env) if rowln_env is not None else (7 if (M + 127) // 128 >= 160 else 0))
 
         def gemm_ln3(a3, K3, w3, bias, residual, ln, dst):
+            if rowln & 4:       # the split written by the same launch (se_gemm_res_ln_x3_bf16)
+                _lib.check(lib.se_gemm_res_ln_x3_bf16(_lib.ptr(a3), K3, _lib.ptr(w3), K3, _lib.ptr(bias), _lib.ptr(residual), _lib.ptr(ln.weight.detach()),
+                                                      _lib.ptr(ln.bias.detach()), float(ln.variance_epsilon), M, H, K3, _lib.ptr(dst), _lib.ptr(x3),
+                                                      _lib.stream()), 'se_gemm_res_ln_x3_bf16')
+                return
             _lib.check(lib.se_gemm_res_ln_bf16(_lib.ptr(a3), K3, _lib.ptr(w3), K3, _lib.ptr(bias), _lib.ptr(residual), _lib.ptr(ln.weight.detach()),
                                                _lib.ptr(ln.bias.detach()), float(ln.variance_epsilon), M, H, K3, _lib.ptr(dst), None, _lib.stream()),
                        'se_gemm_res_ln_bf16')

@@ -77,13 +77,20 @@ def _oracle_pass(cfg, ckpt, pre, wavs, lengths):
     return _ORACLE['r']
 
 
-@pytest.mark.parametrize('precision,hid_l2', [('fp32', 2e-5), ('bf16x3', 3e-5)])
-def test_fp32_mode_meets_1e4_at_the_reference_geometry(gpu, precision, hid_l2):
+@pytest.mark.parametrize('precision,hid_l2', [('fp32', 2e-5), ('bf16x3', 3e-5), ('bf16x3:rowln', 3e-5)])
+def test_fp32_mode_meets_1e4_at_the_reference_geometry(gpu, precision, hid_l2, monkeypatch):
     """both parity modes of the encoder against the oracle: 'fp32' (fp32 operands on the fp32 matrix instruction) and 'bf16x3' (every nn.Linear
     as one bf16 GEMM over three-term splits of both operands, attention core in exact fp32) -- the same bounds, north_star's 1e-4 on enhanced
     magnitudes among them"""
     from speech_enhancement_by_s3prl_amd import pipeline, synth
     torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+    if precision.endswith(':rowln'):
+        # the form the three-term mode takes from B = 21 on (transformer.encode_x3): the two N = 768 projections of a layer as ONE row-complete
+        # projection + residual + LayerNorm launch that also writes the next operand's split (se_gemm_res_ln_x3_bf16) -- forced on at this batch of 2
+        monkeypatch.setenv('SE_AMD_X3_ROWLN', '7')
+        precision = 'bf16x3'
+    elif precision == 'bf16x3':
+        monkeypatch.setenv('SE_AMD_X3_ROWLN', '0')
     cfg = pipeline.make_config()                                   # 6 x 768 x 12 x 3072 (config/pretrain_sample.yaml)
     ckpt = pipeline.synthetic_checkpoint(cfg, seed=0)
     up = pipeline.build_upstream(ckpt, gpu).set_precision(precision)
@@ -158,6 +165,32 @@ def test_mhsa_x3_vs_fp64(gpu, B, T, heads, lens):
     assert torch.isfinite(ctx).all()
     err = (ctx.double() - ref).abs().max().item() / ref.abs().max().item()
     bounded(f'mhsa_x3[{B},{T},{heads}] context max-norm', err, 3e-5)
+
+
+@pytest.mark.parametrize('M,K', [(300, 2304), (128, 768), (1001, 9216)])
+def test_gemm_res_ln_x3_equals_the_two_launches(gpu, M, K):
+    """se_gemm_res_ln_x3_bf16 (row-complete projection + residual + LayerNorm + the split of its rows, one launch) against se_gemm_res_ln_bf16
+    followed by se_split3_bf16: the fp32 rows and all three slices bit for bit (ragged last row tile at M = 300 / 1001)"""
+    from speech_enhancement_by_s3prl_amd import _lib as L
+    lib = L.load()
+    torch.manual_seed(M + K)
+    N = 768
+    A = torch.randn(M, K, device=gpu).bfloat16()
+    W = (torch.randn(N, K, device=gpu) * 0.03).bfloat16()
+    bias, res = torch.randn(N, device=gpu), torch.randn(M, N, device=gpu)
+    lw, lb = torch.rand(N, device=gpu) + 0.5, torch.randn(N, device=gpu)
+    o_ref = torch.empty(M, N, device=gpu)
+    L.check(lib.se_gemm_res_ln_bf16(L.ptr(A), K, L.ptr(W), K, L.ptr(bias), L.ptr(res), L.ptr(lw), L.ptr(lb), 1e-12, M, N, K, L.ptr(o_ref), None, L.stream()), 'ref')
+    s_ref = torch.empty(M, 3 * N, device=gpu, dtype=torch.bfloat16)
+    L.check(lib.se_split3_bf16(L.ptr(o_ref), N, M, N, N, 0, L.ptr(s_ref), L.stream()), 'split')
+    o = torch.empty(M, N, device=gpu)
+    s3 = torch.full((M, 3 * N), float('nan'), device=gpu, dtype=torch.bfloat16)
+    L.check(lib.se_gemm_res_ln_x3_bf16(L.ptr(A), K, L.ptr(W), K, L.ptr(bias), L.ptr(res), L.ptr(lw), L.ptr(lb), 1e-12, M, N, K, L.ptr(o), L.ptr(s3), L.stream()), 'x3')
+    assert torch.equal(o, o_ref)
+    assert torch.equal(s3.view(torch.int16), s_ref.view(torch.int16))
+    # and the three slices reconstruct the fp32 rows to 2^-17
+    y = s3[:, :N].float() + s3[:, 2 * N:].float()
+    assert (y - o).abs().max().item() <= 2.0 ** -16 * o.abs().max().item()
 
 
 def test_x3_position_table_follows_the_sequence_length(gpu):
