@@ -40,6 +40,15 @@ __device__ __forceinline__ float act6(float v, int act) {
   return v;
 }
 
+// A/B (-DSE6_NT_STORES): the tile's 16-B stores as non-temporal (global_store ... nt) -- the dirty lines of a kernel's output are otherwise written back
+// from the eight L2s at the kernel boundary, which the next launch waits for
+typedef unsigned int se6_u32x4 __attribute__((ext_vector_type(4)));
+#ifdef SE6_NT_STORES
+#define SE6_STORE16(ptr_, v_) __builtin_nontemporal_store((se6_u32x4){(v_).x, (v_).y, (v_).z, (v_).w}, reinterpret_cast<se6_u32x4*>(ptr_))
+#else
+#define SE6_STORE16(ptr_, v_) (*reinterpret_cast<uint4*>(ptr_) = (v_))
+#endif
+
 // Epilogue of a 256 x 256 tile held as C^T accumulators acc[8][4] (col = lane & 15 -> output row, row = 4 (lane >> 4) + r -> 4 consecutive
 // columns); expects m0, n0, wr, wc, mrow, ncol, ncol8, godd, bb[4] (bias, zero when the accumulators already carry it) in scope.
 #define SE6_EPILOGUE_BODY(PRED)                                                                                            \
@@ -112,7 +121,7 @@ __device__ __forceinline__ float act6(float v, int act) {
             recv.x = __shfl_xor(send.x, 16);                                                                               \
             recv.y = __shfl_xor(send.y, 16);                                                                               \
             const uint4 o16 = godd ? make_uint4(recv.x, recv.y, keep.x, keep.y) : make_uint4(keep.x, keep.y, recv.x, recv.y); \
-            *reinterpret_cast<uint4*>(out_bf16 + orow + (X3 ? sl * (ldc / 3) : (DUAL && sl == 1) ? dual_off : 0) + n0 + wc * 64 + 16 * (2 * p2 + (godd ? 1 : 0)) + ncol8) = o16; \
+            SE6_STORE16(out_bf16 + orow + (X3 ? sl * (ldc / 3) : (DUAL && sl == 1) ? dual_off : 0) + n0 + wc * 64 + 16 * (2 * p2 + (godd ? 1 : 0)) + ncol8, o16); \
           }                                                                                                                \
         }                                                                                                                  \
       }                                                                                                                    \
