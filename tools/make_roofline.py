@@ -104,7 +104,7 @@ def _micro(name, pattern, cast=float):
 
 skel = {f'{w}_per_simd': _micro('r04_micro_attn_skel.txt', r'QK\^T \| softmax \| PV in program order.*?%d/SIMD:\s+(\d+)' % w) for w in (1, 2, 3, 4)}
 skel_p = {f'{w}_per_simd': _micro('r04_micro_attn_skel.txt', r'QK\^T of the next unit issued before.*?%d/SIMD:\s+(\d+)' % w) for w in (1, 2, 3)}
-clock_ratio = 2.0 / 2.4                                    # sustained core clock under MFMA load / the clock of the nominal 2.5 PFLOP/s
+clock_ratio = 1.93 / 2.4                                   # in-kernel clock of the attention forward (profiles/r04_clk_probe.txt: 1.89-1.98 GHz) / the clock of the nominal 2.5 PFLOP/s
 best_skel = min(v for v in list(skel.values()) + list(skel_p.values()) if v) if any(skel.values()) else None
 out['mhsa_fwd_floor'] = {
     'unit': 'one wave, 32 queries x 64 keys, d = 64: 16 v_mfma_f32_32x32x16_bf16 = 512 matrix clocks on its SIMD',
@@ -125,13 +125,17 @@ out['mhsa_fwd_floor'] = {
         'floor_frac_of_nominal': round(512.0 / best_skel * clock_ratio, 3) if best_skel else None,
         'note': 'what bounds head dim 64 is the vector side of the softmax next to the matrix pipe, not LDS bandwidth: a single wave issues a vector instruction '
                 'every ~5 cycles (8.6 for v_exp), a SIMD with 3-4 waves one every ~2 (profiles/r03_micro_pk_rate.txt), and next to a busy matrix pipe ~9.5 / 12.8 '
-                '(profiles/r03_micro_coissue.txt).  >= 0.5 of nominal needs <= 490 cycles per unit at 2.0 GHz: below what the skeleton itself reaches.',
+                '(profiles/r03_micro_coissue.txt).  At the 1.89-1.98 GHz the chip holds in this kernel (profiles/r04_clk_probe.txt) >= 0.5 of the 2.4-GHz peak means <= 780-820 '
+                'cycles per unit over the WHOLE launch (prologues, tails, idle slots included): the kernel averages ~890 inside a workgroup lifetime and ~1 070 over the launch; '
+                'the register-only skeleton needs 600-780.',
     },
     'stamps': 'profiles/r04_mhsa_stamps.txt: one wave of mhsa.hip alone on its SIMD spends 2 205 cycles per tile (stamped build) for 512 matrix + ~430 softmax-issue '
               'cycles: K fragment reads in front of QK^T ~300 exposed, matrix results in front of the first exponential ~250, V^T reads inside PV ~160, '
               'staging + barrier ~230',
     'achieved_frac': mh.get('frac'),
-    'achieved_cycles_per_unit_at_2GHz': round(mh['avg_launch_ms'] * 1e-3 * 2.0e9 / 192.0) if mh.get('avg_launch_ms') else None,
+    'achieved_cycles_per_unit_at_1.93GHz': round(mh['avg_launch_ms'] * 1e-3 * 1.93e9 / 192.0) if mh.get('avg_launch_ms') else None,
+    'in_kernel_clock_GHz': {'attention forward': '1.89-1.98', 'QKV projection': '1.80-2.00', 'FFN1 + GELU': '1.62-1.78', 'FFN2 / attention output (row-complete)': '1.81-1.83 / 2.02-2.12',
+                            'weight gradient': '2.20-2.26', 'source': 'profiles/r04_clk_probe.txt (csrc/clkprobe.h, tools/clk_probe.py)'},
     'measured_restructurings_round4': {
         'mhsa8.hip: 8 waves, SIMD partners alternating matrix / load segments, 4 barriers per tile (the guide\'s two-waves-per-SIMD layout)': '156-172 us: the load segment '
         'carries the whole softmax of ONE wave (~1 200 stamped cycles) while its partner has 256 cycles of MFMA (profiles/r04_mhsa_stamps.txt)',

@@ -94,6 +94,7 @@ __global__ __launch_bounds__(256 * W) void k(float* out, unsigned long long* cyc
   } else if (MODE == 2) {
     for (int u = 0; u < UNITS; ++u) {
       qk(kf, qf, s0, s1);
+      asm volatile("" : "+v"(s0), "+v"(s1));      // all 8 QK^T MFMAs stay (the first version of this line kept 9 of the unit's 16: only s0[0..3] was used)
       pf[0][0] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(s0, s0, 0, 1, 2, 3));
       pv(vf, pf, o0, o1);
     }
@@ -141,8 +142,9 @@ int main() {
   float* out; unsigned long long* cyc;
   CHECK(hipMalloc(&out, 256 * 1024 * 4));
   CHECK(hipMalloc(&cyc, 2 * 4096 * 8));
-  run<2>("16 MFMAs only (floor 512)", out, cyc);
-  run<3>("softmax vector work only (32 exp, 32 add, 16 pack + glue)", out, cyc);
+  // (a MODE 2 "MFMAs only" line used to be printed here: the compiler removes 6-7 of the unit's 16 MFMAs whose results the loop never consumes, so it read 290-390
+  //  cycles; the floor is 16 x 32 = 512 by the instruction's issue rate: tools/micro/valu_rate.hip measures 36-40 cycles per back-to-back MFMA at the nominal clock)
+  // (likewise no "vector work only" line: with constant scores the compiler hoists 31 of the 32 exponentials out of the loop)
   run<0>("QK^T | softmax | PV in program order", out, cyc);
   run<1>("QK^T of the next unit issued before the softmax of this one", out, cyc);
   return 0;
