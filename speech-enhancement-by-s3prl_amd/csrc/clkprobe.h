@@ -9,7 +9,10 @@
 #define SE_CLKPROBE_DECL(name)                                                                                   \
   __device__ unsigned long long name[4 * SE_CLKPROBE_SLOTS];                                                     \
   extern "C" int se_dev_##name(unsigned long long* host_out) {                                                   \
-    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(name), sizeof(unsigned long long) * 4 * SE_CLKPROBE_SLOTS) == hipSuccess ? 0 : 1; \
+    if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(name), sizeof(unsigned long long) * 4 * SE_CLKPROBE_SLOTS) != hipSuccess) return 1; \
+    void* p_ = nullptr;                      /* and cleared, so that the next read holds one kernel's workgroups only */ \
+    if (hipGetSymbolAddress(&p_, HIP_SYMBOL(name)) != hipSuccess) return 1;                                      \
+    return hipMemset(p_, 0, sizeof(unsigned long long) * 4 * SE_CLKPROBE_SLOTS) == hipSuccess ? 0 : 1;          \
   }
 #define SE_CLKPROBE_BEGIN() \
   const unsigned long long cp_t0_ = __builtin_amdgcn_s_memtime(), cp_r0_ = __builtin_amdgcn_s_memrealtime()

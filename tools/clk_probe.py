@@ -45,6 +45,7 @@ def read(name):
 def run(label, name, launch, flops):
     launch()
     torch.cuda.synchronize()
+    read(name)                       # reading clears the probe buffer: what is read below is this kernel's last launch only
     t0 = time.time()
     n = 0
     while time.time() - t0 < 1.5:
