@@ -251,8 +251,10 @@ def extras_leg(args, w, dev, out):
         finally:
             up.set_precision('bf16')
         r3['note'] = ("TRANSFORMER.set_precision('bf16x3'): x1 w1 + x1 w2 + x2 w1 of the bf16 splits x = x1 + x2 (+ 2^-17) as ONE GEMM of depth 3 K per "
-                      'nn.Linear (se_split3_bf16 + se_gemm_bf16), attention as a flash kernel on two-term splits of Q, K, V, P with an exact fp32 online '
-                      'softmax (se_mhsa_fwd_x3_f32); meets the same 1e-4 test (tests/test_gpu_encoder_fp32.py: enhanced magnitudes 7e-6); not the headline value')
+                      "nn.Linear, every producer writing the next operand's split itself (se_gemm_x3out_bf16, se_layernorm_x3_f32, se_mhsa_fwd_x3_split_f32; from 160 "
+                      'row tiles on the N = 768 projections as one row-complete GEMM + residual + LayerNorm + split launch, se_gemm_res_ln_x3_bf16), attention as a '
+                      'flash kernel on two-term splits of Q, K, V, P with an exact fp32 online softmax; meets the same 1e-4 test (tests/test_gpu_encoder_fp32.py: '
+                      'enhanced magnitudes 7e-6); not the headline value')
         if r3b is not None:
             r3['at_bench_batch'] = r3b
         out['bf16x3_parity_mode'] = r3
