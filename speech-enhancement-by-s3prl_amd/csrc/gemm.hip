@@ -254,9 +254,10 @@ extern "C" int se_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, int l
     // SE_AMD_GEMM7_PLAIN=0 restores the 256 x 256 x 64 kernel.  (A first "A/B" of this switch read 19.55 against 19.44 ms -- both arms had run a stale
     // library whose rebuild had failed behind a `| tail`; build.py now deletes the library when a rebuild fails.)
     static int plain7 = -1;
-    if (plain7 < 0) { const char* e = getenv("SE_AMD_GEMM7_PLAIN"); plain7 = e ? atoi(e) : 1; }
+    static int plain7_mink = 1536;
+    if (plain7 < 0) { const char* e = getenv("SE_AMD_GEMM7_PLAIN"); plain7 = e ? atoi(e) : 1; if (const char* k = getenv("SE_AMD_GEMM7_PLAIN_MINK")) plain7_mink = atoi(k); }
     // ... from 160 row tiles on (M > 20 352: the x3 batch sweep, profiles/r04_x3_rowln_batch.txt); below that the 256 x 256 / 256 x 128 kernels cover the chip better
-    if (plain7 && N == 768 && ldc == 768 && K >= 1536 && act == SE_ACT_IDENTITY && vec_ok && (M + 127) / 128 >= 160) {
+    if (plain7 && N == 768 && ldc == 768 && K >= plain7_mink && act == SE_ACT_IDENTITY && vec_ok && (M + 127) / 128 >= 160) {
       const int rc7 = se_gemm7_plain_launch(A, lda, W, ldw, bias, residual_f32, M, K, out_bf16, out_f32, stream);
       if (rc7 <= 0) return rc7;
     }
