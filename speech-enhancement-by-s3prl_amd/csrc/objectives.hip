@@ -33,7 +33,22 @@ __global__ __launch_bounds__(256) void sisdr_spec_sums_kernel(const float* __res
   const float* p = pred + (size_t)b * F * N;
   const float* t = tar + (size_t)b * F * N;
   double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-  for (int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x; i < L; i += (int64_t)gridDim.x * 256) {
+  // four independent element pairs per trip: eight loads in flight per thread instead of two (the launch was latency-bound at 3.6 TB/s); same fp64 sums
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x;
+  for (; i + 3 * stride < L; i += 4 * stride) {
+    float pv[4], tv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { pv[u] = p[i + u * stride]; tv[u] = t[i + u * stride]; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float s = sqrtf(fmaxf(pv[u], 0.f)), y = sqrtf(fmaxf(tv[u], 0.f));
+      a0 += (double)s * y;
+      a1 += (double)y * y;
+      a2 += (double)s * s;
+    }
+  }
+  for (; i < L; i += stride) {
     const float s = sqrtf(fmaxf(p[i], 0.f)), y = sqrtf(fmaxf(t[i], 0.f));
     a0 += (double)s * y;
     a1 += (double)y * y;
