@@ -45,6 +45,7 @@ __device__ uint4 g_wgrad_zero = {0u, 0u, 0u, 0u};
 typedef __attribute__((address_space(3))) void* w_lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* w_glb_ptr_t;
 #define SE_WTR(ptr) __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(ptr))
+typedef unsigned int h4 __attribute__((ext_vector_type(2)));      // one transposed 64-bit fragment half (asm reads of STAG 3)
 
 // STAG = 1 (round 4): waves 4-7 take the step's one barrier in the MIDDLE of their step (between the two 16-row sub-steps), so the two waves of a
 // SIMD run half a step apart instead of re-aligning at every step top (the attention forward gained 7 % that way, mhsa8.hip).  Costs one ring stage:
@@ -160,6 +161,48 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     __builtin_amdgcn_s_barrier();
   }
   int st = 0;
+  // ---- STAG 3 only: asm fragment reads.  Per-lane LDS addresses of the four (block parity, row half) transposed-read positions inside this wave's
+  //      dY panels (a) and X panel (b); the stage base is added per step, the panel / sub-step offsets are instruction immediates
+  const uint32_t lds_base = (uint32_t)(size_t)(w_lds_ptr_t)smem;
+  uint32_t ra[2][2], rb[2][2];
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y) { ra[x][y] = (uint32_t)(a_base + toff[x][y]); rb[x][y] = (uint32_t)(b_base + toff[x][y]); }
+  h4 fa_lo[2][4], fa_hi[2][4], fb_lo[2][2], fb_hi[2][2];
+  (void)ra; (void)rb; (void)lds_base;
+#define SEW3_RD(dst_, addr_, off_) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst_) : "v"(addr_), "n"(off_))
+  // set `k`, stage base sb_ (uniform), sub-step s_: blocks 0..3 of dY = panel (blk >> 1), 32-row half (blk & 1); blocks 0..1 of X
+#define SEW3_READ(k, sb_, s_)                                                                                   \
+  do {                                                                                                          \
+    const uint32_t a00 = ra[0][0] + (sb_), a01 = ra[0][1] + (sb_), a10 = ra[1][0] + (sb_), a11 = ra[1][1] + (sb_); \
+    const uint32_t b00 = rb[0][0] + (sb_), b01 = rb[0][1] + (sb_), b10 = rb[1][0] + (sb_), b11 = rb[1][1] + (sb_); \
+    SEW3_RD(fa_lo[k][0], a00, (s_) * 2048);           SEW3_RD(fa_hi[k][0], a01, (s_) * 2048);                   \
+    SEW3_RD(fa_lo[k][1], a10, (s_) * 2048);           SEW3_RD(fa_hi[k][1], a11, (s_) * 2048);                   \
+    SEW3_RD(fa_lo[k][2], a00, kWPanel + (s_) * 2048); SEW3_RD(fa_hi[k][2], a01, kWPanel + (s_) * 2048);         \
+    SEW3_RD(fa_lo[k][3], a10, kWPanel + (s_) * 2048); SEW3_RD(fa_hi[k][3], a11, kWPanel + (s_) * 2048);         \
+    SEW3_RD(fb_lo[k][0], b00, (s_) * 2048);           SEW3_RD(fb_hi[k][0], b01, (s_) * 2048);                   \
+    SEW3_RD(fb_lo[k][1], b10, (s_) * 2048);           SEW3_RD(fb_hi[k][1], b11, (s_) * 2048);                   \
+  } while (0)
+  // all but the CNT youngest LDS operations complete; set k's registers are operands, so that nothing that uses them is scheduled above the wait
+#define SEW3_WAIT(k, CNT)                                                                                       \
+  asm volatile("s_waitcnt lgkmcnt(" CNT ")"                                                                     \
+               : "+v"(fa_lo[k][0]), "+v"(fa_hi[k][0]), "+v"(fa_lo[k][1]), "+v"(fa_hi[k][1]), "+v"(fa_lo[k][2]), "+v"(fa_hi[k][2]),           \
+                 "+v"(fa_lo[k][3]), "+v"(fa_hi[k][3]), "+v"(fb_lo[k][0]), "+v"(fb_hi[k][0]), "+v"(fb_lo[k][1]), "+v"(fb_hi[k][1]) :: "memory")
+#define SEW3_MMA(k)                                                                                             \
+  do {                                                                                                          \
+    bf16x8 bq_[2];                                                                                              \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                               \
+      bq_[j] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(fb_lo[k][j], fb_hi[k][j], 0, 1, 2, 3));       \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                             \
+      const bf16x8 aq_ = __builtin_bit_cast(bf16x8, __builtin_shufflevector(fa_lo[k][i], fa_hi[k][i], 0, 1, 2, 3)); \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                             \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq_, bq_[j], acc[i][j], 0, 0, 0);                   \
+    }                                                                                                           \
+  } while (0)
+  if constexpr (STAG == 3) {
+    if (nt > 0) SEW3_READ(0, lds_base, 0);          // tile 0 is certified (the barrier above)
+  }
   for (int t = 0; t < nt; ++t) {
     SEW_STAMP();
     if (!STAG) {
@@ -220,6 +263,29 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         __builtin_amdgcn_sched_barrier(0);                                                                      \
       }                                                                                                         \
     } while (0)
+    if constexpr (STAG == 3) {
+      // STAG 3 (A/B, not the default: 3-5 % SLOWER than STAG 1 -- FFN 181-186 / 167-171 us against 174-177 / 162-165, fine-tune step 19.5 against 19.2 ms,
+      // profiles/r04_wgrad_stag3.txt -- so the fragment-read latency inside a wave is not what the step waits for once two staggered waves share a SIMD):
+      // the software pipeline the compiler would not keep -- the fragment reads are inline asm (the compiler neither waits for them nor
+      // sees them as LDS traffic), the waits are written by hand with the fragment registers as operands (so no MFMA moves above its wait), and
+      // while one sub-step's 8 MFMAs run, the NEXT sub-step's 12 transposed reads are already in the LDS queue: set 0 = (t, sub-step 0), read under the
+      // previous step's second sub-step; set 1 = (t, 1), read here.  A read only writes registers whose last MFMA has issued (in-order issue; the
+      // data returns >= 64 cycles later, the MFMA takes its operands in its first cycles).
+      const uint32_t sbase = lds_base + (uint32_t)(st * kWStage);
+      SEW3_READ(1, sbase, 1);
+      SEW_REFILL();
+      SEW3_WAIT(0, "12");                  // set 0 landed; the 12 reads of set 1 may stay in flight
+      SEW3_MMA(0);
+      SEW_LATE_BARRIER();
+      {
+        // tile t + 1: certified by barrier t, which this wave has passed.  UNCONDITIONAL (after the last tile it reads a stage nobody needs): a branch
+        // here made the compiler merge the two paths' fragment registers with copies placed in FRONT of one path's wait
+        const uint32_t sbn = lds_base + (uint32_t)((st + 1 == kRing ? 0 : st + 1) * kWStage);
+        SEW3_READ(0, sbn, 0);
+        SEW3_WAIT(1, "12");
+      }
+      SEW3_MMA(1);
+    } else
     if constexpr (!PIPE) {
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
@@ -260,9 +326,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     st = st + 1 == kRing ? 0 : st + 1;
   }
+  if constexpr (STAG == 3) SEW3_WAIT(0, "0");      // the last step's look-ahead reads have written their registers before anything reuses them
   SE_CLKPROBE_END(clkprobe_wgrad);
   SEW_STAMP();
 #undef SEW_ISSUE
+#undef SEW3_MMA
+#undef SEW3_WAIT
+#undef SEW3_READ
+#undef SEW3_RD
 #undef SEW_READ
 #undef SEW_MMA
 #undef SEW_REFILL
@@ -300,8 +371,8 @@ __global__ __launch_bounds__(256) void wgrad_slab_reduce_kernel(const float* __r
 static int wgrad_stag() {
   static int v = -1;
   // A/B: 0 = every wave's barrier at the step top (four-stage ring), 1 = waves 4-7 half a step behind (five stages), 2 = 1 with the
-  // refill in front of the sub-step's reads, X fragments first (counted lgkmcnt waits)
-  if (v < 0) { const char* e = getenv("SE_AMD_WGRAD_STAG"); v = e ? atoi(e) : 1; if (v < 0 || v > 2) v = 1; }
+  // refill in front of the sub-step's reads, X fragments first (counted lgkmcnt waits), 3 = 1 with asm fragment reads pipelined across sub-steps
+  if (v < 0) { const char* e = getenv("SE_AMD_WGRAD_STAG"); v = e ? atoi(e) : 1; if (v < 0 || v > 3) v = 1; }
   return v;
 }
 
@@ -321,6 +392,7 @@ extern "C" int se_wgrad_tn_bf16(const uint16_t* dY, int ldy, const uint16_t* X, 
     SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::wgrad_tn_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, se::kWLds));
     SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::wgrad_tn_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, se::kWLdsStag));
     SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::wgrad_tn_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, se::kWLdsStag));
+    SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::wgrad_tn_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, se::kWLdsStag));
     attr_set = true;
   }
   const int tiles_n = (N + se::kWN - 1) / se::kWN, tiles_k = (K + se::kWK - 1) / se::kWK;
@@ -340,7 +412,9 @@ extern "C" int se_wgrad_tn_bf16(const uint16_t* dY, int ldy, const uint16_t* X, 
   }
   {
     se::ProfScope prof(se::kProfGemm, 2.0 * M * (double)N * K, st);
-    if (wgrad_stag() == 2) hipLaunchKernelGGL(se::wgrad_tn_kernel<2>, dim3(work), dim3(512), se::kWLdsStag, st, dY, ldy, X, ldx, M, N, K, m_per_split, tiles_k,
+    if (wgrad_stag() == 3) hipLaunchKernelGGL(se::wgrad_tn_kernel<3>, dim3(work), dim3(512), se::kWLdsStag, st, dY, ldy, X, ldx, M, N, K, m_per_split, tiles_k,
+                                              tiles, work, partials, stamps);
+    else if (wgrad_stag() == 2) hipLaunchKernelGGL(se::wgrad_tn_kernel<2>, dim3(work), dim3(512), se::kWLdsStag, st, dY, ldy, X, ldx, M, N, K, m_per_split, tiles_k,
                                               tiles, work, partials, stamps);
     else if (wgrad_stag()) hipLaunchKernelGGL(se::wgrad_tn_kernel<1>, dim3(work), dim3(512), se::kWLdsStag, st, dY, ldy, X, ldx, M, N, K, m_per_split, tiles_k, tiles,
                                          work, partials, stamps);
@@ -374,12 +448,15 @@ extern "C" int se_wgrad_tn_slabs_bf16(const uint16_t* dY, int ldy, const uint16_
     SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::wgrad_tn_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, se::kWLds));
     SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::wgrad_tn_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, se::kWLdsStag));
     SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::wgrad_tn_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, se::kWLdsStag));
+    SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::wgrad_tn_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, se::kWLdsStag));
     attr_set = true;
   }
   const int tiles_n = (N + se::kWN - 1) / se::kWN, tiles_k = (K + se::kWK - 1) / se::kWK;
   const int tiles = tiles_n * tiles_k, work = tiles * groups;
   se::ProfScope prof(se::kProfGemm, 2.0 * M * (double)N * K, st);
-  if (wgrad_stag() == 2) hipLaunchKernelGGL(se::wgrad_tn_kernel<2>, dim3(work), dim3(512), se::kWLdsStag, st, dY, ldy, X, ldx, M, N, K, rows_per_slab, tiles_k, tiles,
+  if (wgrad_stag() == 3) hipLaunchKernelGGL(se::wgrad_tn_kernel<3>, dim3(work), dim3(512), se::kWLdsStag, st, dY, ldy, X, ldx, M, N, K, rows_per_slab, tiles_k, tiles,
+                                       work, slabs, (unsigned long long*)nullptr);
+  else if (wgrad_stag() == 2) hipLaunchKernelGGL(se::wgrad_tn_kernel<2>, dim3(work), dim3(512), se::kWLdsStag, st, dY, ldy, X, ldx, M, N, K, rows_per_slab, tiles_k, tiles,
                                        work, slabs, (unsigned long long*)nullptr);
   else if (wgrad_stag()) hipLaunchKernelGGL(se::wgrad_tn_kernel<1>, dim3(work), dim3(512), se::kWLdsStag, st, dY, ldy, X, ldx, M, N, K, rows_per_slab, tiles_k, tiles,
                                        work, slabs, (unsigned long long*)nullptr);
