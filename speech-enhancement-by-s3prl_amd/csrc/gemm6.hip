@@ -40,6 +40,15 @@ __device__ __forceinline__ float act6(float v, int act) {
   return v;
 }
 
+// timing-only ablation (-DSE6_ABL_SAMESRC, results wrong): every tile of the persistent kernel fetches the operands of tile (0, 0) -- the same 2 x 256 rows
+// from every CU, i.e. the identical instruction stream with all operand traffic served by L2 / L1 hits: separates "bound by the memory side" from
+// "bound by the LDS-DMA path or the issue stream"
+#ifdef SE6_ABL_SAMESRC
+#define SE6_ABL_SRC(x_) 0
+#else
+#define SE6_ABL_SRC(x_) (x_)
+#endif
+
 // A/B (-DSE6_NT_STORES): the tile's 16-B stores as non-temporal (global_store ... nt) -- the dirty lines of a kernel's output are otherwise written back
 // from the eight L2s at the kernel boundary, which the next launch waits for
 typedef unsigned int se6_u32x4 __attribute__((ext_vector_type(4)));
@@ -372,8 +381,8 @@ __global__ __launch_bounds__(k6Threads) __attribute__((amdgpu_waves_per_eu(2, 2)
       _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_) {                                                                   \
         const int trow_ = (rho_ >> 6) * 128 + h_ * 64 + (rho_ & 63);                                                       \
         const int tcol_ = (rho_ >> 5) * 64 + h_ * 32 + (rho_ & 31);                                                        \
-        a_of[h_][p_] = (uint32_t)(min(m0_ + trow_, M - 1) * lda + lc_) * 2u;                                               \
-        b_of[h_][p_] = (uint32_t)(min(n0_ + tcol_, N - 1) * ldw + lc_) * 2u;                                               \
+        a_of[h_][p_] = (uint32_t)(min(SE6_ABL_SRC(m0_) + trow_, M - 1) * lda + lc_) * 2u;                                  \
+        b_of[h_][p_] = (uint32_t)(min(SE6_ABL_SRC(n0_) + tcol_, N - 1) * ldw + lc_) * 2u;                                  \
       }                                                                                                                    \
     }                                                                                                                      \
   } while (0)
