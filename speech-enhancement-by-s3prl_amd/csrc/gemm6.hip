@@ -43,6 +43,11 @@ __device__ __forceinline__ float act6(float v, int act) {
 // timing-only ablation (-DSE6_ABL_SAMESRC, results wrong): every tile of the persistent kernel fetches the operands of tile (0, 0) -- the same 2 x 256 rows
 // from every CU, i.e. the identical instruction stream with all operand traffic served by L2 / L1 hits: separates "bound by the memory side" from
 // "bound by the LDS-DMA path or the issue stream"
+// -DSE6_ABL=<mask> (persistent kernel only, timing only, results wrong): 1 no LDS-DMA (and nothing to wait for), 2 no s_barrier, 4 no LDS fragment
+// reads (the MFMAs run on whatever the fragment registers hold), 8 no epilogue at all, 16 the epilogue's arithmetic and lane exchange but no store instructions
+#ifndef SE6_ABL
+#define SE6_ABL 0
+#endif
 #ifdef SE6_ABL_SAMESRC
 #define SE6_ABL_SRC(x_) 0
 #else
@@ -55,7 +60,7 @@ typedef unsigned int se6_u32x4 __attribute__((ext_vector_type(4)));
 #ifdef SE6_NT_STORES
 #define SE6_STORE16(ptr_, v_) __builtin_nontemporal_store((se6_u32x4){(v_).x, (v_).y, (v_).z, (v_).w}, reinterpret_cast<se6_u32x4*>(ptr_))
 #else
-#define SE6_STORE16(ptr_, v_) (*reinterpret_cast<uint4*>(ptr_) = (v_))
+#define SE6_STORE16(ptr_, v_) do { if (!(SE6_ABL & 16) || M < 0) *reinterpret_cast<uint4*>(ptr_) = (v_); } while (0)      /* ablation 16: the tile is converted and exchanged but never stored */
 #endif
 
 // Epilogue of a 256 x 256 tile held as C^T accumulators acc[8][4] (col = lane & 15 -> output row, row = 4 (lane >> 4) + r -> 4 consecutive
@@ -360,8 +365,11 @@ __global__ __launch_bounds__(k6Threads) __attribute__((amdgpu_waves_per_eu(2, 2)
   const int range_count = q + (xcd < rem ? 1 : 0);
   const int my_tiles = (range_count > slot) ? (range_count - slot + wpx - 1) / wpx : 0;
   if (my_tiles == 0) return;
-  if (late_start > 0 && my_tiles < (range_count + wpx - 1) / wpx)
-    for (int i = 0; i < late_start; ++i) __builtin_amdgcn_s_sleep(127);
+  if ((late_start & 0xff) > 0 && my_tiles < (range_count + wpx - 1) / wpx)
+    for (int i = 0; i < (late_start & 0xff); ++i) __builtin_amdgcn_s_sleep(127);
+  // A/B (SE_AMD_GEMM6P_SKEW = late_start >> 8): workgroup slot s of every XCD starts (s % 8) x skew x ~0.27 us late, so that the CUs' store bursts
+  // at the tile boundaries do not all hit the memory system in the same microsecond
+  for (int i = 0; i < (late_start >> 8) * (slot & 7); ++i) __builtin_amdgcn_s_sleep(8);
 
   // ---- DMA sources as 32-bit byte offsets from A / W (the launcher checks they fit): 8 registers per tile, rewritten in place when the
   //      stream moves on to the next tile.  Mapping as in gemm6_bf16_kernel.
@@ -394,6 +402,7 @@ __global__ __launch_bounds__(k6Threads) __attribute__((amdgpu_waves_per_eu(2, 2)
 #define SE6P_DMA(base, of, slot_off, buf, kt)                                                                              \
   do {                                                                                                                     \
     const char* sb_ = reinterpret_cast<const char*>(base) + (size_t)(kt) * (k6BK * 2);                                     \
+    if (SE6_ABL & 1) break;                                                                                                \
     _Pragma("unroll") for (int p_ = 0; p_ < 2; ++p_) {                                                                     \
       uint32_t keep_;                                                                                                      \
       asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"      \
@@ -414,11 +423,24 @@ __global__ __launch_bounds__(k6Threads) __attribute__((amdgpu_waves_per_eu(2, 2)
     }
   }
   bf16x8 af[4][2], bfr[2][2];
+  if (SE6_ABL & 4) {      // ablation: the fragments are never read; give them lane-dependent, non-trivial contents once (zeros would raise the clock)
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_) {
+#pragma unroll
+      for (int i_ = 0; i_ < 4; ++i_)
+#pragma unroll
+        for (int e_ = 0; e_ < 8; ++e_) af[i_][s_][e_] = (__bf16)(0.01f * (float)((lane * 7 + i_ * 3 + e_ + s_) % 13 - 6));
+#pragma unroll
+      for (int j_ = 0; j_ < 2; ++j_)
+#pragma unroll
+        for (int e_ = 0; e_ < 8; ++e_) bfr[j_][s_][e_] = (__bf16)(0.01f * (float)((lane * 5 + j_ + e_ * 3 + s_) % 11 - 5));
+    }
+  }
 #define SE6_READ_A(buf, h)                                                                                                 \
-  _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                        \
+  if (!(SE6_ABL & 4)) _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)    \
     af[i_][s_] = *reinterpret_cast<const bf16x8*>(smem + (buf) * k6Buf + ((h) ? k6A1 : k6A0) + a_ad[s_] + i_ * 2048);
 #define SE6_READ_B(buf, h)                                                                                                 \
-  _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                        \
+  if (!(SE6_ABL & 4)) _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)    \
     bfr[j_][s_] = *reinterpret_cast<const bf16x8*>(smem + (buf) * k6Buf + ((h) ? k6B1 : k6B0) + b_ad[s_] + j_ * 2048);
 #define SE6_MMA(mq, nq)                                                                                                    \
   _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                        \
@@ -446,13 +468,13 @@ __global__ __launch_bounds__(k6Threads) __attribute__((amdgpu_waves_per_eu(2, 2)
 #define SE6_SYNC_A()                                                                                                       \
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                       \
   __builtin_amdgcn_sched_barrier(0);                                                                                       \
-  __builtin_amdgcn_s_barrier();                                                                                            \
+  if (!(SE6_ABL & 2)) __builtin_amdgcn_s_barrier();                                                                                            \
   __builtin_amdgcn_sched_barrier(0);                                                                                       \
   if (INM != 2) __builtin_amdgcn_s_setprio(1);
 #define SE6_SYNC_B()                                                                                                       \
   if (INM != 2) __builtin_amdgcn_s_setprio(0);                                                                             \
   __builtin_amdgcn_sched_barrier(0);                                                                                       \
-  __builtin_amdgcn_s_barrier();                                                                                            \
+  if (!(SE6_ABL & 2)) __builtin_amdgcn_s_barrier();                                                                                            \
   __builtin_amdgcn_sched_barrier(0);
 #define SE6P_ISSUE_MID_BEGIN if (INM == 1) { __builtin_amdgcn_sched_barrier(0);
 #define SE6P_ISSUE_MID_END __builtin_amdgcn_sched_barrier(0); }
@@ -514,9 +536,9 @@ __global__ __launch_bounds__(k6Threads) __attribute__((amdgpu_waves_per_eu(2, 2)
   SE6P_DMA(A, a_of[1], k6A1, 1, 1);
   SE6P_DMA(W, b_of[0], k6B0, 1, 1);
   asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
+  if (!(SE6_ABL & 2)) __builtin_amdgcn_s_barrier();
   const bool late = wave >= 4;
-  if (late) __builtin_amdgcn_s_barrier();                  // stagger: waves 4-7 run one barrier behind
+  if (!(SE6_ABL & 2) && (late)) __builtin_amdgcn_s_barrier();                  // stagger: waves 4-7 run one barrier behind
 
   bool stores_pending = false;              // the previous tile's epilogue left exactly 16 store instructions per wave in flight
   f32x4 acc[8][4];
@@ -546,7 +568,7 @@ __global__ __launch_bounds__(k6Threads) __attribute__((amdgpu_waves_per_eu(2, 2)
     SE6P_TILE(0, SE6P_DMA(W, b_of[0], k6B0, 1, nk - 1); tile_id = next_id; SE6P_SET_SRC(tile_id, m0, n0),
               SE6P_DMA(A, a_of[0], k6A0, 0, 0), SE6P_DMA(W, b_of[1], k6B1, 0, 0), SE6P_DMA(A, a_of[1], k6A1, 0, 0), SE6P_W6)
     SE6P_TILE(1, SE6P_DMA(W, b_of[0], k6B0, 0, 0), SE6P_DMA(A, a_of[0], k6A0, 1, 1), SE6P_DMA(W, b_of[1], k6B1, 1, 1), SE6P_DMA(A, a_of[1], k6A1, 1, 1), SE6P_W6)
-    if (!late) __builtin_amdgcn_s_barrier();               // re-align the wave groups: both run the epilogue together
+    if (!(SE6_ABL & 2) && (!late)) __builtin_amdgcn_s_barrier();               // re-align the wave groups: both run the epilogue together
     SE6P_DMA(W, b_of[0], k6B0, 1, 1);                      // B_0 of the next tile's K-tile 1 (its slot was last read in the phase just finished)
 
     // ---- epilogue of tile (m0c, n0c); no LDS, no barrier
@@ -561,7 +583,9 @@ __global__ __launch_bounds__(k6Threads) __attribute__((amdgpu_waves_per_eu(2, 2)
 #pragma unroll
       for (int j = 0; j < 4; ++j) bb[j] = *reinterpret_cast<const float4*>(bias_lds + n0 + wc * 64 + j * 16 + ncol);
       const bool interior = m0 + k6BM <= M;                // N is a multiple of 256 and the bf16 rows are 16-B aligned (launcher)
-      if (interior) {
+      if ((SE6_ABL & 8) && acc[0][0][0] != 12345.678f) {
+        // ablation: no stores (the comparison keeps the accumulators alive)
+      } else if (interior) {
         SE6_EPILOGUE_BODY(false)
         stores_pending = true;
       } else {
@@ -574,7 +598,7 @@ __global__ __launch_bounds__(k6Threads) __attribute__((amdgpu_waves_per_eu(2, 2)
     for (int i = 0; i < 8; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (late && has_next) __builtin_amdgcn_s_barrier();    // stagger again
+    if (!(SE6_ABL & 2) && (late && has_next)) __builtin_amdgcn_s_barrier();    // stagger again
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // no LDS-DMA may outlive the workgroup's LDS allocation
   SE_CLKPROBE_END(clkprobe_gemm6);
@@ -627,6 +651,7 @@ int launch6p(const G6Args& g) {
     if (group_m < 1) group_m = 1;
     const char* ls = getenv("SE_AMD_GEMM6P_LATE");
     late_start = ls ? atoi(ls) : 2;
+    if (const char* sk = getenv("SE_AMD_GEMM6P_SKEW")) late_start |= (atoi(sk) & 0xff) << 8;
     int dev = 0;
     hipDeviceProp_t prop;
     SE_HIP(hipGetDevice(&dev));
