@@ -25,6 +25,11 @@
 #include "encoder_impl.h"
 
 SE_CLKPROBE_DECL(clkprobe_gemm7)
+// -DSE7_ABL=<mask> (gemm7_res_ln_kernel, timing only, results wrong): 1 no LDS-DMA, 2 no s_barrier in the K loop, 4 no LDS fragment reads, 8 no epilogue
+// (LayerNorm + stores), 16 no residual / bias read in front of the K loop
+#ifndef SE7_ABL
+#define SE7_ABL 0
+#endif
 namespace se {
 
 constexpr int k4BM = 128, k4N = 768, k4BK = 32, k4Threads = 512;
@@ -479,6 +484,7 @@ __global__ __launch_bounds__(k4Threads) __attribute__((amdgpu_waves_per_eu(2, 2)
   const size_t w_pstep = (size_t)64 * ldw * 2;            // bytes between the weight rows of consecutive pieces
 #define SE7_DMA1(base_bytes, off32, lds_dst)                                                                               \
   do {                                                                                                                     \
+    if (SE7_ABL & 1) break;                                                                                                \
     uint32_t keep_;                                                                                                        \
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"           \
                  : "=&s"(keep_) : "v"(off32), "s"(base_bytes), "s"(lds_dst) : "memory");                                   \
@@ -512,6 +518,12 @@ __global__ __launch_bounds__(k4Threads) __attribute__((amdgpu_waves_per_eu(2, 2)
   const int cq = lane >> 4;
   const int col0 = wc * 192 + 4 * cq;
   f32x4 acc[4][12];
+  if (SE7_ABL & 16) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int t = 0; t < 12; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  } else
   acc_init4<GELU, RIN, LN>(acc, bias, residual, res_lo, M, m0, id, wave, wr, lane, col0, res_mod);
   // every accumulator is COMPLETE here (opaque uses): with the integer codec the compiler otherwise left residual loads pending into the K loop
   // and protected the hand-issued LDS-DMA operands with s_waitcnt vmcnt(1) / vmcnt(0) INSIDE it -- which drains the DMA ring every K-tile
@@ -535,9 +547,18 @@ __global__ __launch_bounds__(k4Threads) __attribute__((amdgpu_waves_per_eu(2, 2)
   const bool late = wave >= 4;
   asm volatile("s_waitcnt vmcnt(8)" ::: "memory");         // A (0) and piece 0 landed (the residual loads above already drained more than that)
   __builtin_amdgcn_s_barrier();
-  if (late) __builtin_amdgcn_s_barrier();                   // stagger: waves 4-7 one barrier behind
+  if (!(SE7_ABL & 2) && late) __builtin_amdgcn_s_barrier();                   // stagger: waves 4-7 one barrier behind
 
   const int npieces = 3 * nk;
+  bf16x8 abl_a[4], abl_b[4];                 // ablation 4 only: loop-invariant stand-ins for the LDS fragments
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      abl_b[jj][e] = (__bf16)(0.01f * (float)((lane * 7 + jj * 3 + e) % 13 - 6));
+      abl_a[jj][e] = (__bf16)(0.01f * (float)((lane * 5 + jj + e * 3) % 11 - 5));
+    }
+  (void)abl_a; (void)abl_b;
   for (int t = 0; t < nk; ++t) {
     const int a_sl = (t & 1) * k7ASlot;
 #pragma unroll
@@ -547,10 +568,15 @@ __global__ __launch_bounds__(k4Threads) __attribute__((amdgpu_waves_per_eu(2, 2)
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         bf16x8 bfr[4], af[4];
+        if (SE7_ABL & 4) {
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) { bfr[jj] = abl_b[jj]; af[jj] = abl_a[jj]; asm volatile("" : "+v"(bfr[jj]), "+v"(af[jj])); }
+        } else {
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) bfr[jj] = *reinterpret_cast<const bf16x8*>(smem + w_sl + b_ad[s2] + jj * 2048);
 #pragma unroll
         for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(smem + a_sl + a_ad[s2] + i * 2048);
+        }
         // staging (see the header): piece q + 3 -> the slot piece q - 1 left at the end of the previous phase; A (t + 1) -> the slot A (t - 1) left
         if (!INM) {
           if (p == 0 && s2 == 0 && t + 1 < nk) SE7_DMA_A(t + 1);
@@ -571,7 +597,7 @@ __global__ __launch_bounds__(k4Threads) __attribute__((amdgpu_waves_per_eu(2, 2)
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
+        if (!(SE7_ABL & 2)) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         if (!INM) __builtin_amdgcn_s_setprio(1);        // with the refill between the MFMA groups the raised priority costs ~1 % of the step (A/B)
 #pragma unroll
@@ -589,13 +615,16 @@ __global__ __launch_bounds__(k4Threads) __attribute__((amdgpu_waves_per_eu(2, 2)
         }
         if (!INM) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
+        if (!(SE7_ABL & 2)) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
       }
     }
   }
-  if (!late) __builtin_amdgcn_s_barrier();                  // re-align the two groups
+  if (!(SE7_ABL & 2) && !late) __builtin_amdgcn_s_barrier();                  // re-align the two groups
   __syncthreads();                                          // ring is dead: reuse it for the per-column vectors
+  if ((SE7_ABL & 8) && acc[0][0][0] != 12345.678f) {
+    // ablation: no epilogue (the comparison keeps the accumulators alive)
+  } else
   ln_epilogue4<GELU, ROUT, LN, X3OUT>(acc, smem, 8192, ln_w, ln_b, eps, M, m0, id, wave, wr, wc, lane, out_f32, out_bf16, out_lo);
   SE_CLKPROBE_END(clkprobe_gemm7);
 #undef SE7_DMA1
