@@ -57,3 +57,23 @@ def test_wgrad_ring_is_not_drained_by_the_compiler(tmp_path, stag):
     hits = _compiler_vmcnt0_next_to_mfma(body)
     assert not hits, f'compiler-inserted vmcnt(0) inside the MFMA loop of wgrad_tn_kernel<{stag}>: {hits[:3]}'
     assert not any('scratch_' in l for l in body), 'wgrad_tn_kernel spills'
+
+
+@pytest.mark.parametrize('src,prefix,flags', [
+    ('gemm6.hip', '_ZN2se18gemm6p_bf16_kernelILi0ELi2ELi0EE', []),          # persistent 256 x 256 GEMM (QKV)
+    ('gemm6.hip', '_ZN2se18gemm6p_bf16_kernelILi3ELi2ELi0EE', []),          # ... with the GELU epilogue (FFN1)
+    ('gemm4.hip', '_ZN2se19gemm7_res_ln_kernelILi0ELi1ELi1ELi1ELi1ELi0EE', []),   # row-complete GEMM + residual + LayerNorm on the 24-bit stream
+    ('mhsa8.hip', '_ZN2se16mhsaN_fwd_kernelILi8ELi4ELi1EE', ['-fno-slp-vectorize']),   # the inference attention forward
+])
+def test_hot_lds_dma_loops_are_not_drained_by_the_compiler(tmp_path, src, prefix, flags):
+    """the other LDS-DMA kernels of the inference pass: same property (their DMA is inline asm, their waits are counted by hand)"""
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(hipcc):
+        pytest.skip('hipcc not available')
+    out = str(tmp_path / (src + '.s'))
+    subprocess.run([hipcc, '-O3', '-std=c++17', '--offload-arch=gfx950', '-fno-gpu-rdc', '-I', os.path.join(ROOT, 'include'), '-I', CSRC] + flags +
+                   ['-S', '--cuda-device-only', '-o', out, os.path.join(CSRC, src)], check=True, stderr=subprocess.DEVNULL)
+    body = _kernel(open(out).read().split('\n'), prefix)
+    assert sum('v_mfma' in l for l in body) >= 16 and sum('global_load_lds' in l for l in body) >= 2
+    hits = _compiler_vmcnt0_next_to_mfma(body)
+    assert not hits, f'{prefix}: compiler-inserted vmcnt(0) inside an MFMA loop: {hits[:3]}'
