@@ -44,7 +44,7 @@ __device__ __forceinline__ float act6(float v, int act) {
 // from every CU, i.e. the identical instruction stream with all operand traffic served by L2 / L1 hits: separates "bound by the memory side" from
 // "bound by the LDS-DMA path or the issue stream"
 // -DSE6_ABL=<mask> (persistent kernel only, timing only, results wrong): 1 no LDS-DMA (and nothing to wait for), 2 no s_barrier, 4 no LDS fragment
-// reads (the MFMAs run on whatever the fragment registers hold), 8 no epilogue at all, 16 the epilogue's arithmetic and lane exchange but no store instructions
+// reads (the MFMAs run on whatever the fragment registers hold), 8 no epilogue at all, 16 the epilogue's arithmetic and lane exchange but no store instructions, 32 all tiles store to the first 256 output rows (the stores stay, their HBM traffic goes)
 #ifndef SE6_ABL
 #define SE6_ABL 0
 #endif
@@ -69,7 +69,7 @@ typedef unsigned int se6_u32x4 __attribute__((ext_vector_type(4)));
   _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                                          \
     const int gm = m0 + wr * 128 + i * 16 + mrow;                                                                          \
     const bool mok = gm < M;                                                                                               \
-    const size_t orow = (size_t)min(gm, M - 1) * ldc;                                                                      \
+    const size_t orow = (size_t)((SE6_ABL & 32) ? (gm & 255) : min(gm, M - 1)) * ldc;       /* ablation 32: every tile writes rows 0 .. 255 (L2-resident) */ \
     float4 rr[4];                                                                                                          \
     if constexpr (RES) {                                                                                                   \
       _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                      \

@@ -1,12 +1,14 @@
 #!/bin/bash
-# compile-time ablation of the persistent 256 x 256 GEMM (timing only): what the launch spends on LDS-DMA, barriers, LDS fragment reads, epilogue stores
+# compile-time ablation of the persistent 256 x 256 GEMM (timing only): libraries given as arguments (tags), default the full set
 set -e
 root=$(cd "$(dirname "$0")/.." && pwd)
 out=$root/gpurun_out/r04aj
 mkdir -p "$out"
 cd "$root"
-: > "$out/r04_gemm6p_ablation_b.txt"
-for rep in 1 2; do for lib in libse_amd.so libse_amd.abl8.so libse_amd.abl16.so; do
-echo "== $lib" | tee -a "$out/r04_gemm6p_ablation_b.txt"
-SE_AMD_LIB=$root/speech-enhancement-by-s3prl_amd/$lib timeout -k 10 200 python3 tools/bench_kernels.py gemm 2>&1 | grep -v amdgpu.ids | grep "N=2304\|N=3072" | cut -c1-100 | tee -a "$out/r04_gemm6p_ablation_b.txt"
+tags=${@:-"abl1 abl2 abl4 abl8 abl16 abl32 abl15"}
+f="$out/r04_gemm6p_ablation_$(echo $tags | tr ' ' '_').txt"
+: > "$f"
+for rep in 1 2; do for lib in libse_amd.so $(for t in $tags; do echo libse_amd.$t.so; done); do
+echo "== $lib" | tee -a "$f"
+SE_AMD_LIB=$root/speech-enhancement-by-s3prl_amd/$lib timeout -k 10 200 python3 tools/bench_kernels.py gemm 2>&1 | grep -v amdgpu.ids | grep "N=2304\|N=3072" | cut -c1-100 | tee -a "$f"
 done; done
