@@ -20,7 +20,7 @@ OBJ = os.path.join(HERE, 'build' + ('_' + _TAG if _TAG else ''))
 LIB = os.path.join(HERE, 'libse_amd' + ('.' + _TAG if _TAG else '') + '.so')
 ARCH = 'gfx950'
 FLAGS = ['-O3', '-std=c++17', '-fPIC', f'--offload-arch={ARCH}', '-fno-gpu-rdc', '-Wall', '-Wno-unused-function',
-         '-Wno-comment', '-I' + os.path.join(HERE, '..', 'include')]
+         '-Wno-comment', '-I' + os.path.join(HERE, '..', 'include'), '-I' + CSRC]
 if os.environ.get('SE_AMD_BUILD_STAMPS') == '1':       # developer build: in-kernel s_memtime stamps (tools/*_stamps.py); never for measurements
     FLAGS.append('-DSE_AMD_STAMPS')
 if os.environ.get('SE_AMD_EXTRA_DEFINES'):              # developer A/B builds, e.g. -DSE_AMD_OLD_CODEC
@@ -51,7 +51,12 @@ def _digest(paths):
 
 
 def sources():
-    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.hip'))
+    srcs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.hip'))
+    # SE_AMD_BUILD_EXPERIMENTS=<dir>[,<dir>]: developer builds that add the kernels parked under tools/experiments/<dir>/ (not part of the product library)
+    for exp in filter(None, os.environ.get('SE_AMD_BUILD_EXPERIMENTS', '').split(',')):
+        d = os.path.join(HERE, '..', 'tools', 'experiments', exp)
+        srcs += sorted(os.path.join(d, f) for f in os.listdir(d) if f.endswith('.hip'))
+    return srcs
 
 
 def build(force=False, jobs=None, verbose=True):
