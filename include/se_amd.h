@@ -342,10 +342,11 @@ int se_split3_bf16(const float* x, long ld, int rows, int cols, int Kp, int whic
  * Producers of the three-term operand (round 4): the bf16x3 mode's projections, LayerNorms and attention core hand their fp32 result to the next
  * projection already split -- [y1 | y1 | y2], row stride 3 Kp, se_split3_bf16's activation layout -- instead of writing fp32 rows that a separate
  * se_split3_bf16 pass reads back (14 % of that mode's pass).  Same S3PRL rows as the fp32 mode: nn.Linear (+ gelu) of the encoder layers (B2 / B3),
- * their LayerNorms, the attention core behind model.py:164.
+ * their LayerNorms, the attention core behind model.py:164.  Unlike se_split3_bf16 these producers write NO pad columns: Kp must EQUAL the slice width
+ * (N, H, heads * 64 respectively; SE_ERR_INVALID otherwise), so that the next projection's depth 3 Kp never sums over unwritten columns.
  *   se_gemm_x3out_bf16      out3 = split(act(A . W^T + bias)); A (M, K) / W (N, K) three-term operands (K = 3 x the layer's depth); act identity / GELU (erf)
  *   se_layernorm_x3_f32     out_f32 (may be NULL) = LayerNorm(x), out3 = split(LayerNorm(x)); H = 256, 512, 768, 1024
- *   se_mhsa_fwd_x3_split_f32  se_mhsa_fwd_x3_f32 with the context written as its split (Kp >= heads * 64)
+ *   se_mhsa_fwd_x3_split_f32  se_mhsa_fwd_x3_f32 with the context written as its split
  *   se_gemm_res_ln_x3_bf16  the row-complete projection + residual + LayerNorm launch of the bf16 path (se_gemm_res_ln_bf16, N = 768) on three-term
  *                           operands: out_f32 = LayerNorm(A . W^T + bias + residual_f32) (the next residual), out3 (M, 3 x 768) = its split --
  *                           the attention-output and FFN-output dense + LayerNorm of model.py's encoder layers in one launch

@@ -202,8 +202,9 @@ extern "C" int se_layernorm_x3_f32(const float* x, const float* w, const float* 
                                    void* stream) {
   SE_REQUIRE(x && w && b && out3 && M > 0, "se_layernorm_x3_f32: null argument");
   SE_REQUIRE(H == 768 || H == 256 || H == 512 || H == 1024, "se_layernorm_x3_f32: built for H = 256, 512, 768, 1024 (got %d)", H);
-  SE_REQUIRE(Kp >= H && Kp % 8 == 0 && (((uintptr_t)x | (uintptr_t)out_f32 | (uintptr_t)out3 | (uintptr_t)w | (uintptr_t)b) % 16) == 0,
-             "se_layernorm_x3_f32: Kp = %d must be >= H, a multiple of 8; buffers 16-B aligned", Kp);
+  // Kp == H: this producer writes columns [0, H) of each slice only; a wider slice would leave pad columns that the next projection sums over
+  SE_REQUIRE(Kp == H && Kp % 8 == 0 && (((uintptr_t)x | (uintptr_t)out_f32 | (uintptr_t)out3 | (uintptr_t)w | (uintptr_t)b) % 16) == 0,
+             "se_layernorm_x3_f32: Kp = %d must be == H (no pad columns: they are not written), a multiple of 8; buffers 16-B aligned", Kp);
   hipStream_t st = se::as_stream(stream);
   const dim3 grid((M + 3) / 4);
   switch (H) {

@@ -757,7 +757,8 @@ extern "C" int se_gemm_x3out_bf16(const uint16_t* A, int lda, const uint16_t* W,
                                   uint16_t* out3, int Kp, void* stream) {
   SE_REQUIRE(A && W && out3, "se_gemm_x3out_bf16: null argument");
   SE_REQUIRE(M > 0 && N > 0 && N % 4 == 0 && K % se::k6BK == 0 && K >= 2 * se::k6BK, "se_gemm_x3out_bf16: bad shape M=%d N=%d K=%d", M, N, K);
-  SE_REQUIRE(Kp >= N && Kp % 8 == 0 && lda >= K && ldw >= K && lda % 8 == 0 && ldw % 8 == 0, "se_gemm_x3out_bf16: bad leading dimensions");
+  // Kp == N: the epilogue writes columns [0, N) of each slice only (se_split3_bf16 zero-fills a pad, this producer does not: ADVICE r4)
+  SE_REQUIRE(Kp == N && Kp % 8 == 0 && lda >= K && ldw >= K && lda % 8 == 0 && ldw % 8 == 0, "se_gemm_x3out_bf16: bad leading dimensions (Kp must equal N = %d)", N);
   SE_REQUIRE((((uintptr_t)A | (uintptr_t)W | (uintptr_t)out3 | (uintptr_t)bias) % 16) == 0, "se_gemm_x3out_bf16: operands must be 16-B aligned");
   SE_REQUIRE(act == SE_ACT_IDENTITY || act == SE_ACT_GELU, "se_gemm_x3out_bf16: act %d (identity or GELU)", act);
   G6Args g{A, lda, W, ldw, bias, nullptr, M, N, K, out3, nullptr, 3 * Kp, se::as_stream(stream)};

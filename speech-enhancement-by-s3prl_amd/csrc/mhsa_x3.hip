@@ -287,7 +287,7 @@ extern "C" int se_mhsa_fwd_x3_split_f32(const float* qkv, const int32_t* lengths
   SE_REQUIRE(qkv && ctx3, "se_mhsa_fwd_x3_split_f32: null argument");
   SE_REQUIRE(B > 0 && B <= 65535 && T > 0 && heads > 0 && heads <= 65535, "se_mhsa_fwd_x3_split_f32: bad shape B=%d T=%d heads=%d", B, T, heads);
   const int H = heads * se::kHD;
-  SE_REQUIRE(Kp >= H && Kp % 8 == 0 && (((uintptr_t)qkv | (uintptr_t)ctx3) % 16) == 0, "se_mhsa_fwd_x3_split_f32: Kp = %d must be >= %d, a multiple of 8, buffers 16-B aligned", Kp, H);
+  SE_REQUIRE(Kp == H && Kp % 8 == 0 && (((uintptr_t)qkv | (uintptr_t)ctx3) % 16) == 0, "se_mhsa_fwd_x3_split_f32: Kp = %d must be == %d (no pad columns: they are not written), a multiple of 8, buffers 16-B aligned", Kp, H);
   dim3 grid((T + se::kAQ - 1) / se::kAQ, heads, B);
   hipLaunchKernelGGL(se::mhsa_x3_kernel, grid, dim3(256), 0, se::as_stream(stream), qkv, lengths, T, H, (float*)nullptr, ctx3, Kp);
   SE_LAUNCH_CHECK();

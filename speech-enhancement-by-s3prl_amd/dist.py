@@ -30,10 +30,30 @@ def shard_indices(n_items, rank=None, world=None):
     return list(range(rank, n_items, world))
 
 
+def _host_staged(t):
+    """gloo moves HOST memory; handed a device tensor, ProcessGroupGloo stages it through pinned memory on worker threads and streams of its own --
+    the path on which the four-rank one-device rehearsal hung with two or more collectives queued (profiles/r04_gloo_4rank/).  This module never
+    enters that path: on `backend == 'gloo'` every device tensor is staged HERE (device -> host, collective on the host tensor -- gloo's native mode,
+    the one tests/test_dist_gloo.py exercises at world 2 and 4 -- host -> device).  RCCL ('nccl') takes device tensors as they are."""
+    return t.is_cuda and dist.get_backend() == 'gloo'
+
+
+def all_reduce_(t, op=None):
+    """in-place all-reduce(sum) of `t` on the default group, through the host on gloo + device tensors"""
+    op = dist.ReduceOp.SUM if op is None else op
+    if _host_staged(t):
+        h = t.detach().cpu()                 # synchronises with the current stream: every kernel that wrote `t` is done
+        dist.all_reduce(h, op=op)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op)
+    return t
+
+
 def all_reduce_sums(sums):
     """reduce_fn for objective.L1: (sum |.|, count) -> global sums (in place, returns the tensor)."""
     if is_distributed():
-        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+        all_reduce_(sums)
     return sums
 
 
@@ -49,7 +69,12 @@ def broadcast_parameters(module, src=0):
         by_type.setdefault((t.dtype, t.device), []).append(t)
     for group in by_type.values():
         flat = torch.cat([t.reshape(-1) for t in group])
-        dist.broadcast(flat, src=src)
+        if _host_staged(flat):
+            h = flat.cpu()
+            dist.broadcast(h, src=src)
+            flat.copy_(h)
+        else:
+            dist.broadcast(flat, src=src)
         off = 0
         for t in group:
             t.copy_(flat[off:off + t.numel()].view_as(t))
@@ -120,7 +145,7 @@ class FlatGradAllReducer:
         self._gather(skip=done)
         if is_distributed():
             if not done:
-                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+                all_reduce_(self.flat)
             else:
                 rest = [i for i in range(len(self.params)) if i not in done]
                 lo = None
@@ -128,7 +153,7 @@ class FlatGradAllReducer:
                     if lo is not None and (i is None or i != prev + 1):
                         a = sink.offsets[lo]
                         b = sink.offsets[prev] + self.params[prev].numel()
-                        dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM)
+                        all_reduce_(self.flat[a:b])
                         lo = None
                     if i is not None and lo is None:
                         lo = i
@@ -163,14 +188,22 @@ class BucketedGradSink:
         self.handles = []
         self.done = set()
         self.buckets = self.collectives = 0          # of the last step (tests read them)
+        self.launch_stream = None                    # the stream the backward kernels are enqueued on (set by the engine around its C call)
+        self._staged = []                            # gloo + device tensors: (lo, hi, device -> host copy done) of every bucket of this step
+        self._host = self._stage_stream = None
 
     def begin(self):
-        self.handles, self.done = [], set()
+        self.handles, self.done, self._staged = [], set(), []
         self.buckets = self.collectives = 0
 
     def view(self, p):
         e = self.by_param.get(id(p))
         return None if e is None else e[1]
+
+    def _stream(self):
+        """where the bucket's kernels were launched: the stream the engine handed to se_encoder_bwd_cb_bf16 (the callback runs on the
+        autograd worker thread, whose current stream need not be that one), else the calling thread's current stream"""
+        return self.launch_stream if self.launch_stream is not None else torch.cuda.current_stream(self.reducer.flat.device)
 
     def bucket_done(self, params):
         idx = sorted(self.by_param[id(p)][0] for p in params if id(p) in self.by_param)
@@ -180,6 +213,7 @@ class BucketedGradSink:
         self.buckets += 1
         if not is_distributed():
             return
+        flat = self.reducer.flat
         # contiguous runs of parameter indices = contiguous slices of the flat buffer
         run = [idx[0]]
         for i in idx[1:] + [None]:
@@ -188,34 +222,51 @@ class BucketedGradSink:
                 continue
             lo = self.offsets[run[0]]
             hi = self.offsets[run[-1]] + self.reducer.params[run[-1]].numel()
-            # ORDERING.  The backward kernels of this layer were enqueued on torch's current stream (the stream handed to
-            # se_encoder_bwd_cb_bf16) before this callback ran; both backends order the collective behind them by an EVENT on that stream, not by
-            # anything this class does: ProcessGroupNCCL records an event on the current stream and makes its internal RCCL stream wait for it,
-            # ProcessGroupGloo does the same for the stream its device -> pinned-host staging copy runs on.  The event recorded here states that
-            # dependency explicitly (and keeps it true should the callback ever fire from another stream): the collective is issued from a stream
-            # that has waited for every launch of the bucket.
-            if self.reducer.flat.is_cuda:
+            if _host_staged(flat):
+                # gloo rehearsal on device tensors: the bucket leaves for a pinned host buffer NOW, on a side stream behind an event recorded on
+                # the launch stream (the copy runs under the backward of the layers still to come); the host all-reduces of ALL buckets are issued
+                # together in wait(), where gloo sees host tensors only.  No cap on the buckets in flight any more.
+                if self._host is None:
+                    self._host = torch.empty(flat.numel(), dtype=flat.dtype, pin_memory=True)
+                    self._stage_stream = torch.cuda.Stream(device=flat.device)
                 ev = torch.cuda.Event()
-                ev.record(torch.cuda.current_stream(self.reducer.flat.device))
-                torch.cuda.current_stream(self.reducer.flat.device).wait_event(ev)
-            self.handles.append(dist.all_reduce(self.reducer.flat[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
-            # gloo on DEVICE tensors (the several-ranks-on-one-GPU rehearsal, bench.py --one-device --backend gloo): the first four-rank run HUNG with
-            # seven bucket all-reduces in flight -- every rank's main thread inside the tail all_reduce of FlatGradAllReducer.reduce (Python stacks
-            # only; the watchdog output was not kept and gloo's worker threads are native, so what THEY were blocked on is not known: DESIGN
-            # section 7).  Three ranks pass, and four pass when at most `SE_DP_GLOO_INFLIGHT` (default 1) buckets are in flight.  The cause is NOT
-            # established; this cap is a workaround confined to that backend.  RCCL enqueues its collectives on one stream in issue order and
-            # keeps the full overlap.
-            if dist.get_backend() == 'gloo' and self.reducer.flat.is_cuda:
-                cap = max(1, int(os.environ.get('SE_DP_GLOO_INFLIGHT', '1')))
-                while len(self.handles) >= cap + 1 or (cap == 1 and self.handles):
-                    self.handles.pop(0).wait()
-            elif os.environ.get('SE_DP_BUCKET_SYNC') == '1':
+                ev.record(self._stream())
+                self._stage_stream.wait_event(ev)
+                with torch.cuda.stream(self._stage_stream):
+                    self._host[lo:hi].copy_(flat[lo:hi], non_blocking=True)
+                    done_ev = torch.cuda.Event()
+                    done_ev.record(self._stage_stream)
+                self._staged.append((lo, hi, done_ev))
+            elif flat.is_cuda:
+                # RCCL: ProcessGroupNCCL orders the collective behind an event it records on the CURRENT stream at the call -- issue it with the
+                # launch stream current, so that event covers every kernel of the bucket whichever thread the callback fires on
+                with torch.cuda.stream(self._stream()):
+                    self.handles.append(dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+            else:
+                self.handles.append(dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+            if os.environ.get('SE_DP_BUCKET_SYNC') == '1' and self.handles:
                 self.handles.pop().wait()
             self.collectives += 1
             if i is not None:
                 run = [i]
 
     def wait(self):
+        if self._staged:
+            flat = self.reducer.flat
+            handles = []
+            for lo, hi, done_ev in self._staged:          # same order on every rank (the backward's layer order)
+                done_ev.synchronize()
+                handles.append(dist.all_reduce(self._host[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+            for h in handles:
+                h.wait()
+            cur = torch.cuda.current_stream(flat.device)
+            with torch.cuda.stream(self._stage_stream):
+                for lo, hi, _ in self._staged:
+                    flat[lo:hi].copy_(self._host[lo:hi], non_blocking=True)
+                back = torch.cuda.Event()
+                back.record(self._stage_stream)
+            cur.wait_event(back)                          # whoever reads the reduced gradients next does so on the current stream
+            self._staged = []
         for h in self.handles:
             h.wait()
         self.handles = []

@@ -8,6 +8,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
+from .checkpoint import load_checkpoint
 from .preprocessor import OnlinePreprocessor
 from .transformer import TRANSFORMER, TransformerConfig, TransformerSpecPredictionHead
 
@@ -138,7 +139,7 @@ class SpecHead(nn.Module):
     def __init__(self, output_size, ckpt, activation='ReLU', random_init=False, eps=1e-6, **kwargs):
         super().__init__()
         assert ckpt != ''
-        ckpt = torch.load(ckpt, map_location='cpu') if isinstance(ckpt, str) else ckpt
+        ckpt = load_checkpoint(ckpt) if isinstance(ckpt, str) else ckpt
         trans_config = TransformerConfig(ckpt['Settings']['Config'])
         trans_spechead = TransformerSpecPredictionHead(trans_config, output_size)
         trans_spechead.load_state_dict(ckpt['SpecHead'])
@@ -177,7 +178,7 @@ class Mockingjay(nn.Module):
         super().__init__()
         options = {'ckpt_file': dckpt, 'load_pretrain': 'True', 'no_grad': 'False', 'dropout': 'default', 'spec_aug': 'False',
                    'spec_aug_prev': 'True', 'weighted_sum': 'False', 'select_layer': -1, 'permute_input': 'False'}
-        ckpt = torch.load(dckpt, map_location='cpu')
+        ckpt = load_checkpoint(dckpt)
         pretrain_config = ckpt['Settings']['Config']
         online = pretrain_config['online']
         # feature dims without running the (GPU-only) preprocessor: D = base * (1 + delta)

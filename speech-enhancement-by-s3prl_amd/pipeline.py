@@ -6,6 +6,7 @@ import copy
 import torch
 
 from . import decode
+from .checkpoint import reference_paras
 from .heads import SpecHead
 from .objective import L1
 from .preprocessor import OnlinePreprocessor
@@ -70,7 +71,8 @@ def synthetic_checkpoint(config=None, seed=0, inp_dim=80, spec_out=201):
     """An in-memory checkpoint with the S3PRL layout the reference reads (model.py:98-108,144-153)."""
     config = config or make_config()
     sd, head = random_upstream_states(config, inp_dim, spec_out, seed)
-    return {'Settings': {'Config': config, 'Paras': None}, 'Transformer': sd, 'SpecHead': head}
+    # Settings.Paras is the argparse.Namespace of the writing run in every file S3PRL / the reference saves (runner.py:136)
+    return {'Settings': {'Config': config, 'Paras': reference_paras(downstream='SpecHead')}, 'Transformer': sd, 'SpecHead': head}
 
 
 def build_upstream(ckpt, device):

@@ -293,11 +293,17 @@ class OnlinePreprocessor(nn.Module):
         # contiguous fp32 on the device: the lazy phase is tied to that buffer's contents.  A caller that refills the buffer in place (a static graph
         # input, wavs.copy_(next_batch)) before reading the phase would get the phase of ANOTHER batch next to this call's `linear` planes: the
         # version counter recorded here turns that into an error; `lazy_phase = False` restores the eager, self-contained result.
-        ver0 = wavs3._version
+        # Tensors created under torch.inference_mode() track no version counter (reading `_version` raises): the lazy phase is then tied to a private
+        # clone of the batch instead -- one device copy, only on that path.
+        if wavs3.is_inference():
+            wavs3 = wavs3.clone()
+            ver0 = None
+        else:
+            ver0 = wavs3._version
         for ch in chans:
             if 'phase' in need[ch]:
                 def materialize(ch=ch):
-                    if wavs3._version != ver0:
+                    if ver0 is not None and wavs3._version != ver0:
                         raise RuntimeError('LazyPhase: the waveform batch this phase belongs to was modified in place after preprocessor(wavs) returned '
                                            '(version %d -> %d); read the phase before re-using the input buffer, or set preprocessor.lazy_phase = False'
                                            % (ver0, wavs3._version))
@@ -399,7 +405,8 @@ class OnlinePreprocessor(nn.Module):
             side = getattr(feat, '_se_side', None)
             feat = feat.reshape(*lead, *feat.shape[-2:]).to(home)
             if side is not None:
-                feat._se_side = side + (feat._version,)           # (bf16 rows, valid-frame counts, version the pair belongs to)
+                if not feat.is_inference():                       # inference tensors track no version: no hand-off, the encoder recomputes its operand
+                    feat._se_side = side + (feat._version,)       # (bf16 rows, valid-frame counts, version the pair belongs to)
             done[key] = feat
             feats.append(feat)
         return feats

@@ -27,6 +27,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
+from .checkpoint import load_checkpoint
 from .preprocessor import OnlinePreprocessor
 
 
@@ -231,10 +232,13 @@ class _EncoderTrainFn(torch.autograd.Function):
                 except BaseException as e:    # noqa: BLE001
                     errors.append(e)
             cb = _lib.LAYER_DONE_CB(_done)
+            sink.launch_stream = torch.cuda.current_stream(dev)      # = _lib.stream() below: the stream the buckets' kernels are enqueued on
         _lib.check(lib.se_encoder_bwd_cb_bf16(h, _lib.ptr(ctx.lengths), B, T, _lib.ptr(d_hidden), _lib.ptr(saved), saved.numel(), gs,
                                               _lib.ptr(ws), nws, ctx.dropout[0], ctx.dropout[1], cb, None, _lib.stream()), 'se_encoder_bwd_bf16')
-        if sink is not None and errors:
-            raise errors[0]
+        if sink is not None:
+            sink.launch_stream = None
+            if errors:
+                raise errors[0]
         ctx.buf = None
         grads = [ghead[k] for k in ('in_w', 'in_b', 'in_ln_w', 'in_ln_b')]
         for k in _TRUNK_FIELDS:
@@ -466,7 +470,12 @@ class _Engine:
         out = torch.empty(N, 3 * Kp, device=w.device, dtype=torch.bfloat16)
         _lib.check(lib.se_split3_bf16(_lib.ptr(w), K, N, K, Kp, 1, _lib.ptr(out), _lib.stream()), 'se_split3_bf16')
         import weakref
-        cache[key] = (ver, out, Kp, tuple(weakref.ref(t) for t in ws))
+
+        def _evict(_dead, cache=cache, key=key):
+            # a source tensor died (parameter replaced, checkpoint reloaded): drop its split instead of keeping (N, 3 Kp) bf16 on the device for the
+            # engine's lifetime; a later tensor that reuses the id() installs a fresh entry
+            cache.pop(key, None)
+        cache[key] = (ver, out, Kp, tuple(weakref.ref(t, _evict) for t in ws))
         return out, Kp
 
     def _linear3(self, x, weight, bias, M, N, K, act=0, residual=None, out=None):
@@ -668,7 +677,8 @@ class _Engine:
                                             _lib.stream()), 'se_encoder_fwd2_bf16')
         # the call's last launch left the bf16 copy of `hidden` in this workspace: the spec head that follows (model.py:164-165) can skip its
         # conversion pass as long as it is handed exactly this tensor, unmodified, on the same workspace
-        _LAST_ENCODE[(feats.device.index, torch.cuda.current_stream(feats.device).cuda_stream)] = (weakref.ref(hidden), hidden._version, B, T, H_, ws)
+        if not hidden.is_inference():        # (inference tensors track no version counter: no hand-off, the spec head re-casts its input)
+            _LAST_ENCODE[(feats.device.index, torch.cuda.current_stream(feats.device).cuda_stream)] = (weakref.ref(hidden), hidden._version, B, T, H_, ws)
         return hidden
 
     @staticmethod
@@ -727,7 +737,7 @@ class TRANSFORMER(nn.Module):
             self.all_states = None
             self.config = config
         else:
-            self.all_states = torch.load(options['ckpt_file'], map_location='cpu')
+            self.all_states = load_checkpoint(options['ckpt_file'])
             self.config = self.all_states['Settings']['Config']
         self.no_grad = _str2bool(options.get('no_grad', 'False'))
         self.spec_aug = _str2bool(options.get('spec_aug', 'False'))

@@ -32,6 +32,7 @@ def _train_steps(model, opt, pre, batches, gpu, criterion):
 @pytest.mark.parametrize('kind', ['LinearResidual', 'LSTM'])
 def test_checkpoint_roundtrip_resumes_identically(gpu, tmp_path, kind):
     from speech_enhancement_by_s3prl_amd import pipeline, synth
+    from speech_enhancement_by_s3prl_amd.checkpoint import load_checkpoint, reference_paras
     from speech_enhancement_by_s3prl_amd.heads import LinearResidual
     from speech_enhancement_by_s3prl_amd.lstm import LSTM
     from speech_enhancement_by_s3prl_amd.objective import L1, SISDR
@@ -56,13 +57,16 @@ def test_checkpoint_roundtrip_resumes_identically(gpu, tmp_path, kind):
     global_step = 4
     # ---- Runner.save_model (runner.py:129-151)
     all_states = {'Downstream': model.state_dict(), 'Optimizer': opt.state_dict(), 'Global_step': global_step,
-                  'Settings': {'Config': {'runner': {'learning_rate': '2e-4'}, 'model': {kind: {}}}, 'Paras': None}}
+                  'Settings': {'Config': {'runner': {'learning_rate': '2e-4'}, 'model': {kind: {}}}, 'Paras': reference_paras(downstream=kind)}}
     path = str(tmp_path / f'states-{global_step}.ckpt')
     torch.save(all_states, path)
     # the uninterrupted run goes on
     cont = _train_steps(model, opt, pre, batches[3:], gpu, crit)
     # ---- resume (run_downstream.py:94-106 picks the newest states-*.ckpt; Runner.load_model, runner.py:122-126): FRESH objects
-    ckpt = torch.load(path, map_location='cpu', weights_only=True)      # tensors, numbers, dicts only: nothing is executed from the file
+    with pytest.raises(Exception):                  # what the reference's own call does under torch >= 2.6: the Namespace is refused
+        torch.load(path, map_location='cpu', weights_only=True)
+    ckpt = load_checkpoint(path)                    # the product's loader: weights-only + argparse.Namespace allow-listed, nothing is executed
+    assert ckpt['Settings']['Paras'].downstream == kind       # run_downstream.py:206
     assert sorted(ckpt) == ['Downstream', 'Global_step', 'Optimizer', 'Settings'] and ckpt['Global_step'] == global_step
     model2, opt2, crit2 = make()
     with torch.no_grad():                           # make sure the reload, not the seed, provides the parameters

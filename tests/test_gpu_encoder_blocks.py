@@ -365,3 +365,55 @@ def test_gemm_res24_pair_exchange_vs_single_tile(gpu, M, K):
     # the low bytes (same tile-major positions in both kernels) differ by at most one step where the values are a few 1e-6 apart
     d = (l8.view(torch.int8).int() - l7.view(torch.int8).int()).abs()
     assert (d <= 1).float().mean().item() > 0.99
+
+
+def test_gemm6_dual_gelu_launch_bit_identical_to_the_two_launches(gpu):
+    """gemm6.hip: se_gemm6_dual_gelu_launch (the training forward's FFN1: pre-activation AND its GELU from one persistent launch; reached from
+    encoder_train.hip only above 256 tiles, i.e. never by the small-shape training tests -- ADVICE r4): a ragged last row tile (8192 + 37 rows),
+    both outputs in separate allocations with guard rows, bit-identical to se_gemm_bf16(identity) followed by se_gelu_bf16."""
+    import ctypes
+    L = _lib()
+    lib = L.load()
+    fn = lib.se_gemm6_dual_gelu_launch
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    M, N, K = 8192 + 37, 3072, 768
+    torch.manual_seed(5)
+    A = torch.randn(M, K, device=gpu).bfloat16()
+    W = (torch.randn(N, K, device=gpu) * 0.05).bfloat16()
+    bias = torch.randn(N, device=gpu)
+    pre = torch.full((M + 8, N), 3.0, device=gpu, dtype=torch.bfloat16)
+    act = torch.full((M + 8, N), 5.0, device=gpu, dtype=torch.bfloat16)
+    assert fn(L.ptr(A), K, L.ptr(W), K, L.ptr(bias), M, N, K, L.ptr(pre), L.ptr(act), N, L.stream()) == 0
+    _, ref_pre = gemm(A, W, bias, None, 0, 'bf16')
+    ref_act = torch.empty_like(ref_pre)
+    L.check(lib.se_gelu_bf16(L.ptr(ref_pre), ref_pre.numel(), L.ptr(ref_act), L.stream()), 'se_gelu_bf16')
+    torch.cuda.synchronize()
+    assert torch.equal(pre[:M], ref_pre) and torch.equal(act[:M], ref_act)
+    assert torch.all(pre[M:] == 3.0) and torch.all(act[M:] == 5.0)
+    # and against the fp64 product, so that the reference path is not the only witness
+    ref = A[:512].double() @ W.double().T + bias.double()
+    assert (pre[:512].double() - ref).abs().max().item() < 8e-3 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize('res,out', [(False, 'bf16'), (True, 'f32'), (False, 'f32')])
+def test_gemm_bf16_large_m_n768_dispatch_vs_fp64(gpu, res, out):
+    """se_gemm_bf16 at M > 20 352, N = 768, K = 3072: the dispatcher's >= 160-row-tile route (the row-complete kernel without its LayerNorm,
+    gemm4.hip) that only the fine-tune bench reached -- with / without residual, fp32 / bf16 rows, against the fp64 product."""
+    M, N, K = 20352 + 131, 768, 3072
+    torch.manual_seed(9)
+    A = torch.randn(M, K, device=gpu).bfloat16()
+    W = (torch.randn(N, K, device=gpu) * 0.03).bfloat16()
+    bias = torch.randn(N, device=gpu)
+    r = torch.randn(M, N, device=gpu) if res else None
+    o32, o16 = gemm(A, W, bias, r, 0, out)
+    got = o32 if out == 'f32' else o16
+    worst = 0.0
+    for lo in range(0, M, 4096):
+        hi = min(M, lo + 4096)
+        ref = A[lo:hi].double() @ W.double().T + bias.double()
+        if res:
+            ref = ref + r[lo:hi].double()
+        worst = max(worst, (got[lo:hi].double() - ref).abs().max().item() / ref.abs().max().item())
+    assert worst < (8e-3 if out == 'bf16' else 5e-5), worst

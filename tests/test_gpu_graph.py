@@ -46,3 +46,25 @@ def test_two_stream_enhance_step_matches_single_stream(gpu):
         assert (got_pred - ref_pred).abs().max().item() <= 1e-5 * ref_pred.abs().max().item()
         assert (got_wav - ref_wav).abs().max().item() <= 1e-5 * ref_wav.abs().max().item()
         assert abs(got_loss.item() - ref_loss.item()) <= 1e-6 * abs(ref_loss.item())
+
+
+def test_enhance_step_under_inference_mode_matches_no_grad(gpu):
+    """the whole evaluate()-style pass under torch.inference_mode(): the library's tensor hand-offs key on version counters, which inference tensors do
+    not have (the preprocessor raised) -- the pass must run there and give the no_grad results"""
+    from speech_enhancement_by_s3prl_amd import pipeline, synth
+    cfg = pipeline.make_config(layers=2)
+    ckpt = pipeline.synthetic_checkpoint(cfg, seed=2)
+    up = pipeline.build_upstream(ckpt, gpu)
+    pre = pipeline.build_preprocessor(cfg, gpu)
+    step = pipeline.UpstreamEnhanceStep(pre, up)
+    lengths, wavs = synth.fast_batch(2, 32000, seed=5, device=gpu)
+    with torch.no_grad():
+        ref_wav, ref_loss, ref_pred = [t.clone() for t in step(wavs, lengths, 32000)]
+    with torch.inference_mode():
+        w2, l2 = wavs.clone(), lengths.clone()
+        got_wav, got_loss, got_pred = step(w2, l2, 32000)
+        got_wav, got_loss, got_pred = got_wav.clone(), got_loss.clone(), got_pred.clone()
+    torch.cuda.synchronize()
+    assert torch.equal(got_pred, ref_pred)
+    assert (got_wav - ref_wav).abs().max().item() <= 1e-6 * ref_wav.abs().max().item()
+    assert abs(got_loss.item() - ref_loss.item()) <= 1e-6 * abs(ref_loss.item())

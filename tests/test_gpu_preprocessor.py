@@ -319,3 +319,24 @@ def test_lazy_phase_is_tied_to_the_input_buffer(P, gpu):
         assert torch.isfinite(e[3]).all() and e[3].abs().max().item() > 1.0      # eager phase: a plain tensor, self-contained
     finally:
         P.lazy_phase = True
+
+
+def test_preprocessor_under_inference_mode(P, gpu):
+    """tensors created under torch.inference_mode() track no version counter (reading `_version` raises): the fused STFT path must work there too
+    (it raised for every caller that evaluates under inference_mode) -- the lazy phase is tied to a private copy of the batch instead,
+    so an in-place refill of the caller's buffer cannot change it"""
+    torch.manual_seed(12)
+    P.channel_inp, P.channel_tar = 0, 1
+    host = torch.randn(2, 2, 16000) * 0.1
+    ref = P(host.to(gpu))
+    ref_phase = ref[3] + 0
+    with torch.inference_mode():
+        wavs = host.to(gpu)
+        assert wavs.is_inference()
+        f = P(wavs)
+        wavs.zero_()                                   # refill after the call: the lazy phase must still be this batch's
+        ph = f[3] + 0
+        wav = P.istft(f[2], f[3])
+    assert torch.equal(f[2], ref[2])
+    assert torch.equal(ph, ref_phase)
+    assert torch.equal(wav, P.istft(ref[2], ref[3]))
