@@ -303,12 +303,13 @@ int se_mhsa_fwd_bf16(const uint16_t* qkv, const int32_t* lengths, int B, int T, 
    fused QKV weights folds it into the query rows before their bf16 rounding), i.e. ctx = softmax_base2(Q' K^T + pad-mask) V: no
    per-score multiply in front of the exponential, and the running reference starts at 0 (csrc/mhsa.hip, PRE = 1).  Inference only. */
 int se_mhsa_fwd_prescaled_bf16(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, void* stream);
-/* Test / measurement surface: variant 0 = the kernel above, 1 = the software-pipelined half-tile experiment (csrc/mhsa_pipe.hip; measured
-   slower, off by default, SE_AMD_MHSA_PIPE=1 routes se_mhsa_fwd_prescaled_bf16 to it). */
+/* Test / measurement surface: the two kernels behind se_mhsa_fwd_prescaled_bf16 by number -- variant 0 = csrc/mhsa.hip (4-wave workgroups, the default
+   below 768 workgroups), 10 = csrc/mhsa8.hip (8-wave workgroups on one LDS-DMA staged tile, the default from there on); bit-identical results.  Other
+   numbers are the parked experiments of tools/experiments/kernels/ (developer builds only): SE_ERR_UNSUPPORTED in the product library. */
 int se_mhsa_fwd_prescaled_variant_bf16(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, int variant, void* stream);
 /* Row-complete projection on the encoder's 24-bit residual stream (bf16 hi rows + int8 lo bytes, tile-major: csrc/gemm4.hip), exported for
  * tests / measurement: x = LayerNorm(A . W^T + bias + residual), out as fp32 rows or as (bf16, lo).  variant 0 = the encoder's dispatch,
- * 7 = 128 x 768 tiles, 8 = 256 x 384 tiles with the LayerNorm statistics exchanged between the two column halves (csrc/gemm8.hip).
+ * 7 = 128 x 768 tiles (8 = the parked 256 x 384 pair-exchange experiment: SE_ERR_UNSUPPORTED in the product library).
  * scratch: se_gemm_res24_scratch_bytes() zeroed bytes; lo buffers: se_gemm_res24_lo_bytes(M) bytes. */
 size_t se_gemm_res24_scratch_bytes(void);
 size_t se_gemm_res24_lo_bytes(int M);
@@ -419,17 +420,6 @@ int se_mhsa_fwd_lse_bf16(const uint16_t* qkv, const int32_t* lengths, int B, int
 /* flash MHSA backward: d_ctx (B*T, H) bf16 -> dqkv (B*T, 3H) bf16 = [dQ | dK | dV]; dvec (B, heads, T) fp32 scratch */
 int se_mhsa_bwd_bf16(const uint16_t* qkv, const uint16_t* ctx, const uint16_t* d_ctx, const float* lse, const int32_t* lengths,
                      int B, int T, int heads, uint16_t* dqkv, float* dvec, float dropout_p, uint64_t seed, uint32_t site, void* stream);
-/* The same attention dropout mask (csrc/dropout.h: keep(pair, h) of (seed, site); reference: attention_probs_dropout_prob,
- * pretrain_sample.yaml:10) evaluated ONCE per layer and step as two bit matrices (csrc/dropmask.hip: mask_r query-major for the forward
- * and the dQ kernel, mask_c key-major for the dK / dV kernel) instead of being re-hashed inside each of the three attention kernels.
- * se_mhsa_dropmask_bytes(which = 0: mask_r, 1: mask_c); buffers 16-B aligned. */
-size_t se_mhsa_dropmask_bytes(int B, int T, int heads, int which);
-int se_mhsa_dropmask(int B, int T, int heads, float dropout_p, uint64_t seed, uint32_t site, uint32_t* mask_r, uint32_t* mask_c, void* stream);
-int se_mhsa_fwd_lse_masked_bf16(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, float* lse,
-                                const uint32_t* mask_r, float dropout_p, void* stream);
-int se_mhsa_bwd_masked_bf16(const uint16_t* qkv, const uint16_t* ctx, const uint16_t* d_ctx, const float* lse, const int32_t* lengths,
-                            int B, int T, int heads, uint16_t* dqkv, float* dvec, const uint32_t* mask_r, const uint32_t* mask_c,
-                            float dropout_p, void* stream);
 /* y = gelu(x) and dx = dy * gelu'(x), bf16 arrays of n elements (n % 8 == 0) */
 int se_gelu_bf16(const uint16_t* x, size_t n, uint16_t* y, void* stream);
 int se_gelu_bwd_bf16(const uint16_t* dy, const uint16_t* x, size_t n, uint16_t* dx, void* stream);

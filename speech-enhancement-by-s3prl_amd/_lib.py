@@ -10,6 +10,8 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64
 
 import torch
 
+from . import checkpoint as _checkpoint      # noqa: F401  (registers argparse.Namespace with torch's weights-only unpickler: checkpoint.py)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SE_AMD_LIB: developer switch for A/B and stamp builds (tools/): another build of the SAME library; never a fallback
 LIB_PATH = os.environ.get('SE_AMD_LIB') or os.path.join(_HERE, 'libse_amd.so')
@@ -118,10 +120,6 @@ SIGNATURES = {
     'se_spec_epilogue_bwd_f32': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_float, _P, _P, _P]),
     'se_mhsa_fwd_lse_bf16': (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, c_float, ctypes.c_uint64, ctypes.c_uint32, _P]),
     'se_mhsa_bwd_bf16': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, c_float, ctypes.c_uint64, ctypes.c_uint32, _P]),
-    'se_mhsa_dropmask_bytes': (ctypes.c_size_t, [c_int, c_int, c_int, c_int]),
-    'se_mhsa_dropmask': (c_int, [c_int, c_int, c_int, c_float, ctypes.c_uint64, ctypes.c_uint32, _P, _P, _P]),
-    'se_mhsa_fwd_lse_masked_bf16': (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, c_float, _P]),
-    'se_mhsa_bwd_masked_bf16': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, c_float, _P]),
     'se_gelu_bf16': (c_int, [_P, c_size_t, _P, _P]),
     'se_gelu_bwd_bf16': (c_int, [_P, _P, c_size_t, _P, _P]),
     'se_encoder_refresh_bf16': (c_int, [_P, POINTER(EncoderWeights), _P]),

@@ -23,6 +23,8 @@ FLAGS = ['-O3', '-std=c++17', '-fPIC', f'--offload-arch={ARCH}', '-fno-gpu-rdc',
          '-Wno-comment', '-I' + os.path.join(HERE, '..', 'include'), '-I' + CSRC]
 if os.environ.get('SE_AMD_BUILD_STAMPS') == '1':       # developer build: in-kernel s_memtime stamps (tools/*_stamps.py); never for measurements
     FLAGS.append('-DSE_AMD_STAMPS')
+if os.environ.get('SE_AMD_BUILD_EXPERIMENTS'):           # developer builds with the parked kernels of tools/experiments/<dir>/: their call sites are compiled in
+    FLAGS.append('-DSE_AMD_EXPERIMENTS')
 if os.environ.get('SE_AMD_EXTRA_DEFINES'):              # developer A/B builds, e.g. -DSE_AMD_OLD_CODEC
     FLAGS.extend(os.environ['SE_AMD_EXTRA_DEFINES'].split())
 # per-file extra flags.  The flash attention forward and the STFT / iSTFT are VALU-issue bound and v_pk_*_f32 (what the SLP vectoriser

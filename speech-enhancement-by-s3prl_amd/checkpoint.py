@@ -4,18 +4,31 @@ A `states-*.ckpt` of the reference (`runner.py:129-151`) and an S3PRL upstream c
 tensors, numbers, strings and nested dicts -- plus ONE object: `Settings.Paras`, the `argparse.Namespace` of the run that wrote the file
 (`runner.py:136`; read back at `run_downstream.py:104, 206`).  torch's weights-only unpickler (the default of `torch.load` from 2.6 on) refuses that
 class, so a plain `torch.load(path)` raises on every file the reference or S3PRL ever wrote.  `load_checkpoint` allow-lists exactly that class for
-the duration of the call: still a no-code loader (`weights_only=True`; a Namespace is rebuilt from its `__dict__`, no function of the file runs).
+the process (see allow_reference_checkpoints): still a no-code loader (`weights_only=True`; a Namespace is rebuilt from its `__dict__`, no function of the file runs).
 """
 import argparse
 
 import torch
 
 
+def allow_reference_checkpoints():
+    """The reference's scripts call `torch.load(path, map_location='cpu')` themselves (`run_downstream.py:103, 127, 137, 181, 199`, `runner.py:123`,
+    `model.py:98, 143`); under torch >= 2.6 that call refuses the `argparse.Namespace` every one of its checkpoints holds.  Importing any product
+    module (the S3PRL import paths of `s3prl_compat/` included) registers that one class with torch's weights-only unpickler, process-wide, so that
+    those call sites keep working unchanged under `run_downstream.py`.  Still nothing of a file is executed: a Namespace is a plain attribute bag."""
+    torch.serialization.add_safe_globals([argparse.Namespace])
+
+
+allow_reference_checkpoints()
+
+
 def load_checkpoint(path, map_location='cpu'):
     """`torch.load(path, map_location)` as the reference calls it (`run_downstream.py:103, 202`, `runner.py:122`, `model.py:98, 148`), restricted to
     tensors / containers / numbers / strings + `argparse.Namespace`."""
-    with torch.serialization.safe_globals([argparse.Namespace]):
-        return torch.load(path, map_location=map_location, weights_only=True)
+    # (not the `torch.serialization.safe_globals` context manager: leaving it REMOVES the class again, also when it had been registered before --
+    #  the process-wide registration below would be gone after the first call, and with it the reference's own torch.load call sites)
+    allow_reference_checkpoints()
+    return torch.load(path, map_location=map_location, weights_only=True)
 
 
 def reference_paras(downstream='LSTM', **overrides):

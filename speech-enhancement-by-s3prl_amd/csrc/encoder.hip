@@ -613,12 +613,14 @@ extern "C" int se_encoder_fwd2_bf16(const se_encoder* enc, const float* feats, c
   // the slower side; it is now 16 000 rows (B = 1: 8 workgroups, 0.85 vs 1.70 ms).  SE_AMD_FUSED_LN = 2 forces it.  Between its launches the residual stream travels as
   // bf16 + int8 (24 bits, gemm4.hip) instead of fp32 + bf16: 196 instead of 295 MB per K = 768 launch.
   const bool fused = fuse_env && H == 768 && I % 32 == 0 && I >= 128 && (fuse_env == 2 || M >= (enc->cfg.fused_ln_min_rows > 0 ? enc->cfg.fused_ln_min_rows : 16000));
+#ifdef SE_AMD_EXPERIMENTS
   static int use8 = -1;
   if (use8 < 0) { const char* e8 = getenv("SE_AMD_GEMM8"); use8 = e8 ? atoi(e8) : 0; }
   if (fused && use8) {      // gemm8's pair flags + error word start every pass at zero (each launch also leaves them zero); the kernel is off by default
     const size_t fo = se::gemm8_scratch_bytes() - (128 * 2 * 4 + 256);
     if ((rc = se::zero_async(w.g8 + fo, 128 * 2 * 4 + 256, st))) return rc;
   }
+#endif
   if (fused) {
     // one row-complete kernel: the positional table rides the residual input (row index modulo T)
     if ((rc = se::launch_gemm_pos_ln(w.xin, se::kInPad, enc->in_w, se::kInPad, enc->in_b, enc->pe, T, enc->in_ln_w, enc->in_ln_b, enc->cfg.ln_eps, M, H,
@@ -648,7 +650,10 @@ extern "C" int se_encoder_fwd2_bf16(const se_encoder* enc, const float* feats, c
       uint16_t* ob = w.x_bf;      // the last layer writes it too (next to the fp32 `hidden`): the spec head's operand, se_spechead_fwd2_bf16(x_bf_valid = 1)
       uint8_t* ol = (i == L - 1) ? nullptr : w.lo;
       // 256 x 384 tiles with the LayerNorm statistics exchanged between the two column halves (gemm8.hip) where it applies, else 128 x 768
+      rc = 1;
+#ifdef SE_AMD_EXPERIMENTS
       rc = se::launch_gemm8_res24_ln(w.h, I, y.ff2_w, I, y.ff2_b, w.x_bf, w.lo, y.oln_w, y.oln_b, enc->cfg.ln_eps, M, H, I, of, ob, ol, w.g8, st);
+#endif
       if (rc == 1) rc = se::launch_gemm_res24_ln(w.h, I, y.ff2_w, I, y.ff2_b, w.x_bf, w.lo, y.oln_w, y.oln_b, enc->cfg.ln_eps, M, H, I, of, ob, ol, st);
       if (rc) return rc;
     } else {

@@ -18,10 +18,14 @@ int launch_gemm_res24_ln(const uint16_t* A, int lda, const uint16_t* W, int ldw,
 size_t gemm4_lo_bytes(int M);
 // gemm8.hip: the K = 3072 projection on 256 x 384 tiles with the LayerNorm statistics exchanged between the two column halves; returns 1 when
 // the call is not for it (the caller then uses launch_gemm_res24_ln).  `scratch`: gemm8_scratch_bytes() bytes whose trailing flag words are zero
+#ifdef SE_AMD_EXPERIMENTS
 size_t gemm8_scratch_bytes();
 int launch_gemm8_res24_ln(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias, const uint16_t* res_hi, const uint8_t* res_lo,
                           const float* ln_w, const float* ln_b, float eps, int M, int N, int K, float* out_f32, uint16_t* out_bf16, uint8_t* out_lo,
                           void* scratch, hipStream_t st, int force = 0);
+#else
+inline size_t gemm8_scratch_bytes() { return 256; }      // the pair-exchange kernel (tools/experiments/kernels/gemm8.hip) is not part of the product library
+#endif
 int launch_gemm_gelu_ln(const uint16_t* A, int lda, const uint16_t* W, int ldw, const float* bias, const float* ln_w, const float* ln_b, float eps,
                         int M, int N, int K, float* out_f32, uint16_t* out_bf16, hipStream_t st);
 int launch_layernorm(const float* x, const float* pe, int T, const float* w, const float* b, int M, int H, float eps,

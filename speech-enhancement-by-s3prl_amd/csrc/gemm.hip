@@ -265,10 +265,14 @@ extern "C" int se_gemm_bf16(const uint16_t* A, int lda, const uint16_t* W, int l
       const int rc6 = se_gemm6_launch(A, lda, W, ldw, bias, residual_f32, M, N, K, act, out_bf16, out_f32, ldc, vec_ok, stream);
       if (rc6 <= 0) return rc6;
     }
+#ifdef SE_AMD_EXPERIMENTS
     if (use5 && N >= 1536) {
       const int rc5 = se_gemm5_launch(A, lda, W, ldw, bias, residual_f32, M, N, K, act, out_bf16, out_f32, ldc, vec_ok, stream);
       if (rc5 <= 0) return rc5;
     }
+#else
+    (void)use5;
+#endif
     const int rc = (N >= 1536) ? se_gemm3_launch(A, lda, W, ldw, bias, residual_f32, M, N, K, act, out_bf16, out_f32, ldc, vec_ok, stream) : 1;
     if (rc <= 0) return rc;
     return se_gemm2_launch(A, lda, W, ldw, bias, residual_f32, M, N, K, act, out_bf16, out_f32, ldc, vec_ok, 3, stream);

@@ -808,6 +808,13 @@ extern "C" int se_gemm_res24_ln_bf16(const uint16_t* A, int lda, const uint16_t*
                                      int variant, void* scratch, void* stream) {
   SE_REQUIRE(A && W && res_hi && res_lo && ln_w && ln_b && (out_f32 || out_bf16), "se_gemm_res24_ln_bf16: null argument");
   hipStream_t st = se::as_stream(stream);
+#ifndef SE_AMD_EXPERIMENTS
+  (void)scratch;
+  if (variant == 8) {
+    se::set_error("se_gemm_res24_ln_bf16: variant 8 (the 256 x 384 pair-exchange experiment) is not part of the product library");
+    return SE_ERR_UNSUPPORTED;
+  }
+#else
   if (variant == 0 || variant == 8) {
     const int rc = se::launch_gemm8_res24_ln(A, lda, W, ldw, bias, res_hi, res_lo, ln_w, ln_b, eps, M, N, K, out_f32, out_bf16, out_lo, scratch, st, variant == 8);
     if (rc != 1) return rc;
@@ -816,5 +823,6 @@ extern "C" int se_gemm_res24_ln_bf16(const uint16_t* A, int lda, const uint16_t*
       return SE_ERR_UNSUPPORTED;
     }
   }
+#endif
   return se::launch_gemm_res24_ln(A, lda, W, ldw, bias, res_hi, res_lo, ln_w, ln_b, eps, M, N, K, out_f32, out_bf16, out_lo, st);
 }

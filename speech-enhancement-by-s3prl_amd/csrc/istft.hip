@@ -315,7 +315,8 @@ extern "C" int se_istft_f32(const se_plan* plan, const float* power, const float
   return SE_OK;
 }
 
-// the experimental persistent kernel of istft2.hip (SE_AMD_STFT2=1; measured equal or slower)
+// the persistent kernel of istft2.hip: the path of log_input != 0 (log_predicted planes: exp in the load); as a replacement of the default kernel it
+// measured equal or slower (SE_AMD_STFT2=1 in experiment builds)
 extern "C" int se_istft2p_tphase_f32(const se_plan* plan, const float* power, const unsigned* tphase, int B, int F, int log_input,
                                      float* wav_out, int wav_stride, const int64_t* lengths, float* sumsq_out, void* stream);
 
@@ -328,7 +329,11 @@ extern "C" int se_istft_tphase_f32(const se_plan* plan, const float* power, cons
   SE_REQUIRE(wav_stride >= n_out, "se_istft_tphase_f32: wav_stride=%d < %d output samples", wav_stride, n_out);
   SE_REQUIRE(sumsq_out == nullptr || lengths != nullptr, "se_istft_tphase_f32: sumsq_out needs lengths");
   SE_REQUIRE(ref_sumsq_out == nullptr || (ref && sumsq_out && ref_stride >= n_out), "se_istft_tphase_f32: ref_sumsq_out needs ref (row stride >= %d) and sumsq_out", n_out);
+#ifdef SE_AMD_EXPERIMENTS
   static const bool use2 = getenv("SE_AMD_STFT2") != nullptr;
+#else
+  const bool use2 = false;
+#endif
   hipStream_t st = se::as_stream(stream);
   if (use2 || log_input) {
     int rc = se_istft2p_tphase_f32(plan, power, tphase, B, F, log_input, wav_out, wav_stride, lengths, sumsq_out, stream);

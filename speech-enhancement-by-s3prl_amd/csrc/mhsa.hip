@@ -410,13 +410,15 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OC
 
 }  // namespace se
 
+int se_mhsaN_fwd_launch(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, int never_speculate, int nw, int wpe, hipStream_t st);   // mhsa8.hip
+#ifdef SE_AMD_EXPERIMENTS      // the parked attention forwards (tools/experiments/kernels/, mhsa8.hip's other layouts): developer builds only
 int se_mhsa_fwd_pipe_launch(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, int occ, hipStream_t st);   // mhsa_pipe.hip
 int se_mhsa2_fwd_launch(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, int never_speculate, hipStream_t st);   // mhsa2.hip
 int se_mhsa3_fwd_launch(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, int never_speculate, hipStream_t st);   // mhsa3.hip
 int se_mhsa8_fwd_launch(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, int never_speculate, hipStream_t st);   // mhsa8.hip
 int se_mhsa9_fwd_launch(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, int never_speculate, hipStream_t st);   // mhsa9.hip
-int se_mhsaN_fwd_launch(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, int never_speculate, int nw, int wpe, hipStream_t st);   // mhsa8.hip
 int se_mhsaP_fwd_launch(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, int never_speculate, int wgs, hipStream_t st);   // mhsa8.hip
+#endif
 
 static int mhsa_fwd_launch(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, float* lse, float dropout_p,
                            uint64_t seed, uint32_t site, void* stream) {
@@ -454,23 +456,26 @@ static int mhsa_prescaled_launch(const uint16_t* qkv, const int32_t* lengths, in
   const int H = heads * se::kHD;
   dim3 grid((T + se::kAQ - 1) / se::kAQ, heads, B);
   se::ProfScope prof(se::kProfMhsa, 4.0 * B * (double)heads * T * (double)T * se::kHD, se::as_stream(stream));
+  static int spec = -1;
+  if (spec < 0) { const char* e = getenv("SE_AMD_MHSA_SPEC"); spec = e ? atoi(e) : 1; }      // 0: always the exact online-softmax tile (A/B)
+  // 10: 8 free-running waves on one LDS-DMA staged tile, two workgroups per CU, waves 4-7 half a tile behind (mhsa8.hip; the default from 768 workgroups on)
+  if (pipe == 10) return se_mhsaN_fwd_launch(qkv, lengths, B, T, heads, ctx, spec ? 0 : 1, 8, 4, se::as_stream(stream));
+#ifdef SE_AMD_EXPERIMENTS
   static int pipe_occ = -1;
   if (pipe_occ < 0) {
     const char* o = getenv("SE_AMD_MHSA_PIPE_OCC");
     pipe_occ = o ? atoi(o) : 2;
   }
   if (pipe == 1) return se_mhsa_fwd_pipe_launch(qkv, lengths, B, T, heads, ctx, pipe_occ, se::as_stream(stream));
-  static int spec = -1;
-  if (spec < 0) { const char* e = getenv("SE_AMD_MHSA_SPEC"); spec = e ? atoi(e) : 1; }      // 0: always the exact online-softmax tile (A/B)
   if (pipe == 12) return se_mhsa9_fwd_launch(qkv, lengths, B, T, heads, ctx, spec ? 0 : 1, se::as_stream(stream));      // 8 waves, software-pipelined over the key tiles (mhsa9.hip)
   if (pipe == 11 || pipe == 13 || pipe == 14)      // variant 10 as persistent workgroups (mhsa8.hip); 13 / 14: with 8 / 5 workgroups (tests: long item lists, both list forms)
     return se_mhsaP_fwd_launch(qkv, lengths, B, T, heads, ctx, spec ? 0 : 1, pipe == 11 ? 0 : (pipe == 13 ? 8 : 5), se::as_stream(stream));
-  if (pipe == 9 || pipe == 10 || pipe == 16) return se_mhsaN_fwd_launch(qkv, lengths, B, T, heads, ctx, spec ? 0 : 1, pipe == 16 ? 16 : 8, pipe == 9 ? 2 : 4, se::as_stream(stream));   // 8 / 16 free-running waves on one LDS-DMA staged tile (mhsa8.hip)
+  if (pipe == 9 || pipe == 16) return se_mhsaN_fwd_launch(qkv, lengths, B, T, heads, ctx, spec ? 0 : 1, pipe == 16 ? 16 : 8, pipe == 9 ? 2 : 4, se::as_stream(stream));
   if (pipe == 8) return se_mhsa8_fwd_launch(qkv, lengths, B, T, heads, ctx, spec ? 0 : 1, se::as_stream(stream));      // 8-wave alternating segments (mhsa8.hip)
   if (pipe == 3) return se_mhsa3_fwd_launch(qkv, lengths, B, T, heads, ctx, spec ? 0 : 1, se::as_stream(stream));      // interleaved matrix / vector stream, two query blocks per wave (mhsa3.hip)
   if (pipe == 2) return se_mhsa2_fwd_launch(qkv, lengths, B, T, heads, ctx, spec ? 0 : 1, se::as_stream(stream));      // two query blocks per wave (mhsa2.hip)
   static int dma = -1;
-  if (dma < 0) { const char* e = getenv("SE_AMD_MHSA_DMA"); dma = e ? atoi(e) : 0; }        // A/B: 1 LDS-DMA 2-slot ring, 2 three slots + two tiles in flight, 3 one-body ring at 4 waves per SIMD, 4 the same at 3 (all measured equal or slower: DESIGN section 6)
+  if (dma < 0) { const char* e = getenv("SE_AMD_MHSA_DMA"); dma = e ? atoi(e) : 0; }        // A/B: LDS-DMA rings inside this file's kernel (all measured equal or slower)
   static int nw8 = -1;
   if (nw8 < 0) { const char* e = getenv("SE_AMD_MHSA_NW"); nw8 = (e && atoi(e) == 8) ? 1 : 0; }      // A/B: 8-wave workgroups (256 queries share a staged tile)
   if (dma == 3)
@@ -485,6 +490,12 @@ static int mhsa_prescaled_launch(const uint16_t* qkv, const int32_t* lengths, in
     dim3 grid8((T + 255) / 256, heads, B);
     hipLaunchKernelGGL((se::mhsa_fwd_kernel<2, 0, 1, 0, 8>), grid8, dim3(512), 0, se::as_stream(stream), qkv, lengths, T, H, ctx, nullptr, 0u, 0u, spec ? 1.f : -1.f);
   } else
+#else
+  if (pipe != 0) {
+    se::set_error("se_mhsa_fwd_prescaled: variant %d is a parked experiment (developer builds: SE_AMD_BUILD_EXPERIMENTS=kernels); the product has 0 and 10", pipe);
+    return SE_ERR_UNSUPPORTED;
+  }
+#endif
     hipLaunchKernelGGL((se::mhsa_fwd_kernel<3, 0, 1, 0>), grid, dim3(256), 0, se::as_stream(stream), qkv, lengths, T, H, ctx, nullptr, 0u, 0u, spec ? 1.f : -1.f);
   SE_LAUNCH_CHECK();
   return SE_OK;
@@ -509,7 +520,7 @@ extern "C" int se_mhsa_fwd_prescaled_bf16(const uint16_t* qkv, const int32_t* le
   static int pipe = -2, min_wgs = 768;
   if (pipe == -2) {
     const char* e = getenv("SE_AMD_MHSA_PIPE");
-    pipe = e ? atoi(e) : -1;     // A/B: force one variant (0 = this file's kernel, 1 .. 3, 8, 9, 10, 12, 16: the experiments, all parity-tested)
+    pipe = e ? atoi(e) : -1;     // A/B: force one variant (0 = this file's kernel, 10 = mhsa8.hip's; developer builds: the parked experiments too)
     if (const char* m = getenv("SE_AMD_MHSA8_MIN_WGS")) min_wgs = atoi(m);
   }
   if (pipe >= 0) return mhsa_prescaled_launch(qkv, lengths, B, T, heads, ctx, pipe, stream);
@@ -520,10 +531,10 @@ extern "C" int se_mhsa_fwd_prescaled_bf16(const uint16_t* qkv, const int32_t* le
   return mhsa_prescaled_launch(qkv, lengths, B, T, heads, ctx, wgs8 >= min_wgs ? 10 : 0, stream);
 }
 
-// test / measurement surface: variant 0 = this file's kernel, 1 = the software-pipelined experiment of mhsa_pipe.hip, 2 = two query blocks per wave (mhsa2.hip)
+// test / measurement surface: variant 0 = this file's kernel (the default below 768 workgroups), 10 = mhsa8.hip's (the default from there on)
 extern "C" int se_mhsa_fwd_prescaled_variant_bf16(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, int variant,
                                                   void* stream) {
-  SE_REQUIRE((variant >= 0 && variant <= 3) || (variant >= 8 && variant <= 14) || variant == 16, "se_mhsa_fwd_prescaled_variant_bf16: variant %d (0 .. 3, 8 .. 14, 16)", variant);
+  SE_REQUIRE(variant >= 0 && variant <= 16, "se_mhsa_fwd_prescaled_variant_bf16: variant %d (0 or 10)", variant);
   return mhsa_prescaled_launch(qkv, lengths, B, T, heads, ctx, variant, stream);
 }
 
@@ -533,6 +544,7 @@ extern "C" int se_mhsa_fwd_lse_bf16(const uint16_t* qkv, const int32_t* lengths,
   return mhsa_fwd_launch(qkv, lengths, B, T, heads, ctx, lse, dropout_p, seed, site, stream);
 }
 
+#ifdef SE_AMD_EXPERIMENTS
 // Training forward with the dropout mask of dropmask.hip (se_mhsa_dropmask: query-major bit matrix `mask_r`) instead of the in-kernel hash: same
 // mask, same result up to the place of the 1 / (1 - p) factor (applied to the fp32 context sums instead of to each probability before its bf16
 // rounding).
@@ -551,3 +563,4 @@ extern "C" int se_mhsa_fwd_lse_masked_bf16(const uint16_t* qkv, const int32_t* l
   SE_LAUNCH_CHECK();
   return SE_OK;
 }
+#endif

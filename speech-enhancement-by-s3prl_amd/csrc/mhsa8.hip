@@ -597,6 +597,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WP
   }
 }
 
+#ifdef SE_AMD_EXPERIMENTS
 // ---------------------------------------------------------------------------------------------------------------------------------------------
 // mhsaP_fwd_kernel: mhsaN_fwd_kernel<8, 4, 1> as a PERSISTENT workgroup.  The in-kernel clock probe (csrc/clkprobe.h, profiles/r04_clk_probe.txt)
 // put numbers on the launch: a 256-query workgroup lives 56 950 cycles = 30.2 us at the 1.885 GHz the chip holds in this kernel, the 1 536
@@ -862,6 +863,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #undef SEP_DSETUP
 #undef SEP_DECODE
 }
+#endif      // SE_AMD_EXPERIMENTS
 
 }  // namespace se
 
@@ -870,6 +872,7 @@ int se_mhsaN_fwd_launch(const uint16_t* qkv, const int32_t* lengths, int B, int 
   const int H = heads * se::kHD;
   SE_REQUIRE((double)T * 3.0 * H * 2.0 < 2147483648.0, "se_mhsaN: T * 3 H * 2 = %.0f bytes exceeds the 31-bit DMA offset", (double)T * 3.0 * H * 2.0);
   dim3 grid((T + nw * 32 - 1) / (nw * 32), heads, B);
+#ifdef SE_AMD_EXPERIMENTS
   static const int stag = getenv("SE_AMD_MHSA_STAG") ? atoi(getenv("SE_AMD_MHSA_STAG")) : 1;      // A/B: 0 = every wave's barrier at the tile end; 1 .. 3: the staggered forms
   if (nw == 16 && stag) hipLaunchKernelGGL((se::mhsaN_fwd_kernel<16, 4, 1>), grid, dim3(1024), 0, st, qkv, lengths, T, H, ctx, never_speculate ? -1.f : 1.f);
   else if (nw == 8 && wpe == 4 && stag == 2) hipLaunchKernelGGL((se::mhsaN_fwd_kernel<8, 4, 2>), grid, dim3(512), 0, st, qkv, lengths, T, H, ctx, never_speculate ? -1.f : 1.f);
@@ -878,10 +881,15 @@ int se_mhsaN_fwd_launch(const uint16_t* qkv, const int32_t* lengths, int B, int 
   else if (nw == 16) hipLaunchKernelGGL((se::mhsaN_fwd_kernel<16, 4>), grid, dim3(1024), 0, st, qkv, lengths, T, H, ctx, never_speculate ? -1.f : 1.f);
   else if (wpe == 4) hipLaunchKernelGGL((se::mhsaN_fwd_kernel<8, 4>), grid, dim3(512), 0, st, qkv, lengths, T, H, ctx, never_speculate ? -1.f : 1.f);
   else hipLaunchKernelGGL((se::mhsaN_fwd_kernel<8, 2>), grid, dim3(512), 0, st, qkv, lengths, T, H, ctx, never_speculate ? -1.f : 1.f);
+#else
+  SE_REQUIRE(nw == 8 && wpe == 4, "se_mhsaN: the product library has the <8 waves, 4 per SIMD, staggered> form only");
+  hipLaunchKernelGGL((se::mhsaN_fwd_kernel<8, 4, 1>), grid, dim3(512), 0, st, qkv, lengths, T, H, ctx, never_speculate ? -1.f : 1.f);
+#endif
   SE_LAUNCH_CHECK();
   return SE_OK;
 }
 
+#ifdef SE_AMD_EXPERIMENTS
 // variant 11: mhsaP_fwd_kernel -- two persistent workgroups per CU (SE_AMD_MHSAP_WGS overrides the grid for A/B); variants 13 / 14: 8 / 5 workgroups
 int se_mhsaP_fwd_launch(const uint16_t* qkv, const int32_t* lengths, int B, int T, int heads, uint16_t* ctx, int never_speculate, int wgs, hipStream_t st) {
   const int H = heads * se::kHD;
@@ -931,3 +939,4 @@ extern "C" int se_mhsa8_fwd_stamps_bf16(const uint16_t* qkv, const int32_t* leng
   return SE_OK;
 }
 #endif
+#endif      // SE_AMD_EXPERIMENTS

@@ -490,6 +490,7 @@ extern "C" int se_mhsa_bwd_bf16(const uint16_t* qkv, const uint16_t* ctx, const 
   return SE_OK;
 }
 
+#ifdef SE_AMD_EXPERIMENTS
 // Backward with the dropout mask of dropmask.hip (se_mhsa_dropmask) instead of the in-kernel hash: mask_r query-major (dQ kernel), mask_c key-major
 // (dK / dV kernel).  Same mask and the same gradients up to where the 1 / (1 - p) factor is applied.
 extern "C" int se_mhsa_bwd_masked_bf16(const uint16_t* qkv, const uint16_t* ctx, const uint16_t* d_ctx, const float* lse, const int32_t* lengths,
@@ -513,3 +514,4 @@ extern "C" int se_mhsa_bwd_masked_bf16(const uint16_t* qkv, const uint16_t* ctx,
   SE_LAUNCH_CHECK();
   return SE_OK;
 }
+#endif

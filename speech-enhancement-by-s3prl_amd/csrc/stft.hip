@@ -409,9 +409,11 @@ extern "C" int se_stft2_f32(const se_plan* plan, const float* wavs, int B, int C
   return stft_launch(plan, wavs, B, C, T, jobs, 2, nullptr, stream);
 }
 
+#ifdef SE_AMD_EXPERIMENTS
 // the experimental persistent kernels of stft2.hip (SE_AMD_STFT2=1; measured equal or slower)
 extern "C" int se_stft2p_tphase_f32(const se_plan* plan, const float* wavs, int B, int C, int T, int channel_a, float* power_a, unsigned* tphase_a, float* mel_a,
                                     int channel_b, float* power_b, unsigned* tphase_b, float* mel_b, void* stream);
+#endif
 
 extern "C" int se_stft_tphase_f32(const se_plan* plan, const float* wavs, int B, int C, int T, int channel_a, float* power_a, unsigned* tphase_a, float* mel_a,
                                   int channel_b, float* power_b, unsigned* tphase_b, float* mel_b, void* stream) {
@@ -420,8 +422,10 @@ extern "C" int se_stft_tphase_f32(const se_plan* plan, const float* wavs, int B,
   SE_REQUIRE(B > 0 && C > 0 && channel_a >= 0 && channel_a < C && channel_b < C, "se_stft_tphase_f32: bad B=%d C=%d channels=%d,%d", B, C, channel_a, channel_b);
   SE_REQUIRE(T > se::kHalf, "se_stft_tphase_f32: T=%d must exceed n_fft/2=%d (reflect padding)", T, se::kHalf);
   SE_REQUIRE(B <= 65535, "se_stft_tphase_f32: B=%d exceeds grid.y limit", B);
+#ifdef SE_AMD_EXPERIMENTS
   static const bool use2 = getenv("SE_AMD_STFT2") != nullptr;
   if (use2) return se_stft2p_tphase_f32(plan, wavs, B, C, T, channel_a, power_a, tphase_a, mel_a, channel_b, power_b, tphase_b, mel_b, stream);
+#endif
   float* pa = reinterpret_cast<float*>(tphase_a);
   float* pb = reinterpret_cast<float*>(tphase_b);
   const se::StftOut jobs[2] = {{power_a, pa, nullptr, mel_a, channel_a, (((uintptr_t)power_a | (uintptr_t)pa) % 16) == 0, 1},

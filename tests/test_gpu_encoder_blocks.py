@@ -127,7 +127,7 @@ def test_mhsa_vs_torch(gpu, B, T, heads, lens):
 
 
 @pytest.mark.parametrize('B,T,heads,lens', [(2, 1001, 12, None), (3, 300, 4, [300, 17, 129]), (1, 64, 1, None), (2, 130, 2, [1, 65]), (8, 257, 1, [257, 200, 64, 63, 1, 128, 129, 256])])
-@pytest.mark.parametrize('variant', [0, 1, 2, 3, 8, 9, 10, 11, 12, 13, 14, 16])
+@pytest.mark.parametrize('variant', [0, 10])
 def test_mhsa_prescaled_vs_torch(gpu, B, T, heads, lens, variant):
     """the inference kernel on pre-scaled queries (variant 0) and the software-pipelined half-tile experiment (variant 1, csrc/mhsa_pipe.hip)
     vs fp64 on the SAME bf16 operands: softmax_base2(Q' K^T) V with Q' = bf16(Q log2(e) / 8)"""
@@ -156,7 +156,7 @@ def test_mhsa_prescaled_vs_torch(gpu, B, T, heads, lens, variant):
     assert err.max().item() < 8e-3 * ref.abs().max().item(), err.max().item()      # P and the output are rounded to bf16 (2^-9 relative)
 
 
-@pytest.mark.parametrize('variant', [0, 1, 2, 3, 8, 9, 10, 11, 12, 13, 14, 16])
+@pytest.mark.parametrize('variant', [0, 10])
 def test_mhsa_prescaled_rising_maxima(gpu, variant):
     """rising row maxima across key tiles (both sides of the deferred-rescale branch, which here must also shift the S' tile computed ahead)"""
     L = _lib()
@@ -183,7 +183,7 @@ def test_mhsa_prescaled_rising_maxima(gpu, variant):
     assert err < 2e-2 * ref.abs().max().item(), err
 
 
-@pytest.mark.parametrize('variant', [0, 1, 2, 3, 8, 9, 10, 11, 12, 13, 14, 16])
+@pytest.mark.parametrize('variant', [0, 10])
 @pytest.mark.parametrize('level', [-90.0, -30.0, 70.0])
 def test_mhsa_prescaled_far_from_reference(gpu, variant, level):
     """every score sits near `level` (base-2 exponent domain): far BELOW the initial reference 0 the speculative exp2(S) of the first tile
@@ -323,10 +323,11 @@ def test_gemm_res_ln_exact_rows(gpu):
 
 
 @pytest.mark.parametrize('M,K', [(32032, 3072), (602, 768), (1001, 3072), (257, 128)])
-def test_gemm_res24_pair_exchange_vs_single_tile(gpu, M, K):
-    """The 256 x 384 tile kernel whose two column halves exchange LayerNorm statistics across workgroups (gemm8) against the 128 x 768
-    row-complete kernel (gemm7) on the same 24-bit-stream inputs, and both against fp64: both output forms (fp32 rows; bf16 + lo bytes),
-    ragged row counts (602 = 2 x 256 + 90, 257: one row into the second tile), the bench shape, repeated launches (flags self-reset)."""
+def test_gemm_res24_row_complete_vs_fp64(gpu, M, K):
+    """The row-complete projection + residual + LayerNorm on the 24-bit residual stream (gemm4.hip: gemm7_res_ln_kernel, the encoder's out-proj / FFN2
+    launch at bench size) through its measurement entry: both output forms (fp32 rows; bf16 + lo bytes) against fp64, ragged row counts (602 = 4 x 128
+    + 90, 257: one row into the third tile), the bench shape; a non-zero low byte plane decodes as hi + lo * 2^-8 ulp(hi).  (The 256 x 384
+    pair-exchange kernel this test used to compare with is parked under tools/experiments/kernels/ with its own test.)"""
     L = _lib()
     lib = L.load()
     torch.manual_seed(M + K)
@@ -345,26 +346,27 @@ def test_gemm_res24_pair_exchange_vs_single_tile(gpu, M, K):
         o32 = torch.full((M, N), float('nan'), device=gpu) if fp32_out else None
         o16 = None if fp32_out else torch.zeros(M, N, device=gpu, dtype=torch.bfloat16)
         olo = None if fp32_out else torch.zeros(nlo, device=gpu, dtype=torch.uint8)
-        L.check(lib.se_gemm_res24_ln_bf16(L.ptr(A), K, L.ptr(W), K, L.ptr(bias), L.ptr(res), L.ptr(res_lo), L.ptr(lw), L.ptr(lb), 1e-12, M, N, K,
-                                          L.ptr(o32), L.ptr(o16), L.ptr(olo), variant, L.ptr(scratch), L.stream()), 'se_gemm_res24_ln_bf16')
-        return o32, o16, olo
+        rc = lib.se_gemm_res24_ln_bf16(L.ptr(A), K, L.ptr(W), K, L.ptr(bias), L.ptr(res), L.ptr(res_lo), L.ptr(lw), L.ptr(lb), 1e-12, M, N, K,
+                                       L.ptr(o32), L.ptr(o16), L.ptr(olo), variant, L.ptr(scratch), L.stream())
+        return rc, o32, o16, olo
 
-    for rep in range(3):                                                 # repeated launches on the same scratch: the pair flags reset themselves
-        o8, _, _ = run(8, True)
-    o7, _, _ = run(7, True)
+    rc, o7, _, _ = run(7, True)
+    assert rc == 0
     scale = ref.abs().max().item()
-    assert (o8.double() - ref).abs().max().item() < 2e-5 * scale + 2e-4
     assert (o7.double() - ref).abs().max().item() < 2e-5 * scale + 2e-4
-    assert (o8 - o7).abs().max().item() < 1e-4 * scale                  # same products; the statistics are combined in a different order
-    _, b8, l8 = run(8, False)
-    _, b7, l7 = run(7, False)
-    assert (b8.double() - ref).abs().max().item() < 2 ** -8 * scale
-    agree = (b8 == b7).float().mean().item()
-    assert agree > 0.999, agree                                          # bf16 roundings of values a few 1e-6 apart
-    assert torch.equal(scratch[-(128 * 2 * 4 + 256):], torch.zeros(128 * 2 * 4 + 256, device=gpu, dtype=torch.uint8))   # flags + error word left clear
-    # the low bytes (same tile-major positions in both kernels) differ by at most one step where the values are a few 1e-6 apart
-    d = (l8.view(torch.int8).int() - l7.view(torch.int8).int()).abs()
-    assert (d <= 1).float().mean().item() > 0.99
+    rc0, o0, _, _ = run(0, True)                                         # variant 0 = the encoder's dispatch: the same kernel in the product library
+    assert rc0 == 0 and torch.equal(o0, o7)
+    rc, _, b7, l7 = run(7, False)
+    assert rc == 0 and (b7.double() - ref).abs().max().item() < 2 ** -8 * scale
+    # the 24-bit value (bf16 + signed low byte on the fp32 bit pattern, gemm4.hip) is the fp32 row to 2^-16 relative: rows of the row-major part of
+    # the tile-major low plane are not decoded here; the decode is exercised end to end by the next launch reading (b7, l7) as its residual
+    rc, o_next, _, _ = (lambda: (lib.se_gemm_res24_ln_bf16(L.ptr(A), K, L.ptr(W), K, L.ptr(bias), L.ptr(b7), L.ptr(l7), L.ptr(lw), L.ptr(lb), 1e-12, M, N, K,
+                                                           L.ptr(o7), None, None, 7, L.ptr(scratch), L.stream()), o7, None, None))()
+    assert rc == 0
+    ref2 = torch.nn.functional.layer_norm(A.double() @ W.double().T + bias.double() + ref, (N,), lw.double(), lb.double(), 1e-12)
+    assert (o_next.double() - ref2).abs().max().item() < 1e-4 * ref2.abs().max().item() + 2e-4      # a bf16-only residual would be ~4e-3 off
+    assert lib.se_gemm_res24_ln_bf16(L.ptr(A), K, L.ptr(W), K, L.ptr(bias), L.ptr(res), L.ptr(res_lo), L.ptr(lw), L.ptr(lb), 1e-12, M, N, K,
+                                     L.ptr(o7), None, None, 8, L.ptr(scratch), L.stream()) != 0      # the parked experiment is refused, loudly
 
 
 def test_gemm6_dual_gelu_launch_bit_identical_to_the_two_launches(gpu):

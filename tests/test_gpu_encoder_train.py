@@ -29,11 +29,7 @@ def rel_l2(a, b):
 @pytest.mark.parametrize('B,T,heads,lens,drop', [(2, 300, 12, [300, 177], 0.0), (1, 129, 4, None, 0.0), (3, 64, 2, [64, 1, 33], 0.0),
                                                   (2, 301, 12, [301, 190], 0.1), (1, 130, 4, None, 0.25),
                                                   (1, 1001, 12, None, 0.0)])       # the fine-tune bench's T' = 1001
-@pytest.mark.parametrize('masked', [False, True])
-def test_mhsa_backward_vs_autograd(gpu, B, T, heads, lens, drop, masked):
-    """masked: the dropout mask as the two bit matrices of csrc/dropmask.hip (generated once, read by all three kernels) instead of the in-kernel hash"""
-    if masked and drop == 0.0:
-        pytest.skip('the bit-matrix form exists for dropout > 0 only')
+def test_mhsa_backward_vs_autograd(gpu, B, T, heads, lens, drop):
     L = _L()
     lib = L.load()
     torch.manual_seed(T)
@@ -47,17 +43,9 @@ def test_mhsa_backward_vs_autograd(gpu, B, T, heads, lens, drop, masked):
     seed, site = 0x1234567890abcdef % (1 << 63), 7
     dqkv = torch.full((B * T, 3 * H), float('nan'), device=gpu, dtype=torch.bfloat16)
     dvec = torch.empty(B, heads, T, device=gpu, dtype=torch.float32)
-    if masked:
-        mr = torch.full((lib.se_mhsa_dropmask_bytes(B, T, heads, 0) // 4,), -1, device=gpu, dtype=torch.int32)
-        mc = torch.full((lib.se_mhsa_dropmask_bytes(B, T, heads, 1) // 4,), -1, device=gpu, dtype=torch.int32)
-        L.check(lib.se_mhsa_dropmask(B, T, heads, drop, seed, site, L.ptr(mr), L.ptr(mc), L.stream()), 'dropmask')
-        L.check(lib.se_mhsa_fwd_lse_masked_bf16(L.ptr(qkv_g), L.ptr(len_g), B, T, heads, L.ptr(ctx), L.ptr(lse), L.ptr(mr), drop, L.stream()), 'fwd')
-        L.check(lib.se_mhsa_bwd_masked_bf16(L.ptr(qkv_g), L.ptr(ctx), L.ptr(do_g), L.ptr(lse), L.ptr(len_g), B, T, heads, L.ptr(dqkv), L.ptr(dvec),
-                                            L.ptr(mr), L.ptr(mc), drop, L.stream()), 'bwd')
-    else:
-        L.check(lib.se_mhsa_fwd_lse_bf16(L.ptr(qkv_g), L.ptr(len_g), B, T, heads, L.ptr(ctx), L.ptr(lse), drop, seed, site, L.stream()), 'fwd')
-        L.check(lib.se_mhsa_bwd_bf16(L.ptr(qkv_g), L.ptr(ctx), L.ptr(do_g), L.ptr(lse), L.ptr(len_g), B, T, heads, L.ptr(dqkv), L.ptr(dvec),
-                                     drop, seed, site, L.stream()), 'bwd')
+    L.check(lib.se_mhsa_fwd_lse_bf16(L.ptr(qkv_g), L.ptr(len_g), B, T, heads, L.ptr(ctx), L.ptr(lse), drop, seed, site, L.stream()), 'fwd')
+    L.check(lib.se_mhsa_bwd_bf16(L.ptr(qkv_g), L.ptr(ctx), L.ptr(do_g), L.ptr(lse), L.ptr(len_g), B, T, heads, L.ptr(dqkv), L.ptr(dvec),
+                                 drop, seed, site, L.stream()), 'bwd')
     # fp64 autograd on the same (bf16-valued) operands
     x = qkv.double().requires_grad_(True)
     q, k, v = [t.reshape(B, T, heads, 64).permute(0, 2, 1, 3) for t in x.reshape(B, T, 3 * H).split(H, dim=-1)]
@@ -86,31 +74,6 @@ def test_mhsa_backward_vs_autograd(gpu, B, T, heads, lens, drop, masked):
         if n < T:
             assert torch.count_nonzero(got[b * T + n:(b + 1) * T, H:]) == 0
 
-
-@pytest.mark.parametrize('B,T,heads,drop', [(2, 301, 3, 0.1), (1, 1001, 2, 0.1), (1, 64, 1, 0.5), (1, 513, 1, 0.25)])
-def test_dropout_bit_matrices_equal_the_hashed_mask(gpu, B, T, heads, drop):
-    """csrc/dropmask.hip against the oracle's keep_mask (the restatement of csrc/dropout.h the hashed kernels are tested with): BIT-EXACT, in both
-    layouts -- query-major word pairs (even keys, odd keys) per 64-key tile, key-major words of 32 queries"""
-    import numpy as np
-    L = _L()
-    lib = L.load()
-    seed, site = 0x0fedcba987654321, 3
-    nr, nc = lib.se_mhsa_dropmask_bytes(B, T, heads, 0) // 4, lib.se_mhsa_dropmask_bytes(B, T, heads, 1) // 4
-    mr = torch.zeros(nr, device=gpu, dtype=torch.int32)
-    mc = torch.zeros(nc, device=gpu, dtype=torch.int32)
-    L.check(lib.se_mhsa_dropmask(B, T, heads, drop, seed, site, L.ptr(mr), L.ptr(mc), L.stream()), 'dropmask')
-    keep = oenc.keep_mask(seed, site, B * heads * T, T, drop).reshape(B * heads, T, T).numpy().astype(bool)
-    Wr, Tc, Wc = 4 * ((T + 127) // 128), 128 * ((T + 127) // 128), 8 * ((T + 255) // 256)
-    R = mr.cpu().numpy().view(np.uint32).reshape(B * heads, T, Wr)
-    C = mc.cpu().numpy().view(np.uint32).reshape(B * heads, Tc, Wc)
-    # query-major: key k of row q = bit (k % 64) // 2 of word 2 (k // 64) + (k & 1)
-    k = np.arange(T)
-    got_r = (R[:, :, 2 * (k // 64) + (k & 1)] >> ((k % 64) // 2).astype(np.uint32)) & 1
-    assert np.array_equal(got_r.astype(bool), keep)
-    # key-major: query q of key k = bit q % 32 of word q // 32
-    q = np.arange(T)
-    got_c = (C[:, :T, :][:, :, q // 32] >> (q % 32).astype(np.uint32)) & 1          # [bh, key, query]
-    assert np.array_equal(got_c.astype(bool).transpose(0, 2, 1), keep)
 
 
 def test_gelu_forward_backward(gpu):

@@ -6,6 +6,8 @@ rows of a softmax summing to one, zero loss of identical inputs, invariance of t
 import pytest
 import torch
 
+from conftest import bounded
+
 pytestmark = pytest.mark.gpu
 
 
@@ -134,3 +136,90 @@ def test_losses_of_identical_inputs_at_full_size(gpu):
     assert abs(loss.item()) < 2e-7
     s, _ = SISDR()(predicted=tar, linear_tar=tar, stft_lengths=lens)
     assert s.item() < -60.0            # -SI-SDR in dB: a perfect estimate is limited only by eps
+
+
+def _mockingjay_grads(model, crit, feats, tar, lens):
+    for p in model.parameters():
+        p.grad = None
+    pred, res = model(features=feats)
+    loss, _ = crit(log_predicted=res['log_predicted'], linear_tar=tar, stft_lengths=lens)
+    loss.backward()
+    return float(loss.detach()), {n: p.grad.detach().double().clone() for n, p in model.named_parameters()}
+
+
+def test_finetune_step_full_size_equals_the_sum_of_its_utterances(gpu):
+    """configs[2]'s training step at its per-GPU shape (B = 32, L = 6, T' = 1001: 32 032 rows, the sizes at which the row-complete N = 768 GEMMs, the
+    persistent FFN1 dual store and the staggered weight-gradient kernel switch on -- runner.py:431-471) checked through a size-independent property:
+    the loss is the GLOBAL masked mean (objective.py:113-116), so with S_b / C_b the L1 sum / element count of utterance b
+        loss = sum_b S_b / sum_b C_b        and        grad(loss) = sum_b (C_b / C) grad(loss_b),   loss_b = S_b / C_b,
+    where every loss_b and its gradient comes from the SAME model run on that utterance alone -- 1 001 rows, i.e. through the small-M kernels and the
+    unfused paths.  Dropout is off here (its masks are keyed by element index, so utterance b alone would draw other masks); the sign gradient of L1
+    flips where bf16 rounding moves log_predicted across the target, hence the cosine / norm form of the gradient bound (as the per-utterance
+    gradient scoring test)."""
+    from speech_enhancement_by_s3prl_amd import pipeline
+    from speech_enhancement_by_s3prl_amd.objective import L1
+    cfg = pipeline.make_config(layers=6)
+    cfg['transformer'].update(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    ckpt = pipeline.synthetic_checkpoint(cfg, seed=11)
+    model = pipeline.build_mockingjay(ckpt, gpu)
+    model.train()
+    B, T = 32, 1001
+    g = torch.Generator().manual_seed(77)
+    feats = torch.randn(B, T, 80, generator=g).to(gpu)
+    tar = (torch.rand(B, T, 201, generator=g) + 0.05).to(gpu)
+    lens = torch.randint(500, T + 1, (B,), generator=g)
+    lens[0] = T
+    feats = feats * (torch.arange(T)[None, :, None] < lens[:, None, None]).to(gpu)      # S3PRL derives the valid frames from all-zero feature rows
+    lens = lens.to(gpu)
+    crit = L1()
+    loss_full, g_full = _mockingjay_grads(model, crit, feats, tar, lens)
+    counts = lens.double() * 201
+    C = counts.sum().item()
+    acc = {n: torch.zeros_like(v) for n, v in g_full.items()}
+    s_sum = 0.0
+    for b in range(B):
+        lb, gb = _mockingjay_grads(model, crit, feats[b:b + 1], tar[b:b + 1], lens[b:b + 1])
+        s_sum += lb * counts[b].item()
+        for n in acc:
+            acc[n] += gb[n] * (counts[b].item() / C)
+    assert abs(loss_full - s_sum / C) < 2e-3 * abs(loss_full), (loss_full, s_sum / C)
+    worst_cos, worst_norm = 1.0, 0.0
+    for n in acc:
+        if n.endswith('attention.self.key.bias'):
+            continue                  # its true gradient is ZERO (a constant added to every key's score leaves the softmax unchanged): both sides are rounding noise
+        a, r = g_full[n].flatten(), acc[n].flatten()
+        cos = float(torch.dot(a, r) / (a.norm() * r.norm() + 1e-300))
+        ratio = float(a.norm() / (r.norm() + 1e-300))
+        worst_cos, worst_norm = min(worst_cos, cos), max(worst_norm, abs(ratio - 1.0))
+        assert cos > 0.985 and abs(ratio - 1.0) < 0.05, (n, cos, ratio)
+    bounded('finetune_fullsize 1 - min cosine(grad, sum of per-utterance grads)', 1.0 - worst_cos, 2e-3)
+    bounded('finetune_fullsize max |norm ratio - 1|', worst_norm, 5e-3)
+
+
+def test_finetune_step_dispatch_switches_agree():
+    """the same full-size step (train mode, dropout 0.1, identical seeded masks) with the large-M dispatch of round 4 ON (default) and OFF
+    (SE_AMD_GEMM7_PLAIN=0: 256 x 256 tiles instead of the row-complete N = 768 kernel; SE_AMD_GEMM6_DUAL=0: FFN1 pre-activation and GELU as two
+    launches; SE_AMD_WGRAD_STAG=0: the unstaggered weight-gradient ring): loss, gradient norm and a seeded sample of every parameter's gradient agree
+    to the bf16 bound.  Two subprocesses (the switches are read once per process)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(env_extra):
+        env = dict(os.environ, **env_extra)
+        r = subprocess.run([sys.executable, os.path.join(root, 'tests', '_finetune_fullsize_worker.py')], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [l for l in r.stdout.splitlines() if l.startswith('RESULT ')][-1]
+        return json.loads(line[7:])
+
+    on = run({})
+    off = run({'SE_AMD_GEMM7_PLAIN': '0', 'SE_AMD_GEMM6_DUAL': '0', 'SE_AMD_WGRAD_STAG': '0'})
+    assert abs(on['loss'] - off['loss']) < 2e-3 * abs(off['loss']), (on['loss'], off['loss'])
+    assert abs(on['gnorm'] - off['gnorm']) < 3e-2 * off['gnorm'], (on['gnorm'], off['gnorm'])
+    import torch as _t
+    a = _t.tensor([v for n in sorted(on['samples']) for v in on['samples'][n]], dtype=_t.float64)
+    b = _t.tensor([v for n in sorted(off['samples']) for v in off['samples'][n]], dtype=_t.float64)
+    cos = float(_t.dot(a, b) / (a.norm() * b.norm()))
+    assert cos > 0.99, cos

@@ -77,8 +77,6 @@ qkv = qkv.bfloat16()
 ctx = torch.empty(M, H, device=dev, dtype=torch.bfloat16)
 run('attention forward (mhsaN<8,4,1>) B=32 T=1001', 'clkprobe_mhsa',
     lambda: L.check(lib.se_mhsa_fwd_prescaled_variant_bf16(L.ptr(qkv), None, B, T, heads, L.ptr(ctx), 10, L.stream()), 'mhsa'), 4.0 * B * heads * T * T * 64)
-run('attention forward, persistent (mhsaP) B=32 T=1001', 'clkprobe_mhsa',
-    lambda: L.check(lib.se_mhsa_fwd_prescaled_variant_bf16(L.ptr(qkv), None, B, T, heads, L.ptr(ctx), 11, L.stream()), 'mhsa'), 4.0 * B * heads * T * T * 64)
 
 x = torch.randn(M, 3072, device=dev).bfloat16()
 for (N, K, act, lab) in ((2304, 768, 0, 'QKV projection'), (3072, 768, 3, 'FFN1 + GELU'), (3072, 768, 0, 'FFN1 shape WITHOUT the GELU'), (2304, 768, 3, 'QKV shape WITH a GELU')):
