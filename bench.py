@@ -91,8 +91,8 @@ def cpu_baseline(batch, layers, seconds_budget=25.0):
 
 
 # committed counter passes (tools/collect_profiles.sh), one file per workload: bench.py cannot run counter passes on itself
-PMC_FILES = {'enhance': 'r04_pmc_fetch_write.json', 'finetune': 'r04_pmc_fetch_write_finetune.json',
-             'head:mel120': 'r04_pmc_fetch_write_head_mel120.json', 'head:linear201': 'r04_pmc_fetch_write_head_linear201.json'}
+PMC_FILES = {'enhance': 'r05_pmc_fetch_write.json', 'finetune': 'r05_pmc_fetch_write_finetune.json',
+             'head:mel120': 'r05_pmc_fetch_write_head_mel120.json', 'head:linear201': 'r05_pmc_fetch_write_head_linear201.json'}
 
 
 # every kernel the prof family 'gemm_bf16' times (csrc/gemm*.hip): the traffic figure is the launch-weighted mean over the same launches

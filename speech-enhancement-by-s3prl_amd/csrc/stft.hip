@@ -351,6 +351,7 @@ __global__ __launch_bounds__(kThreads) void stft_kernel(
 
 #ifdef SE_STFT_TU_SMALL
 // the no-mel build of this file (stft_small.hip): only the kernel and this launcher
+extern "C" int se_stft_small_plane_floats(void) { return se::kPlane; }
 extern "C" int se_stft_launch_small(const se_plan* plan, const float* wavs, int B, int C, int T, const void* jobs_, int njobs, void* stream) {
   const se::StftOut* jobs = static_cast<const se::StftOut*>(jobs_);
   const int F = T / se::kHop + 1;
@@ -362,6 +363,7 @@ extern "C" int se_stft_launch_small(const se_plan* plan, const float* wavs, int 
 }
 #else
 extern "C" int se_stft_launch_small(const se_plan* plan, const float* wavs, int B, int C, int T, const void* jobs, int njobs, void* stream);
+extern "C" int se_stft_small_plane_floats(void);
 
 static int stft_launch(const se_plan* plan, const float* wavs, int B, int C, int T, const se::StftOut* jobs, int njobs, unsigned long long* dbgbuf, void* stream) {
   const int F = T / se::kHop + 1;
@@ -375,7 +377,7 @@ static int stft_launch(const se_plan* plan, const float* wavs, int B, int C, int
   bool any_mel = false;
   for (int j = 0; j < njobs; ++j) any_mel = any_mel || jobs[j].mel != nullptr;
   // 10-frame workgroups (stft_small.hip): planes of 2 016 floats; a mel bank fits its table (34 floats per filter + 4) there up to 59 filters
-  const bool small_fits = !any_mel || plan->geom.n_mels * (se::kMelMaxW + 2) + 4 <= 2016;
+  const bool small_fits = !any_mel || plan->geom.n_mels * (se::kMelMaxW + 2) + 4 <= se_stft_small_plane_floats();
   if (small_ok && small_fits && !dbgbuf) return se_stft_launch_small(plan, wavs, B, C, T, jobs, njobs, stream);
   hipLaunchKernelGGL(se::stft_kernel, grid, dim3(se::kThreads), 0, se::as_stream(stream), wavs, C, T, F, plan->d_window, plan->d_tw400, plan->d_tw200,
                      plan->d_mel_start, plan->d_mel_len, plan->d_mel_w, plan->geom.n_mels, jobs[0], jobs[njobs > 1 ? 1 : 0], dbgbuf);

@@ -163,7 +163,7 @@ def bench_gemm_ln():
 
 
 def bench_res24():
-    """FFN-output / attention-output projections on the 24-bit stream: 128 x 768 tiles (variant 7) vs the 256 x 384 pair-exchange tiles (8)"""
+    """FFN-output / attention-output projections on the 24-bit stream: the 128 x 768 row-complete tiles (variant 7)"""
     M, N = 32 * 1001, 768
     for K in (768, 3072):
         A = torch.randn(M, K, device=dev).bfloat16()
@@ -175,7 +175,7 @@ def bench_res24():
         o16 = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
         olo = torch.empty(nlo, device=dev, dtype=torch.uint8)
         scratch = torch.zeros(lib.se_gemm_res24_scratch_bytes(), device=dev, dtype=torch.uint8)
-        for variant in (7, 8):
+        for variant in (7,):      # 8 = the parked 256 x 384 pair-exchange experiment (developer builds)
             def run():
                 L.check(lib.se_gemm_res24_ln_bf16(L.ptr(A), K, L.ptr(W), K, L.ptr(bias), L.ptr(res), L.ptr(rlo), L.ptr(lw), L.ptr(lb), 1e-12, M, N, K, None,
                                                   L.ptr(o16), L.ptr(olo), variant, L.ptr(scratch), L.stream()), 'res24')

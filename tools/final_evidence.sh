@@ -19,11 +19,13 @@ tools/collect_profiles.sh $tag _head_mel120 --workload head --head-feat mel120
 tools/collect_profiles.sh $tag _head_linear201 --workload head --head-feat linear201
 fi
 [ "$part" = 1 ] && exit 0
+if [ "$part" != 3 ]; then      # part 3: only what follows the side-workload lines (re-run after a failure further down)
 tools/collect_profiles.sh $tag _finetune --workload finetune
 cd "$root"
 python3 bench.py --workload lstm --no-cpu-baseline > "$out/${tag}_lstm_bench.json" 2> "$out/lstm.err"
 python3 tools/bench_kernels.py mhsa_train > "$out/${tag}_mhsa_train.txt" 2>&1
 python3 tools/bench_kernels.py mhsa_peaked > "$out/${tag}_mhsa_peaked.txt" 2>&1
+fi
 python3 tools/bench_kernels.py all > "$out/${tag}_bench_kernels.txt" 2>&1
 python3 tools/bench_kernels.py hbm >> "$out/${tag}_bench_kernels.txt" 2>&1
 SE_AMD_GEMM_SMALL_M=0 python3 tools/bench_kernels.py square >> "$out/${tag}_bench_kernels.txt" 2>&1
