@@ -125,6 +125,16 @@ int se_features2_f32(const float* raw, int raw_time_major, int B, int D, int F,
                      float* out, void* workspace, size_t workspace_bytes,
                      uint16_t* out_bf16_pad, int ld_pad, int32_t* valid_count, void* stream);
 
+/* The same result in ONE pass over the raw plane (no feature-major intermediate): a workgroup owns 32 frames and recomputes log / deltas from a
+ * (32 + 4 delta)-frame window; the CMVN statistics (cmvn != 0) come from a statistics-only launch in front.  workspace (cmvn != 0 only)
+ * >= se_features3_workspace_bytes(B, D, delta).  colstats_out (B, D*(1+delta), 2) optional, cmvn == 0 only: per (utterance, output column) the pair
+ * (mean over time, 1 / (unbiased std + colstats_eps)) of the rows written to `out` -- what LinearResidual's own CMVN (model.py:29-31) needs, handed to
+ * se_head_linear_pre_f32 so that the head does not read the features a second time for it.  Side outputs as se_features2_f32. */
+size_t se_features3_workspace_bytes(int B, int D, int delta);
+int se_features3_f32(const float* raw, int raw_time_major, int B, int D, int F, int apply_log, int delta, int cmvn, float eps,
+                     float* out, void* workspace, size_t workspace_bytes, uint16_t* out_bf16_pad, int ld_pad, int32_t* valid_count,
+                     float* colstats_out, float colstats_eps, void* stream);
+
 /*
  * se_istft_f32 -- row A6: OnlinePreprocessor.istft(linears, phases) (runner.py:267): mag = power^(1/linear_power),
  * (mag cos phi, mag sin phi) -> inverse 400-pt real DFT -> x Hann -> overlap-add -> / sum(w^2) -> trim n_fft/2.
@@ -182,6 +192,17 @@ size_t se_head_workspace_bytes(int B, int F, int D, int N);
 int se_head_linear_f32(const float* feats, const float* W, const float* bias, const float* linears,
                        int B, int F, int D, int N, int act, int cmvn, float eps,
                        float* predicted, float* offset, void* workspace, size_t workspace_bytes, void* stream);
+
+/* The evaluate()-style pass (runner.py:556-575) calls the head once per batch with unchanged weights: se_head_split_weights_f32 writes the
+ * three-term bf16 split se_head_linear_f32 builds internally on every call (W3: se_head_w3_bytes(N, D) bytes) once, and se_head_linear_pre_f32
+ * is se_head_linear_f32 on that split and on ready-made column statistics `stats` (B, D, 2) = (mean, 1 / (unbiased std + eps)) per (utterance,
+ * feature column) -- se_features3_f32's colstats_out -- or NULL for no CMVN.  Same kernel, same results. */
+size_t se_head_w3_bytes(int N, int D);
+/* stats (B, D, 2) = (mean over time, 1 / (unbiased std + eps)) of feats (B, F, D): the CMVN of model.py:29-31 as se_head_linear_pre_f32 takes it */
+int se_head_colstats_f32(const float* feats, int B, int F, int D, float eps, float* stats, void* stream);
+int se_head_split_weights_f32(const float* W, int N, int D, uint16_t* W3, void* stream);
+int se_head_linear_pre_f32(const float* feats, const uint16_t* W3, const float* bias, const float* linears, const float* stats,
+                           int B, int F, int D, int N, int act, float* predicted, float* offset, void* stream);
 
 /*
  * se_head_linear_bwd_f32 -- autograd of C1/C2 wrt the head parameters (runner.py:459 loss.backward()):
@@ -514,6 +535,14 @@ int se_colsum_bf16(const uint16_t* x, int rows, int cols, int ld, float* out, vo
  * optional, = grad_scale * d loss_b / d predicted (pass 1/B, or 1/global_B under data parallelism). scratch: device double[5 B]. */
 int se_sisdr_spec_f32(const float* predicted, const float* linear_tar, const int64_t* frame_lengths, int B, int F, int N, float eps,
                       float grad_scale, double* scratch, float* loss_b, float* grad, void* stream);
+
+/* The same criterion for the evaluate()-style pass (no gradient) as two launches: `lengths` are frame counts (len_div == 0) or WAVEFORM lengths
+ * (frames = lengths / len_div + 1, runner.py:455), partial sums in `scratch` (se_sisdr_spec_loss_scratch_doubles(B, F, N) doubles, no clearing),
+ * loss_b (B), sums_out = {sum_b loss_b, B}, loss_out = their ratio: objective.py:81-100 incl. its mean over the utterances.  Fixed summation order. */
+size_t se_sisdr_spec_loss_scratch_doubles(int B, int F, int N);
+int se_sisdr_spec_loss_f32(const float* predicted, const float* linear_tar, const int64_t* lengths, int len_div, int B, int F, int N, float eps,
+                           double* scratch, float* loss_b, double* sums_out, float* loss_out, void* stream);
+
 /* objective.WSD (objective.py:119-153) in two steps, so that a data-parallel caller can all-reduce(MAX) the batch-wide energy
  * maximum in between: energy (B*F) = sum_n linear_tar, energy_max (1 float) = its maximum over every frame of the batch; then
  * sums[0..1] = (sum_b speech_b, sum_b noise_b) (device double[3]) and grad (optional) = grad_scale * d(alpha sums[0] +

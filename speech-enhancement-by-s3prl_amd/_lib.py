@@ -67,12 +67,18 @@ SIGNATURES = {
     'se_features_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int]),
     'se_features_f32': (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P, _P, c_size_t, _P]),
     'se_features2_f32': (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P, _P, c_size_t, _P, c_int, _P, _P]),
+    'se_features3_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
+    'se_features3_f32': (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P, _P, c_size_t, _P, c_int, _P, _P, c_float, _P]),
     'se_istft_f32': (c_int, [_P, _P, _P, c_int, c_int, c_float, _P, c_int, _P, _P, _P]),
     'se_masked_sumsq_f32': (c_int, [_P, c_int, c_int, c_int, _P, _P, _P]),
     'se_dbnorm_f32': (c_int, [_P, c_int, c_int, c_int, _P, _P, _P, c_float, c_float, _P]),
     'se_length_masks_i64': (c_int, [_P, c_int, c_int, _P, _P]),
     'se_head_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int]),
     'se_head_linear_f32': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P, _P, _P, c_size_t, _P]),
+    'se_head_colstats_f32': (c_int, [_P, c_int, c_int, c_int, c_float, _P, _P]),
+    'se_head_w3_bytes': (c_size_t, [c_int, c_int]),
+    'se_head_split_weights_f32': (c_int, [_P, c_int, c_int, _P, _P]),
+    'se_head_linear_pre_f32': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
     'se_head_linear_bwd_f32': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P, _P, _P, c_size_t, _P]),
     'se_head_dx_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int]),
     'se_head_linear_dx_f32': (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P, _P, c_size_t, _P]),
@@ -136,6 +142,8 @@ SIGNATURES = {
     'se_lstm_fwd_bf16': (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P]),
     'se_lstm_bwd_bf16': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     'se_colsum_bf16': (c_int, [_P, c_int, c_int, c_int, _P, _P]),
+    'se_sisdr_spec_loss_scratch_doubles': (c_size_t, [c_int, c_int, c_int]),
+    'se_sisdr_spec_loss_f32': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P, _P, _P]),
     'se_sisdr_spec_f32': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_float, c_float, _P, _P, _P, _P]),
     'se_wsd_energy_f32': (c_int, [_P, c_int, c_int, c_int, _P, _P, _P]),
     'se_wsd_f32': (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, c_float, c_float, c_float, _P, _P, _P]),

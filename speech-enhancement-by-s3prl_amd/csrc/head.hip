@@ -244,6 +244,11 @@ __global__ __launch_bounds__(256, 2) void head_kernel(const float* __restrict__ 
 // while they are staged (CMVN first, in fp32).  LDS: 16-k chunks, rows at a 48-B pitch (conflict-free ds_read_b128 of 16 consecutive rows):
 // 3 x (128 + NT * 32) x 48 B = 50.7 KB at N = 201 -> 3 workgroups per CU as before.  Epilogue: the kernel above's, unchanged (same C / D map).
 constexpr int kH3K = 16;          // k per chunk
+// developer ablation of head3_kernel (timing only, results wrong): -DSE_HEAD_ABL=<mask>: 1 no K loop, 2 no epilogue loads / stores (LDS round trip kept),
+// 4 no feature / statistics loads, 8 no MFMAs, 16 no activation
+#ifndef SE_HEAD_ABL
+#define SE_HEAD_ABL 0
+#endif
 typedef __attribute__((ext_vector_type(8))) __bf16 h3_bf16x8;
 
 __device__ __forceinline__ void split3(float x, uint16_t& a, uint16_t& b, uint16_t& c) {
@@ -294,7 +299,7 @@ __global__ __launch_bounds__(256, 2) void head3_kernel(const float* __restrict__
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int row0 = blockIdx.x * kHM;
-  const int nchunk = Kp / kH3K;
+  const int nchunk = (SE_HEAD_ABL & 1) ? 0 : Kp / kH3K;
 
   f32x16 acc[NT];
 #pragma unroll
@@ -325,7 +330,7 @@ __global__ __launch_bounds__(256, 2) void head3_kernel(const float* __restrict__
     const int r = it >> 2, c4 = it & 3;                                                                                     \
     const int row = row0 + r, k = (c) * kH3K + 4 * c4;                                                                      \
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f), s0 = make_float4(0.f, 1.f, 0.f, 1.f), s1 = s0;                              \
-    if (row < rows && k < D) {                                                                                              \
+    if (!(SE_HEAD_ABL & 4) && row < rows && k < D) {                                                                        \
       const float* src = feats + (size_t)row * D + k;                                                                       \
       if (k + 3 < D) {                                                                                                      \
         v = *reinterpret_cast<const float4*>(src);                                                                          \
@@ -364,7 +369,7 @@ __global__ __launch_bounds__(256, 2) void head3_kernel(const float* __restrict__
 #pragma unroll
     for (int j = 0; j < kVecIt; ++j) {
       const int i = lane + 64 * j;
-      dst[j] = (linears && vec_io && i < nvec) ? *reinterpret_cast<const float4*>(linears + g + 4 * i) : make_float4(1.f, 1.f, 1.f, 1.f);
+      dst[j] = (!(SE_HEAD_ABL & 2) && linears && vec_io && i < nvec) ? *reinterpret_cast<const float4*>(linears + g + 4 * i) : make_float4(1.f, 1.f, 1.f, 1.f);
     }
   };
   load_lin(0, lin[0]);      // the first pass's rows travel under the whole K loop
@@ -404,6 +409,7 @@ __global__ __launch_bounds__(256, 2) void head3_kernel(const float* __restrict__
       const char* wt = wp + t * 32 * 16;
       const h3_bf16x8 w0 = *reinterpret_cast<const h3_bf16x8*>(wt), w1 = *reinterpret_cast<const h3_bf16x8*>(wt + 2 * NT * 32 * 16),
                       w2 = *reinterpret_cast<const h3_bf16x8*>(wt + 4 * NT * 32 * 16);
+      if (SE_HEAD_ABL & 8) { asm volatile("" :: "v"(w0), "v"(w1), "v"(w2), "v"(a0), "v"(a1), "v"(a2)); continue; }
       // smallest terms first
       acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, w0, acc[t], 0, 0, 0);
       acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, w2, acc[t], 0, 0, 0);
@@ -436,7 +442,7 @@ __global__ __launch_bounds__(256, 2) void head3_kernel(const float* __restrict__
         for (int r8 = 0; r8 < kHHalf / 2; ++r8) {
           const int r = (kHHalf / 2) * h + r8;
           const int rl = (r & 3) + (kHHalf == 16 ? 8 * ((r >> 2) & 1) : 0) + 4 * (lane >> 5);
-          Es[rl * N + n] = apply_act(acc[t][r] + bn[t], act);
+          Es[rl * N + n] = (SE_HEAD_ABL & 16) ? acc[t][r] + bn[t] : apply_act(acc[t][r] + bn[t], act);
         }
       }
     }
@@ -455,6 +461,7 @@ __global__ __launch_bounds__(256, 2) void head3_kernel(const float* __restrict__
           const int i = lane + 64 * j;
           if (i < nvec) {
             const float4 o = *reinterpret_cast<const float4*>(Es + 4 * i);
+            if (SE_HEAD_ABL & 2) { asm volatile("" :: "v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w)); continue; }
             if (offset) *reinterpret_cast<float4*>(offset + g + 4 * i) = o;
             if (predicted) {
               const float4 l = lin[h & 1][j];
@@ -485,6 +492,7 @@ __global__ __launch_bounds__(256, 2) void head3_kernel(const float* __restrict__
 
 // internal (not part of the public header): column statistics shared with head_bwd.hip
 extern "C" int se_head_colstats_f32(const float* feats, int B, int F, int D, float eps, float* stats, void* stream) {
+  SE_REQUIRE(feats && stats && B > 0 && B <= 65535 && F >= 2 && D > 0, "se_head_colstats_f32: bad argument (B=%d F=%d D=%d)", B, F, D);
   hipLaunchKernelGGL(se::colstats_kernel, dim3((D + 63) / 64, B), dim3(256), 0, se::as_stream(stream), feats, F, D, eps, stats);
   SE_LAUNCH_CHECK();
   return SE_OK;
@@ -562,5 +570,40 @@ extern "C" int se_head_linear_f32(const float* feats, const float* W, const floa
     case 6: return launch_head<6>(feats, W, bias, linears, stats, rows, F, D, N, act, predicted, offset, st);
     case 7: return launch_head<7>(feats, W, bias, linears, stats, rows, F, D, N, act, predicted, offset, st);
     default: return launch_head<8>(feats, W, bias, linears, stats, rows, F, D, N, act, predicted, offset, st);
+  }
+}
+
+
+// ---- round 5: the evaluate()-style pass calls the head once per batch with the SAME weights and with column statistics that the feature launch
+// has already produced (se_features3_f32's colstats_out: every feature row is in LDS there).  se_head_linear_f32 re-splits the weights and
+// re-reads the features for the statistics on every call (two launches + 123 MB at 256 utterances); these entry points take both ready-made.
+extern "C" size_t se_head_w3_bytes(int N, int D) {
+  const size_t rows_p = (size_t)((N + 31) / 32) * 32, Kp = (size_t)((D + 15) / 16) * 16;
+  return 3 * rows_p * Kp * sizeof(uint16_t);
+}
+
+extern "C" int se_head_split_weights_f32(const float* W, int N, int D, uint16_t* W3, void* stream) {
+  SE_REQUIRE(W && W3 && N > 0 && N <= 256 && D > 0, "se_head_split_weights_f32: bad argument (N=%d D=%d)", N, D);
+  const int rows_p = (N + 31) / 32 * 32, Kp = (D + 15) / 16 * 16;
+  hipLaunchKernelGGL(se::head_split_w_kernel, dim3((rows_p * Kp + 255) / 256), dim3(256), 0, se::as_stream(stream), W, N, D, rows_p, Kp, W3);
+  SE_LAUNCH_CHECK();
+  return SE_OK;
+}
+
+extern "C" int se_head_linear_pre_f32(const float* feats, const uint16_t* W3, const float* bias, const float* linears, const float* stats,
+                                      int B, int F, int D, int N, int act, float* predicted, float* offset, void* stream) {
+  SE_REQUIRE(feats && W3 && (predicted || offset), "se_head_linear_pre_f32: null argument");
+  SE_REQUIRE(B > 0 && B <= 65535 && F >= 2 && D > 0 && N > 0 && N <= 256, "se_head_linear_pre_f32: bad shape B=%d F=%d D=%d N=%d (N <= 256)", B, F, D, N);
+  hipStream_t st = se::as_stream(stream);
+  const int rows = B * F, nt = (N + 31) / 32, Kp = (D + 15) / 16 * 16;
+  switch (nt) {
+    case 1: return launch_head3<1>(feats, W3, Kp, bias, linears, stats, rows, F, D, N, act, predicted, offset, st);
+    case 2: return launch_head3<2>(feats, W3, Kp, bias, linears, stats, rows, F, D, N, act, predicted, offset, st);
+    case 3: return launch_head3<3>(feats, W3, Kp, bias, linears, stats, rows, F, D, N, act, predicted, offset, st);
+    case 4: return launch_head3<4>(feats, W3, Kp, bias, linears, stats, rows, F, D, N, act, predicted, offset, st);
+    case 5: return launch_head3<5>(feats, W3, Kp, bias, linears, stats, rows, F, D, N, act, predicted, offset, st);
+    case 6: return launch_head3<6>(feats, W3, Kp, bias, linears, stats, rows, F, D, N, act, predicted, offset, st);
+    case 7: return launch_head3<7>(feats, W3, Kp, bias, linears, stats, rows, F, D, N, act, predicted, offset, st);
+    default: return launch_head3<8>(feats, W3, Kp, bias, linears, stats, rows, F, D, N, act, predicted, offset, st);
   }
 }

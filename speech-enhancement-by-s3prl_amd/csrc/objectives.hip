@@ -136,7 +136,111 @@ __global__ __launch_bounds__(256) void wsd_kernel(const float* __restrict__ inp,
   block_add3(a0, a1, 0.0, sums);
 }
 
+// ---- round 5: the criterion of the evaluate()-style pass as TWO launches and nothing else (objective.py:81-100 is one call): no clearing launch
+// (per-(utterance, chunk) partial sums go to their own slots of a slab instead of three atomics), frame counts derived inside from the waveform
+// lengths (len_div > 0: frames = lengths / len_div + 1, runner.py:455), the mean over the utterances formed by the final launch (the torch tail of
+// _SISDRFn.forward was six element-wise launches of ~5 us each).  The sum order is fixed: the loss is reproducible run to run.
+__device__ __forceinline__ int frames_of(const int64_t* __restrict__ lengths, int b, int len_div, int F) {
+  const int wl = (int)min(max(lengths[b], (int64_t)0), (int64_t)0x7fffffff);
+  return min(F, len_div > 0 ? wl / len_div + 1 : wl);
+}
+
+__global__ __launch_bounds__(256) void sisdr_spec_slab_kernel(const float* __restrict__ pred, const float* __restrict__ tar,
+                                                              const int64_t* __restrict__ lengths, int len_div, int F, int N, double* __restrict__ slab) {
+  __shared__ double red[3][4];
+  const int b = blockIdx.y;
+  const int64_t L = (int64_t)frames_of(lengths, b, len_div, F) * N;
+  const float* p = pred + (size_t)b * F * N;
+  const float* t = tar + (size_t)b * F * N;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x;
+  for (; i + 3 * stride < L; i += 4 * stride) {
+    float pv[4], tv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { pv[u] = p[i + u * stride]; tv[u] = t[i + u * stride]; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float s = sqrtf(fmaxf(pv[u], 0.f)), y = sqrtf(fmaxf(tv[u], 0.f));
+      a0 += (double)s * y;
+      a1 += (double)y * y;
+      a2 += (double)s * s;
+    }
+  }
+  for (; i < L; i += stride) {
+    const float s = sqrtf(fmaxf(p[i], 0.f)), y = sqrtf(fmaxf(t[i], 0.f));
+    a0 += (double)s * y;
+    a1 += (double)y * y;
+    a2 += (double)s * s;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    a0 += __shfl_xor(a0, off);
+    a1 += __shfl_xor(a1, off);
+    a2 += __shfl_xor(a2, off);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = a0;
+    red[1][threadIdx.x >> 6] = a1;
+    red[2][threadIdx.x >> 6] = a2;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3)
+    slab[((size_t)b * gridDim.x + blockIdx.x) * 3 + threadIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+
+// one workgroup: loss_b[b] from the slab rows of utterance b (per_b slots of 3 doubles; `first` / `count` select them: the head's fused form keeps
+// one slot pair per 128-row workgroup instead of per chunk), then out = {sum_b loss_b, B} and loss = their ratio
+__global__ __launch_bounds__(256) void sisdr_spec_mean_kernel(const double* __restrict__ slab, int per_b, int B, float eps, float* __restrict__ loss_b,
+                                                              double* __restrict__ out, float* __restrict__ loss) {
+  __shared__ double red[4];
+  double acc = 0.0;
+  for (int b = threadIdx.x; b < B; b += 256) {
+    double S = 0.0, T2 = 0.0, Q = 0.0;
+    const double* r = slab + (size_t)b * per_b * 3;
+    for (int c = 0; c < per_b; ++c) { S += r[3 * c]; T2 += r[3 * c + 1]; Q += r[3 * c + 2]; }
+    const double e = (double)eps;
+    const double a = S / (T2 + e);
+    const double ay2 = a * a * T2;
+    const double norm = a * a * T2 - 2.0 * a * S + Q + e;
+    const float lb = (float)(-10.0 * log10(ay2 / norm + e));
+    loss_b[b] = lb;
+    acc += (double)lb;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double sum = (red[0] + red[1]) + (red[2] + red[3]);
+    out[0] = sum;
+    out[1] = (double)B;
+    *loss = (float)(sum / (double)B);
+  }
+}
+
 }  // namespace se
+
+// partial-sum slots per utterance: enough workgroups to fill the chip (~2 048 in all), no more -- the one-workgroup mean launch walks them
+static int sisdr_loss_chunks(int B, int F, int N) {
+  const int64_t by_size = ((int64_t)F * N + 8191) / 8192;
+  return (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(64, by_size), std::max(1, 2048 / B)));
+}
+
+extern "C" size_t se_sisdr_spec_loss_scratch_doubles(int B, int F, int N) { return (size_t)B * sisdr_loss_chunks(B, F, N) * 3; }
+
+extern "C" int se_sisdr_spec_loss_f32(const float* predicted, const float* linear_tar, const int64_t* lengths, int len_div, int B, int F, int N, float eps,
+                                      double* scratch, float* loss_b, double* sums_out, float* loss_out, void* stream) {
+  SE_REQUIRE(predicted && linear_tar && lengths && scratch && loss_b && sums_out && loss_out, "se_sisdr_spec_loss_f32: null argument");
+  SE_REQUIRE(B > 0 && B <= 65535 && F > 0 && N > 0 && len_div >= 0, "se_sisdr_spec_loss_f32: bad shape");
+  hipStream_t st = se::as_stream(stream);
+  const int chunks = sisdr_loss_chunks(B, F, N);
+  hipLaunchKernelGGL(se::sisdr_spec_slab_kernel, dim3(chunks, B), dim3(256), 0, st, predicted, linear_tar, lengths, len_div, F, N, scratch);
+  SE_LAUNCH_CHECK();
+  hipLaunchKernelGGL(se::sisdr_spec_mean_kernel, dim3(1), dim3(256), 0, st, scratch, chunks, B, eps, loss_b, sums_out, loss_out);
+  SE_LAUNCH_CHECK();
+  return SE_OK;
+}
 
 extern "C" int se_sisdr_spec_f32(const float* predicted, const float* linear_tar, const int64_t* frame_lengths, int B, int F, int N, float eps,
                                  float grad_scale, double* scratch, float* loss_b, float* grad, void* stream) {

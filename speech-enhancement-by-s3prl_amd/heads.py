@@ -107,6 +107,20 @@ class LinearResidual(nn.Module):
                                                 self.cmvn, self.eps)
         return predicted, {'offset': offset}
 
+    def _w3(self, dev):
+        """the three-term bf16 split of the weights (se_head_split_weights_f32), rebuilt when the parameter changed (in-place update, new storage, device)"""
+        w = self.linear.weight
+        key = (w.data_ptr(), w._version, str(dev))
+        c = getattr(self, '_w3_cache', None)
+        if c is None or c[0] != key:
+            lib = _lib.load()
+            N, D = w.shape
+            wf = w.detach().contiguous().float()
+            w3 = torch.empty(int(lib.se_head_w3_bytes(N, D)), device=dev, dtype=torch.uint8)
+            _lib.check(lib.se_head_split_weights_f32(_lib.ptr(wf), N, D, _lib.ptr(w3), _lib.stream()), 'se_head_split_weights_f32')
+            c = self._w3_cache = (key, w3)
+        return c[1]
+
     def _forward_lazy(self, features, linears):
         from .preprocessor import LazyTensor
         lib = _lib.load()
@@ -114,19 +128,32 @@ class LinearResidual(nn.Module):
         N = self.linear.weight.shape[0]
         feats = features.contiguous().float()
         lin = linears.contiguous().float()
-        w, b = self.linear.weight.detach().float().clone(), self.linear.bias.detach().float().clone()
         act, cmvn, eps = self._act, int(self.cmvn), float(self.eps)
+        # column statistics: handed over by the feature launch (preprocessor.head_stats_eps; every feature row was in LDS there) when they belong to
+        # exactly this tensor and this eps -- otherwise one pass over the features here
+        stats = None
+        if cmvn:
+            side = getattr(features, '_se_colstats', None)
+            if side is not None and side[1] == eps and side[2] == features._version and feats.data_ptr() == features.data_ptr():
+                stats = side[0]
+            else:
+                stats = torch.empty(B, D, 2, device=feats.device, dtype=torch.float32)
+                _lib.check(lib.se_head_colstats_f32(_lib.ptr(feats), B, F, D, eps, _lib.ptr(stats), _lib.stream()), 'se_head_colstats_f32')
+        w3 = self._w3(feats.device)
+        bias = self.linear.bias.detach().contiguous().float()         # no copy for an fp32 parameter
+        wkey = (self.linear.weight.data_ptr(), self.linear.weight._version, self.linear.bias._version)
 
         def run(want_offset):
+            if (self.linear.weight.data_ptr(), self.linear.weight._version, self.linear.bias._version) != wkey:
+                raise RuntimeError('LinearResidual: the parameters changed after forward() returned and before its lazy `offset` was read; read it first '
+                                   '(or set head.lazy_offset = False)')
             out = torch.empty(B, F, N, device=feats.device, dtype=torch.float32)
-            nbytes = lib.se_head_workspace_bytes(B, F, D, N)
-            ws = torch.empty(nbytes, device=feats.device, dtype=torch.uint8)
             if want_offset:      # the mask itself: the same launch without the noisy-power product
-                _lib.check(lib.se_head_linear_f32(_lib.ptr(feats), _lib.ptr(w), _lib.ptr(b), None, B, F, D, N, act, cmvn, eps, _lib.ptr(out), None,
-                                                  _lib.ptr(ws), nbytes, _lib.stream()), 'se_head_linear_f32')
+                _lib.check(lib.se_head_linear_pre_f32(_lib.ptr(feats), _lib.ptr(w3), _lib.ptr(bias), None, _lib.ptr(stats), B, F, D, N, act, _lib.ptr(out), None,
+                                                      _lib.stream()), 'se_head_linear_pre_f32')
             else:
-                _lib.check(lib.se_head_linear_f32(_lib.ptr(feats), _lib.ptr(w), _lib.ptr(b), _lib.ptr(lin), B, F, D, N, act, cmvn, eps, _lib.ptr(out), None,
-                                                  _lib.ptr(ws), nbytes, _lib.stream()), 'se_head_linear_f32')
+                _lib.check(lib.se_head_linear_pre_f32(_lib.ptr(feats), _lib.ptr(w3), _lib.ptr(bias), _lib.ptr(lin), _lib.ptr(stats), B, F, D, N, act, _lib.ptr(out), None,
+                                                      _lib.stream()), 'se_head_linear_pre_f32')
             return out
         predicted = run(False)
         return predicted, {'offset': LazyTensor((B, F, N), feats.device, lambda: run(True))}

@@ -179,17 +179,25 @@ class HeadEnhanceStep:
 
     def __init__(self, preprocessor, head, criterion=None):
         self.pre, self.head, self.criterion = preprocessor, head, criterion
+        if getattr(head, 'cmvn', False) and hasattr(head, 'eps'):
+            # the head normalises its input over time (model.py:29-31): the feature launch has every row in LDS and hands the statistics over
+            self.pre.head_stats_eps = float(head.eps)
 
     @torch.no_grad()
     def __call__(self, wavs, lengths, max_len=None):
+        from .objective import SISDR
         feats_up, feats_down, lin_inp, ph_inp, lin_tar, ph_tar = self.pre(wavs)
         predicted, res = self.head(features=feats_down, linears=lin_inp)
         wav_tar = wavs[:, self.pre.channel_tar, :]
         wav_pred = decode.decode_wav(self.pre, predicted, ph_inp, lengths, wav_tar, max_len=max_len)
         loss = None
         if self.criterion is not None:
-            stft_lengths = lengths // self.pre._win_args['hop_length'] + 1
-            loss, _ = self.criterion(predicted=predicted, linear_inp=lin_inp, linear_tar=lin_tar, stft_lengths=stft_lengths, **res)
+            hop = self.pre._win_args['hop_length']
+            if isinstance(self.criterion, (L1, SISDR)):      # frame counts derived inside the kernel (runner.py:455): no element-wise launches in front
+                lens_kw = {'wav_lengths': lengths, 'hop': hop}
+            else:
+                lens_kw = {'stft_lengths': lengths // hop + 1}
+            loss, _ = self.criterion(predicted=predicted, linear_inp=lin_inp, linear_tar=lin_tar, **lens_kw, **res)
         return wav_pred, predicted, lin_tar, loss
 
 

@@ -326,17 +326,33 @@ class OnlinePreprocessor(nn.Module):
             B, D, F = raw.shape
         Dout = D * (1 + delta)
         out = torch.empty(B, F, Dout, device=raw.device, dtype=torch.float32)
-        nbytes = lib.se_features_workspace_bytes(B, D, F, delta)
-        ws = torch.empty(nbytes, device=raw.device, dtype=torch.uint8)
         side = encoder_side and Dout <= self.ENCODER_IN_PAD
         xin = torch.empty(B * F, self.ENCODER_IN_PAD, device=raw.device, dtype=torch.bfloat16) if side else None
         valid = torch.empty(B, device=raw.device, dtype=torch.int32) if side else None
-        _lib.check(lib.se_features2_f32(_lib.ptr(raw), int(raw_time_major), B, D, F, int(bool(log)), int(delta),
-                                        int(bool(cmvn)), float(self.eps), _lib.ptr(out), _lib.ptr(ws), nbytes,
-                                        _lib.ptr(xin), self.ENCODER_IN_PAD if side else 0, _lib.ptr(valid), _lib.stream()), 'se_features2_f32')
+        if not self.one_pass_features:      # A/B: the round-1 two-launch form through a feature-major intermediate
+            nbytes = lib.se_features_workspace_bytes(B, D, F, delta)
+            ws = torch.empty(nbytes, device=raw.device, dtype=torch.uint8)
+            _lib.check(lib.se_features2_f32(_lib.ptr(raw), int(raw_time_major), B, D, F, int(bool(log)), int(delta),
+                                            int(bool(cmvn)), float(self.eps), _lib.ptr(out), _lib.ptr(ws), nbytes,
+                                            _lib.ptr(xin), self.ENCODER_IN_PAD if side else 0, _lib.ptr(valid), _lib.stream()), 'se_features2_f32')
+        else:
+            nbytes = lib.se_features3_workspace_bytes(B, D, delta) if cmvn else 0
+            ws = torch.empty(nbytes, device=raw.device, dtype=torch.uint8) if cmvn else None
+            # LinearResidual's own CMVN (model.py:29-31) needs the column statistics of exactly these rows: the owner of the head says so
+            # (head_stats_eps, pipeline.HeadEnhanceStep) and they ride on the returned tensor as `_se_colstats`
+            hs_eps = None if (cmvn or encoder_side) else self.head_stats_eps
+            colstats = torch.empty(B, Dout, 2, device=raw.device, dtype=torch.float32) if hs_eps is not None else None
+            _lib.check(lib.se_features3_f32(_lib.ptr(raw), int(raw_time_major), B, D, F, int(bool(log)), int(delta), int(bool(cmvn)), float(self.eps),
+                                            _lib.ptr(out), _lib.ptr(ws), nbytes, _lib.ptr(xin), self.ENCODER_IN_PAD if side else 0, _lib.ptr(valid),
+                                            _lib.ptr(colstats), float(hs_eps) if hs_eps is not None else 0.0, _lib.stream()), 'se_features3_f32')
+            if colstats is not None:
+                out._se_colstats = (colstats, float(hs_eps))
         if side:
             out._se_side = (xin, valid)
         return out
+
+    one_pass_features = True       # False: se_features2_f32 (two launches, feature-major intermediate)
+    head_stats_eps = None          # eps of a LinearResidual(cmvn=True) fed by these features: its column statistics come out of the feature launch
 
     def forward(self, wavs=None, feat_list=None):
         # wavs: (batch_size, channel, max_len); returns [(batch, max_feat_len, feat_dim), ...]
@@ -403,10 +419,13 @@ class OnlinePreprocessor(nn.Module):
             else:
                 feat = raw
             side = getattr(feat, '_se_side', None)
+            cst = getattr(feat, '_se_colstats', None)
             feat = feat.reshape(*lead, *feat.shape[-2:]).to(home)
             if side is not None:
                 if not feat.is_inference():                       # inference tensors track no version: no hand-off, the encoder recomputes its operand
                     feat._se_side = side + (feat._version,)       # (bf16 rows, valid-frame counts, version the pair belongs to)
+            if cst is not None and feat.is_cuda and not feat.is_inference():
+                feat._se_colstats = cst + (feat._version,)        # (statistics, eps, version of the tensor they describe)
             done[key] = feat
             feats.append(feat)
         return feats
