@@ -131,6 +131,7 @@ int se_features2_f32(const float* raw, int raw_time_major, int B, int D, int F,
  * (mean over time, 1 / (unbiased std + colstats_eps)) of the rows written to `out` -- what LinearResidual's own CMVN (model.py:29-31) needs, handed to
  * se_head_linear_pre_f32 so that the head does not read the features a second time for it.  Side outputs as se_features2_f32. */
 size_t se_features3_workspace_bytes(int B, int D, int delta);
+size_t se_features3_colstats_workspace_bytes(int B, int D, int F, int delta);      /* workspace when colstats_out != NULL (8-byte aligned) */
 int se_features3_f32(const float* raw, int raw_time_major, int B, int D, int F, int apply_log, int delta, int cmvn, float eps,
                      float* out, void* workspace, size_t workspace_bytes, uint16_t* out_bf16_pad, int ld_pad, int32_t* valid_count,
                      float* colstats_out, float colstats_eps, void* stream);
@@ -203,6 +204,18 @@ int se_head_colstats_f32(const float* feats, int B, int F, int D, float eps, flo
 int se_head_split_weights_f32(const float* W, int N, int D, uint16_t* W3, void* stream);
 int se_head_linear_pre_f32(const float* feats, const uint16_t* W3, const float* bias, const float* linears, const float* stats,
                            int B, int F, int D, int N, int act, float* predicted, float* offset, void* stream);
+
+/* The evaluate()-style pass of a mask head scored by objective.SISDR (runner.py:556-575 with vcb.yaml / pseudo_noise.yaml): se_head_linear_pre_f32
+ * AND se_sisdr_spec_loss_f32 of its `predicted` against linear_tar -- where the kernel allows (201 bins, Sigmoid, F >= 128, 16-B aligned planes) the
+ * criterion's sums are taken from the products on their way out of the head's registers; otherwise the two entry points run one after the other.
+ * lengths / len_div / loss_b / sums_out / loss_out as se_sisdr_spec_loss_f32; scratch: se_head_sisdr_scratch_doubles(B, F, N) doubles. */
+size_t se_head_sisdr_scratch_doubles(int B, int F, int N);
+int se_head_linear_sisdr_f32(const float* feats, const uint16_t* W3, const float* bias, const float* linears, const float* stats,
+                             int B, int F, int D, int N, int act, float* predicted, float* offset,
+                             const float* linear_tar, const int64_t* lengths, int len_div, float eps, double* scratch,
+                             float* loss_b, double* sums_out, float* loss_out, void* stream);
+/* the fold of that fused form's slab (two slots of three doubles per tile_rows-row workgroup): loss_b, {sum, B}, mean */
+int se_sisdr_head_mean_f32(const double* slab, int B, int F, int tile_rows, float eps, float* loss_b, double* sums_out, float* loss_out, void* stream);
 
 /*
  * se_head_linear_bwd_f32 -- autograd of C1/C2 wrt the head parameters (runner.py:459 loss.backward()):

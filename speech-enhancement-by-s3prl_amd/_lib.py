@@ -68,6 +68,7 @@ SIGNATURES = {
     'se_features_f32': (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P, _P, c_size_t, _P]),
     'se_features2_f32': (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P, _P, c_size_t, _P, c_int, _P, _P]),
     'se_features3_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
+    'se_features3_colstats_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int]),
     'se_features3_f32': (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P, _P, c_size_t, _P, c_int, _P, _P, c_float, _P]),
     'se_istft_f32': (c_int, [_P, _P, _P, c_int, c_int, c_float, _P, c_int, _P, _P, _P]),
     'se_masked_sumsq_f32': (c_int, [_P, c_int, c_int, c_int, _P, _P, _P]),
@@ -79,6 +80,9 @@ SIGNATURES = {
     'se_head_w3_bytes': (c_size_t, [c_int, c_int]),
     'se_head_split_weights_f32': (c_int, [_P, c_int, c_int, _P, _P]),
     'se_head_linear_pre_f32': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
+    'se_head_sisdr_scratch_doubles': (c_size_t, [c_int, c_int, c_int]),
+    'se_head_linear_sisdr_f32': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_float, _P, _P, _P, _P, _P]),
+    'se_sisdr_head_mean_f32': (c_int, [_P, c_int, c_int, c_int, c_float, _P, _P, _P, _P]),
     'se_head_linear_bwd_f32': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P, _P, _P, c_size_t, _P]),
     'se_head_dx_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int]),
     'se_head_linear_dx_f32': (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P, _P, c_size_t, _P]),

@@ -203,7 +203,8 @@ constexpr int kTileT = 32;
 
 __global__ __launch_bounds__(256) void feat_tile_kernel(const float* __restrict__ raw, int raw_time_major, int D, int F, int apply_log, int delta,
                                                         int cmvn, float eps, const float* __restrict__ stats, float* __restrict__ out,
-                                                        uint16_t* __restrict__ out_bf16_pad, int ld_pad, int32_t* __restrict__ valid_count) {
+                                                        uint16_t* __restrict__ out_bf16_pad, int ld_pad, int32_t* __restrict__ valid_count,
+                                                        double* __restrict__ col_part) {
   extern __shared__ __attribute__((aligned(16))) float x[];      // (1 + delta) * D rows of pitch P
   const int b = blockIdx.y, t0 = blockIdx.x * kTileT, tid = threadIdx.x;
   const int H = 2 * delta, W = kTileT + 2 * H, P = W + 1;
@@ -282,6 +283,22 @@ __global__ __launch_bounds__(256) void feat_tile_kernel(const float* __restrict_
       o[it] = xt[dd2 * P + tl2];
     }
   }
+  // column statistics of the rows just written, for the mask head's own CMVN (model.py:29-31): this tile's sum and square sum per output column in
+  // fp64 (the products of fp32 values are exact there: the one-pass variance of feat_colstats_fold_kernel equals the two-pass fp32 one to below fp32
+  // resolution, as head.hip's colstats_kernel) -- a second pass over log / deltas for them cost as much as this whole launch
+  if (col_part) {
+    for (int dd = tid; dd < Dout; dd += 256) {
+      double sm = 0.0, sq = 0.0;
+      for (int tl = 0; tl < nt; ++tl) {
+        const double v = (double)xt[dd * P + tl];
+        sm += v;
+        sq = fma(v, v, sq);
+      }
+      double* cp = col_part + (((size_t)b * gridDim.x + blockIdx.x) * Dout + dd) * 2;
+      cp[0] = sm;
+      cp[1] = sq;
+    }
+  }
   if (out_bf16_pad) {
     uint16_t* ob = out_bf16_pad + ((size_t)b * F + t0) * ld_pad;
     const int pairs = ld_pad >> 1;
@@ -308,6 +325,23 @@ __global__ __launch_bounds__(256) void feat_tile_kernel(const float* __restrict_
     __syncthreads();
     if (tid == 0) atomicAdd(&valid_count[b], cnts[0] + cnts[1] + cnts[2] + cnts[3]);
   }
+}
+
+// stats[(b, dd)] = (mean, 1 / (unbiased std + eps)) from the tiles' partial sums (fixed order)
+__global__ __launch_bounds__(256) void feat_colstats_fold_kernel(const double* __restrict__ col_part, int ntile, int Dout, int F, float eps,
+                                                                 float* __restrict__ stats) {
+  const int b = blockIdx.y, dd = blockIdx.x * 256 + threadIdx.x;
+  if (dd >= Dout) return;
+  double S = 0.0, Q = 0.0;
+  const double* cp = col_part + ((size_t)b * ntile * Dout + dd) * 2;
+  for (int t = 0; t < ntile; ++t) {
+    S += cp[(size_t)t * Dout * 2];
+    Q += cp[(size_t)t * Dout * 2 + 1];
+  }
+  const double mean = S / (double)F;
+  const double var = fmax(Q - S * mean, 0.0) / (double)(F - 1);
+  stats[((size_t)b * Dout + dd) * 2] = (float)mean;
+  stats[((size_t)b * Dout + dd) * 2 + 1] = 1.0f / ((float)sqrt(var) + eps);
 }
 
 }  // namespace se
@@ -351,7 +385,11 @@ extern "C" int se_features2_f32(const float* raw, int raw_time_major, int B, int
 }
 
 
+// cmvn: the (mean, std + eps) pairs; colstats_out: the tiles' (sum, square sum) pairs in fp64 (call with the F the launch will get)
 extern "C" size_t se_features3_workspace_bytes(int B, int D, int delta) { return (size_t)B * D * (1 + delta) * 2 * sizeof(float) + 256; }
+extern "C" size_t se_features3_colstats_workspace_bytes(int B, int D, int F, int delta) {
+  return (size_t)B * ((F + se::kTileT - 1) / se::kTileT) * D * (1 + delta) * 2 * sizeof(double) + 256;
+}
 
 extern "C" int se_features3_f32(const float* raw, int raw_time_major, int B, int D, int F, int apply_log, int delta, int cmvn, float eps,
                                 float* out, void* workspace, size_t workspace_bytes, uint16_t* out_bf16_pad, int ld_pad, int32_t* valid_count,
@@ -361,12 +399,14 @@ extern "C" int se_features3_f32(const float* raw, int raw_time_major, int B, int
   SE_REQUIRE(B > 0 && B <= 65535 && D > 0 && D <= 65535 && F >= 2 && delta >= 0 && delta <= 3, "se_features3_f32: bad shape B=%d D=%d F=%d delta=%d", B, D, F, delta);
   SE_REQUIRE(!(cmvn && colstats_out), "se_features3_f32: colstats_out describes un-normalised features (cmvn must be 0)");
   SE_REQUIRE(!cmvn || (workspace && workspace_bytes >= se_features3_workspace_bytes(B, D, delta)), "se_features3_f32: workspace too small");
+  SE_REQUIRE(!colstats_out || (workspace && workspace_bytes >= se_features3_colstats_workspace_bytes(B, D, F, delta) && (uintptr_t)workspace % 8 == 0),
+             "se_features3_f32: colstats_out needs se_features3_colstats_workspace_bytes(B, D, F, delta) bytes of workspace");
   const size_t rows_lds = (size_t)(1 + delta) * F * sizeof(float);
   const int Dout = D * (1 + delta);
   const size_t tile_lds = (size_t)Dout * (se::kTileT + 4 * delta + 1) * sizeof(float);
   SE_REQUIRE(tile_lds <= 120 * 1024, "se_features3_f32: D*(1+delta)=%d too wide for the LDS window", Dout);
   hipStream_t st = se::as_stream(stream);
-  float* stats = cmvn ? reinterpret_cast<float*>(workspace) : colstats_out;
+  float* stats = cmvn ? reinterpret_cast<float*>(workspace) : nullptr;
   if (stats) {
     SE_REQUIRE(rows_lds <= 64 * 1024, "se_features3_f32: F=%d too long for the LDS row buffer", F);
     static const bool wave_rows = getenv("SE_AMD_FEAT_STATS_WG") == nullptr;      // A/B: the workgroup-per-row statistics launch
@@ -384,8 +424,14 @@ extern "C" int se_features3_f32(const float* raw, int raw_time_major, int B, int
   }
   if (tile_lds > 64 * 1024)
     SE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(se::feat_tile_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds));
-  hipLaunchKernelGGL(se::feat_tile_kernel, dim3((F + se::kTileT - 1) / se::kTileT, B), dim3(256), tile_lds, st, raw, raw_time_major, D, F, apply_log,
-                     delta, cmvn, eps, cmvn ? stats : nullptr, out, out_bf16_pad, ld_pad, valid_count);
+  const int ntile = (F + se::kTileT - 1) / se::kTileT;
+  double* col_part = colstats_out ? reinterpret_cast<double*>(workspace) : nullptr;
+  hipLaunchKernelGGL(se::feat_tile_kernel, dim3(ntile, B), dim3(256), tile_lds, st, raw, raw_time_major, D, F, apply_log,
+                     delta, cmvn, eps, cmvn ? stats : nullptr, out, out_bf16_pad, ld_pad, valid_count, col_part);
   SE_LAUNCH_CHECK();
+  if (colstats_out) {
+    hipLaunchKernelGGL(se::feat_colstats_fold_kernel, dim3((Dout + 255) / 256, B), dim3(256), 0, st, col_part, ntile, Dout, F, colstats_eps, colstats_out);
+    SE_LAUNCH_CHECK();
+  }
   return SE_OK;
 }

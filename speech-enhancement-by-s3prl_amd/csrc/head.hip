@@ -10,6 +10,7 @@
 // Bound: HBM (4*F*(D + 2N) bytes per utterance, +4*F*N when `offset` is stored); the f32 MFMA rate
 // (157 TF) puts the GEMM itself at about the same time, so the kernel is balanced, not MFMA-bound.
 #include <stdlib.h>
+#include <algorithm>
 #include "common.h"
 #include "prof.h"
 
@@ -422,7 +423,16 @@ __global__ __launch_bounds__(256, 2) void head3_kernel(const float* __restrict__
 #undef SEH_DMA_W
 #undef SEH_LOAD_F
 
-  // ---- epilogue: as head_kernel (same accumulator map)
+  // ---- epilogue: as head_kernel (same accumulator map).  The slab is private to the wave and an LDS queue serves one wave's instructions in order: what
+  //      the exchange between its lanes needs is the LDS counter drained and the compiler kept from moving LDS accesses across the point.  A
+  //      workgroup-scope fence (the round-3 form, still in head_kernel) also waits for vmcnt(0): every pass then sat out the acknowledgement of its
+  //      own 16-B stores AND the arrival of the next pass's noisy-power rows it had just requested -- the prefetch hid nothing
+#define SEH_LDS_WAVE_SYNC()                                   \
+  do {                                                        \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        \
+    __builtin_amdgcn_wave_barrier();                          \
+    asm volatile("" ::: "memory");                            \
+  } while (0)
   __syncthreads();
   float* Es = reinterpret_cast<float*>(smem3) + wave * (kHHalf * NT * 32);
   float bn[NT];
@@ -446,9 +456,7 @@ __global__ __launch_bounds__(256, 2) void head3_kernel(const float* __restrict__
         }
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    SEH_LDS_WAVE_SYNC();
     const int rbase = row0 + wave * 32 + kHHalf * h;
     const int nrow = min(kHHalf, rows - rbase);
     if (nrow > 0) {
@@ -482,9 +490,325 @@ __global__ __launch_bounds__(256, 2) void head3_kernel(const float* __restrict__
         }
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    SEH_LDS_WAVE_SYNC();
+  }
+}
+
+#undef SEH_LDS_WAVE_SYNC
+
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+// Round 5: head3_kernel without its control flow.  The ablation of head3 at 256 utterances (tools/one_head.py, -DSE_HEAD_ABL: 234 us = K loop 118
+// [feature loads 79, MFMAs 44] + epilogue traffic 74 + activation 41, nothing overlapping anything) and its ISA said why: `act` is a run-time switch
+// evaluated per output element (branches around every v_exp / v_rcp), the feature / statistics loads sit in nested conditionals whose merges the
+// compiler resolves with s_waitcnt vmcnt(0) INSIDE the "prefetch", and the workgroup-scope fences of the epilogue wait for vmcnt(0) too -- each
+// pass sat out its own stores and the rows it had just requested.  Here:
+//   * ACT is a template parameter; N, alignment and F >= 128 are launcher preconditions (anything else runs head3_kernel)
+//   * the CMVN statistics of the (at most two) utterances a 128-row tile touches are staged in LDS once; a chunk's feature items are then ONE
+//     unconditional 16-B load each (row and column clamped into the tensor; the column shift is undone in registers), issued THREE chunks ahead into
+//     statically named registers (the chunk loop is unrolled by three), with hand-counted vmcnt beside the weight DMA
+//   * the epilogue's lane exchange through the wave's private LDS slab waits for the LDS counter only
+//   * SIS: the SISDR criterion's three sums (objective.py:81-100: <s, t>, <t, t>, <s, s> of the square-rooted planes over the valid frames) are taken from
+//     the products on their way out -- one extra plane read instead of a launch that reads two -- per workgroup and utterance into a slab that
+//     sisdr_head_mean_kernel (objectives.hip) folds in a fixed order
+template <int ACT>
+__device__ __forceinline__ float act_c(float v) {
+  if constexpr (ACT == SE_ACT_RELU) return fmaxf(v, 0.f);
+  else if constexpr (ACT == SE_ACT_SIGMOID) return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * v));
+  else if constexpr (ACT == SE_ACT_GELU) return v * 0.5f * (1.0f + erff(v * 0.70710678118654752f));
+  else if constexpr (ACT == SE_ACT_EXP) return expf(v);
+  else return v;
+}
+
+constexpr int kH5StatCols = 256;      // Kp <= 256
+
+template <int NT, int ACT, int SIS>
+__global__ __launch_bounds__(256, 2) void head5_kernel(const float* __restrict__ feats, const uint16_t* __restrict__ W3, int Kp,
+                                                       const float* __restrict__ bias, const float* __restrict__ linears,
+                                                       const float* __restrict__ stats, int rows, int F, int D, int N,
+                                                       float* __restrict__ predicted, float* __restrict__ offset,
+                                                       const float* __restrict__ tar, const int64_t* __restrict__ lengths, int len_div,
+                                                       double* __restrict__ slab) {
+  constexpr int kWBuf = 3 * 2 * NT * 32 * 16;
+  constexpr int kABuf = 3 * 2 * kHM * 16;
+  constexpr int kStage = 2 * kWBuf + 2 * kABuf;
+  constexpr int kEpi = 4 * kHHalf * (NT * 32) * 4;
+  constexpr int kMain = kStage > kEpi ? kStage : kEpi;
+  constexpr int kPieces = kWBuf / 1024;                              // 3 NT
+  constexpr int kWIss = (kPieces + 3) / 4;                           // weight DMAs per wave and chunk (the last one may repeat a piece)
+  __shared__ __attribute__((aligned(16))) char smem5[kMain + 2 * kH5StatCols * 8 + 64];
+  char* Ws = smem5;
+  char* As = smem5 + 2 * kWBuf;
+  float2* St = reinterpret_cast<float2*>(smem5 + kMain);            // [2 utterances][Kp] (mean, 1 / (std + eps))
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int row0 = blockIdx.x * kHM;
+  const int nchunk = Kp / kH3K;
+  const int b0 = row0 / F;
+  const int boundary = (b0 + 1) * F;                                 // first row of the tile's second utterance (F >= 128: there is no third)
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  typedef __attribute__((address_space(3))) char* lds_h_t;
+  const uint32_t lds_w = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(lds_h_t)smem5);
+  const char* wbase = reinterpret_cast<const char*>(W3);
+#define SE5_DMA_W(c)                                                                                                        \
+  do {                                                                                                                      \
+    const char* sb_ = wbase + (size_t)(c) * kWBuf;                                                                          \
+    _Pragma("unroll") for (int q_ = 0; q_ < kWIss; ++q_) {                                                                  \
+      const int j_ = min(wave + 4 * q_, kPieces - 1);                                                                       \
+      const uint32_t off_ = (uint32_t)(j_ * 1024 + lane * 16);                                                              \
+      uint32_t keep_;                                                                                                       \
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"  \
+                   : "=&s"(keep_) : "v"(off_), "s"(sb_), "s"(lds_w + (uint32_t)(((c) & 1) * kWBuf + j_ * 1024)) : "memory"); \
+    }                                                                                                                       \
+  } while (0)
+
+  // ---- this thread's two feature items per chunk: rows r and 64 + r, 16-B piece c4
+  const int fr = tid >> 2, c4 = tid & 3;
+  const float* fp0 = feats + (size_t)min(row0 + fr, rows - 1) * D;
+  const float* fp1 = feats + (size_t)min(row0 + 64 + fr, rows - 1) * D;
+  const int su0 = (row0 + fr >= boundary) ? Kp : 0, su1 = (row0 + 64 + fr >= boundary) ? Kp : 0;
+  float4 fv[3][2];
+#define SE5_LOAD_F(c, s)                                                                                                    \
+  do {                                                                                                                      \
+    const int kk_ = min((c) * kH3K + 4 * c4, D - 4);                                                                        \
+    fv[s][0] = *reinterpret_cast<const float4*>(fp0 + kk_);                                                                 \
+    fv[s][1] = *reinterpret_cast<const float4*>(fp1 + kk_);                                                                 \
+  } while (0)
+
+  // statistics of the tile's two utterances: requested FIRST (they are the oldest loads when their LDS stores wait for them, so that wait leaves the
+  // weight DMA and the feature loads behind them in flight), stored to LDS after everything else of the prologue has been issued
+  float2 sv[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int i = tid + 256 * q;
+    const int u = i >= Kp ? 1 : 0, k = i - u * Kp;
+    sv[q] = make_float2(0.f, 1.f);
+    if (stats && i < 2 * Kp && k < D && (size_t)(b0 + u) * F < (size_t)rows) sv[q] = *reinterpret_cast<const float2*>(stats + ((size_t)(b0 + u) * D + k) * 2);
+  }
+  SE5_DMA_W(0);
+  SE5_LOAD_F(0, 0);
+  if (nchunk > 1) SE5_LOAD_F(1, 1);
+  if (nchunk > 2) SE5_LOAD_F(2, 2);
+  // the noisy-power rows (and, SIS, the target rows) of a pass: ONE register set each, item j re-requested for the next pass right after pass h has
+  // used it (between that pass's stores) -- a pass of look-ahead for both planes in 2 x 28 registers; the first pass's rows travel under the K loop
+  constexpr int kVecIt = (kHHalf * NT * 32 / 4 + 63) / 64;
+  float4 lin[kVecIt], tv[SIS ? kVecIt : 1];
+  auto load_item = [&](const float* __restrict__ src, int h, int j, float fill) -> float4 {
+    const int rbase = row0 + wave * 32 + kHHalf * h;
+    const int nrow = min(kHHalf, rows - rbase);
+    const int nvec = nrow > 0 ? (nrow * N) >> 2 : 0;
+    const int i = lane + 64 * j;
+    return (src && h < 32 / kHHalf && i < nvec) ? *reinterpret_cast<const float4*>(src + (size_t)rbase * N + 4 * i) : make_float4(fill, fill, fill, fill);
+  };
+#pragma unroll
+  for (int j = 0; j < kVecIt; ++j) {
+    lin[j] = load_item(linears, 0, j, 1.f);
+    if constexpr (SIS) tv[j] = load_item(tar, 0, j, 0.f);
+  }
+  St[tid] = sv[0];
+  if (tid + 256 < 2 * Kp) St[tid + 256] = sv[1];
+  __syncthreads();                                                   // statistics visible (the first split reads them)
+
+  // one chunk: S = c % 3 (static).  Issue order per wave: prologue [W(0) F(0) F(1) F(2) ...], then per chunk c [W(c + 1) F(c + 3)]; at the top of
+  // chunk c the only younger group that may stay in flight is F(c + 2) (two loads) -- at c = 0 F(1) and F(2)
+#define SE5_CHUNK(c, S)                                                                                                     \
+  do {                                                                                                                      \
+    if ((c) == 0) {                                                                                                         \
+      if (nchunk > 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                                      \
+      else if (nchunk > 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                                                 \
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                 \
+    } else if ((c) + 2 < nchunk) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                                           \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                   \
+    char* Ab = As + ((c) & 1) * kABuf;                                                                                      \
+    const int k_ = (c) * kH3K + 4 * c4;                                                                                     \
+    const int sh_ = k_ - min(k_, D - 4);              /* 0 inside the row; 1..3 on its last piece; >= 4 past it */           \
+    _Pragma("unroll") for (int rep = 0; rep < 2; ++rep) {                                                                   \
+      const float4 a = fv[S][rep];                                                                                          \
+      float4 v;                                                                                                             \
+      v.x = sh_ == 0 ? a.x : sh_ == 1 ? a.y : sh_ == 2 ? a.z : sh_ == 3 ? a.w : 0.f;                                        \
+      v.y = sh_ == 0 ? a.y : sh_ == 1 ? a.z : sh_ == 2 ? a.w : 0.f;                                                         \
+      v.z = sh_ == 0 ? a.z : sh_ == 1 ? a.w : 0.f;                                                                          \
+      v.w = sh_ == 0 ? a.w : 0.f;                                                                                           \
+      const float4* sp = reinterpret_cast<const float4*>(St + (rep ? su1 : su0) + k_);                                      \
+      const float4 s0 = sp[0], s1 = sp[1];                                                                                  \
+      v = make_float4((v.x - s0.x) * s0.y, (v.y - s0.z) * s0.w, (v.z - s1.x) * s1.y, (v.w - s1.z) * s1.w);                  \
+      uint16_t p0[4], p1[4], p2[4];                                                                                         \
+      split3(v.x, p0[0], p1[0], p2[0]);                                                                                     \
+      split3(v.y, p0[1], p1[1], p2[1]);                                                                                     \
+      split3(v.z, p0[2], p1[2], p2[2]);                                                                                     \
+      split3(v.w, p0[3], p1[3], p2[3]);                                                                                     \
+      char* d = Ab + ((c4 >> 1) * kHM + fr + 64 * rep) * 16 + (c4 & 1) * 8;                                                 \
+      *reinterpret_cast<uint2*>(d) = make_uint2(p0[0] | ((uint32_t)p0[1] << 16), p0[2] | ((uint32_t)p0[3] << 16));          \
+      *reinterpret_cast<uint2*>(d + 2 * kHM * 16) = make_uint2(p1[0] | ((uint32_t)p1[1] << 16), p1[2] | ((uint32_t)p1[3] << 16)); \
+      *reinterpret_cast<uint2*>(d + 4 * kHM * 16) = make_uint2(p2[0] | ((uint32_t)p2[1] << 16), p2[2] | ((uint32_t)p2[3] << 16)); \
+    }                                                                                                                       \
+    __syncthreads();                                                                                                        \
+    if ((c) + 1 < nchunk) SE5_DMA_W((c) + 1);                                                                               \
+    if ((c) + 3 < nchunk) SE5_LOAD_F((c) + 3, S);                                                                           \
+    const char* ap = Ab + (wave * 32 + (lane & 31)) * 16 + (lane >> 5) * (kHM * 16);                                        \
+    const char* wp = Ws + ((c) & 1) * kWBuf + (lane & 31) * 16 + (lane >> 5) * (NT * 32 * 16);                              \
+    const h3_bf16x8 a0 = *reinterpret_cast<const h3_bf16x8*>(ap), a1 = *reinterpret_cast<const h3_bf16x8*>(ap + 2 * kHM * 16), \
+                    a2 = *reinterpret_cast<const h3_bf16x8*>(ap + 4 * kHM * 16);                                            \
+    _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                                                        \
+      const char* wt = wp + t * 32 * 16;                                                                                    \
+      const h3_bf16x8 w0 = *reinterpret_cast<const h3_bf16x8*>(wt), w1 = *reinterpret_cast<const h3_bf16x8*>(wt + 2 * NT * 32 * 16), \
+                      w2 = *reinterpret_cast<const h3_bf16x8*>(wt + 4 * NT * 32 * 16);                                      \
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, w0, acc[t], 0, 0, 0);      /* smallest terms first, as head3_kernel */ \
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, w2, acc[t], 0, 0, 0);                                            \
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, w1, acc[t], 0, 0, 0);                                            \
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, w0, acc[t], 0, 0, 0);                                            \
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, w1, acc[t], 0, 0, 0);                                            \
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, w0, acc[t], 0, 0, 0);                                            \
+    }                                                                                                                       \
+  } while (0)
+
+  for (int c = 0; c < nchunk; c += 3) {
+    SE5_CHUNK(c, 0);
+    if (c + 1 < nchunk) SE5_CHUNK(c + 1, 1);
+    if (c + 2 < nchunk) SE5_CHUNK(c + 2, 2);
+  }
+#undef SE5_CHUNK
+#undef SE5_DMA_W
+#undef SE5_LOAD_F
+
+  // ---- epilogue (accumulator map and LDS slab as head3_kernel; 16-B global accesses only: the launcher checked the alignment)
+  __syncthreads();
+#define SE5_LDS_WAVE_SYNC()                                   \
+  do {                                                        \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        \
+    __builtin_amdgcn_wave_barrier();                          \
+    asm volatile("" ::: "memory");                            \
+  } while (0)
+  float* Es = reinterpret_cast<float*>(smem5) + wave * (kHHalf * NT * 32);
+  float bn[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int n = t * 32 + (lane & 31);
+    bn[t] = (bias && n < N) ? bias[n] : 0.f;
+  }
+  // SIS: valid frames of the tile's two utterances, and the running sums {<s,t>, <t,t>, <s,s>} of each
+  int len0 = 0, len1 = 0;
+  double sa[3] = {0.0, 0.0, 0.0}, sb[3] = {0.0, 0.0, 0.0};
+  if constexpr (SIS) {
+    const int nutt = (rows + F - 1) / F;
+    auto frames = [&](int b) {
+      if (b >= nutt) return 0;
+      const int wl = (int)min(max(lengths[b], (int64_t)0), (int64_t)0x7fffffff);
+      return min(F, len_div > 0 ? wl / len_div + 1 : wl);
+    };
+    len0 = frames(b0);
+    len1 = frames(b0 + 1);
+  }
+  const uint32_t magic = (1u << 20) / (uint32_t)N + 1u;             // e / N == (e * magic) >> 20 for e < 2 048, N <= 256
+  (void)magic;
+#pragma unroll
+  for (int h = 0; h < 32 / kHHalf; ++h) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int n = t * 32 + (lane & 31);
+      if (n < N) {
+#pragma unroll
+        for (int r8 = 0; r8 < kHHalf / 2; ++r8) {
+          const int r = (kHHalf / 2) * h + r8;
+          const int rl = (r & 3) + (kHHalf == 16 ? 8 * ((r >> 2) & 1) : 0) + 4 * (lane >> 5);
+          Es[rl * N + n] = act_c<ACT>(acc[t][r] + bn[t]);
+        }
+      }
+    }
+    SE5_LDS_WAVE_SYNC();
+    const int rbase = row0 + wave * 32 + kHHalf * h;
+    const int nrow = min(kHHalf, rows - rbase);
+    if (nrow > 0) {
+      const int cnt = nrow * N;
+      const size_t g = (size_t)rbase * N;
+      const int nvec = cnt >> 2;
+      // SIS: element e of the pass belongs to utterance b0 while e < eb, to b0 + 1 from there on; valid while e < lim0 resp. eb <= e < lim1
+      int eb = 0, lim0 = 0, lim1 = 0;
+      if constexpr (SIS) {
+        eb = min(max(boundary - rbase, 0), nrow) * N;
+        lim0 = min(max(len0 - (rbase - b0 * F), 0) * N, eb);
+        lim1 = eb + min(max(len1 - max(rbase - boundary, 0), 0), nrow) * N;
+        lim1 = min(lim1, cnt);
+      }
+      // a pass's <= 28 elements per lane are summed in fp32 (hardware square roots, masks as selects: ~12 issue slots per element; the fp64 form of
+      // sisdr_spec_slab_kernel -- two precise square roots, three fp64 products and six fp64 fused adds per element -- made this launch 300 us where
+      // head + criterion as two launches take 260), the passes in fp64
+      float pa[3] = {0.f, 0.f, 0.f}, pb[3] = {0.f, 0.f, 0.f};
+      const bool straddle = SIS && eb < cnt && eb > 0;
+#pragma unroll
+      for (int j = 0; j < kVecIt; ++j) {
+        const int i = lane + 64 * j;
+        const float4 l = lin[j];
+        float4 tq = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (SIS) tq = tv[j];
+        lin[j] = load_item(linears, h + 1, j, 1.f);
+        if constexpr (SIS) tv[j] = load_item(tar, h + 1, j, 0.f);
+        if (i < nvec) {
+          const float4 o = *reinterpret_cast<const float4*>(Es + 4 * i);
+          if (offset) *reinterpret_cast<float4*>(offset + g + 4 * i) = o;
+          const float4 p = make_float4(o.x * l.x, o.y * l.y, o.z * l.z, o.w * l.w);
+          if (predicted) *reinterpret_cast<float4*>(predicted + g + 4 * i) = p;
+          if constexpr (SIS) {
+            const float pe[4] = {p.x, p.y, p.z, p.w}, te[4] = {tq.x, tq.y, tq.z, tq.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int e = 4 * i + q;
+              const float sv = __builtin_amdgcn_sqrtf(fmaxf(pe[q], 0.f)), yv = __builtin_amdgcn_sqrtf(fmaxf(te[q], 0.f));
+              // eb == 0: the whole pass belongs to the second utterance, eb == cnt: to the first
+              const bool in0 = e < lim0;
+              const float s0 = in0 ? sv : 0.f, y0 = in0 ? yv : 0.f;
+              pa[0] = fmaf(s0, y0, pa[0]); pa[1] = fmaf(y0, y0, pa[1]); pa[2] = fmaf(s0, s0, pa[2]);
+              if (eb < cnt) {
+                const bool in1 = e >= eb && e < lim1;
+                const float s1 = in1 ? sv : 0.f, y1 = in1 ? yv : 0.f;
+                pb[0] = fmaf(s1, y1, pb[0]); pb[1] = fmaf(y1, y1, pb[1]); pb[2] = fmaf(s1, s1, pb[2]);
+              }
+            }
+          }
+        }
+      }
+      (void)straddle;
+      for (int i = 4 * nvec + lane; i < cnt; i += 64) {               // a ragged last tile only (cnt % 4 != 0)
+        const float o = Es[i];
+        if (offset) offset[g + i] = o;
+        const float p = linears ? linears[g + i] * o : o;
+        if (predicted) predicted[g + i] = p;
+        if constexpr (SIS) {
+          const float sv = __builtin_amdgcn_sqrtf(fmaxf(p, 0.f)), yv = __builtin_amdgcn_sqrtf(fmaxf(tar[g + i], 0.f));
+          if (i < lim0) { pa[0] = fmaf(sv, yv, pa[0]); pa[1] = fmaf(yv, yv, pa[1]); pa[2] = fmaf(sv, sv, pa[2]); }
+          else if (i >= eb && i < lim1) { pb[0] = fmaf(sv, yv, pb[0]); pb[1] = fmaf(yv, yv, pb[1]); pb[2] = fmaf(sv, sv, pb[2]); }
+        }
+      }
+      if constexpr (SIS) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { sa[q] += (double)pa[q]; sb[q] += (double)pb[q]; }
+      }
+    }
+    SE5_LDS_WAVE_SYNC();
+  }
+#undef SE5_LDS_WAVE_SYNC
+  if constexpr (SIS) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        sa[q] += __shfl_xor(sa[q], off);
+        sb[q] += __shfl_xor(sb[q], off);
+      }
+    __syncthreads();                                                 // every wave is past its slab
+    double* red = reinterpret_cast<double*>(smem5);                  // [4 waves][6]
+    if (lane == 0) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) { red[wave * 6 + q] = sa[q]; red[wave * 6 + 3 + q] = sb[q]; }
+    }
+    __syncthreads();
+    if (tid < 6) slab[(size_t)blockIdx.x * 6 + tid] = (red[tid] + red[6 + tid]) + (red[12 + tid] + red[18 + tid]);
   }
 }
 
@@ -590,12 +914,41 @@ extern "C" int se_head_split_weights_f32(const float* W, int N, int D, uint16_t*
   return SE_OK;
 }
 
+// the branch-free kernel's preconditions: N in (192, 224] (7 column tiles: the reference's 201 bins), a compile-time activation it was instantiated for,
+// F >= 128 (a tile touches at most two utterances), at most 256 staged statistics columns, 16-B aligned planes, D >= 4
+static bool head5_ok(const float* linears, const float* predicted, const float* offset, const float* tar, int F, int D, int N, int act) {
+  static const bool on = getenv("SE_AMD_HEAD5") == nullptr || atoi(getenv("SE_AMD_HEAD5")) != 0;      // 0: always head3_kernel (A/B)
+  const int Kp = (D + 15) / 16 * 16;
+  return on && (N + 31) / 32 == 7 && (act == SE_ACT_SIGMOID || act == SE_ACT_RELU) && F >= se::kHM && Kp <= se::kH5StatCols && D >= 4 &&
+         ((((uintptr_t)predicted | (uintptr_t)offset | (uintptr_t)linears | (uintptr_t)tar) % 16) == 0) && (N * 8 * 4) % 16 == 0;
+}
+
+static int launch_head5(const float* feats, const uint16_t* W3, const float* bias, const float* linears, const float* stats, int rows, int F, int D, int N,
+                        int act, float* predicted, float* offset, const float* tar, const int64_t* lengths, int len_div, double* slab, hipStream_t st) {
+  const int Kp = (D + 15) / 16 * 16;
+  se::ProfScope prof(se::kProfHead, 4.0 * rows * ((double)D + (linears ? N : 0) + (predicted ? N : 0) + (offset ? N : 0) + (tar ? N : 0)), st);
+  const dim3 grid((rows + se::kHM - 1) / se::kHM), block(256);
+  if (tar)
+    hipLaunchKernelGGL((se::head5_kernel<7, SE_ACT_SIGMOID, 1>), grid, block, 0, st, feats, W3, Kp, bias, linears, stats, rows, F, D, N, predicted, offset, tar,
+                       lengths, len_div, slab);
+  else if (act == SE_ACT_SIGMOID)
+    hipLaunchKernelGGL((se::head5_kernel<7, SE_ACT_SIGMOID, 0>), grid, block, 0, st, feats, W3, Kp, bias, linears, stats, rows, F, D, N, predicted, offset, nullptr,
+                       nullptr, 0, nullptr);
+  else
+    hipLaunchKernelGGL((se::head5_kernel<7, SE_ACT_RELU, 0>), grid, block, 0, st, feats, W3, Kp, bias, linears, stats, rows, F, D, N, predicted, offset, nullptr,
+                       nullptr, 0, nullptr);
+  SE_LAUNCH_CHECK();
+  return SE_OK;
+}
+
 extern "C" int se_head_linear_pre_f32(const float* feats, const uint16_t* W3, const float* bias, const float* linears, const float* stats,
                                       int B, int F, int D, int N, int act, float* predicted, float* offset, void* stream) {
   SE_REQUIRE(feats && W3 && (predicted || offset), "se_head_linear_pre_f32: null argument");
   SE_REQUIRE(B > 0 && B <= 65535 && F >= 2 && D > 0 && N > 0 && N <= 256, "se_head_linear_pre_f32: bad shape B=%d F=%d D=%d N=%d (N <= 256)", B, F, D, N);
   hipStream_t st = se::as_stream(stream);
   const int rows = B * F, nt = (N + 31) / 32, Kp = (D + 15) / 16 * 16;
+  if (head5_ok(linears, predicted, offset, nullptr, F, D, N, act))
+    return launch_head5(feats, W3, bias, linears, stats, rows, F, D, N, act, predicted, offset, nullptr, nullptr, 0, nullptr, st);
   switch (nt) {
     case 1: return launch_head3<1>(feats, W3, Kp, bias, linears, stats, rows, F, D, N, act, predicted, offset, st);
     case 2: return launch_head3<2>(feats, W3, Kp, bias, linears, stats, rows, F, D, N, act, predicted, offset, st);
@@ -606,4 +959,31 @@ extern "C" int se_head_linear_pre_f32(const float* feats, const uint16_t* W3, co
     case 7: return launch_head3<7>(feats, W3, Kp, bias, linears, stats, rows, F, D, N, act, predicted, offset, st);
     default: return launch_head3<8>(feats, W3, Kp, bias, linears, stats, rows, F, D, N, act, predicted, offset, st);
   }
+}
+
+// The evaluate()-style pass of a mask head scored by objective.SISDR (runner.py:556-575 with vcb.yaml / pseudo_noise.yaml): se_head_linear_pre_f32 AND
+// se_sisdr_spec_loss_f32 on its `predicted`, the criterion's sums taken from the products as they leave the head's registers (one extra read of
+// linear_tar instead of a launch that reads predicted and linear_tar).  Shapes the fused kernel does not take run the two entry points one after the other.
+extern "C" int se_sisdr_head_mean_f32(const double* slab, int B, int F, int tile_rows, float eps, float* loss_b, double* sums_out, float* loss_out, void* stream);
+
+extern "C" size_t se_head_sisdr_scratch_doubles(int B, int F, int N) {
+  const size_t wgs = ((size_t)B * F + se::kHM - 1) / se::kHM;
+  return std::max(wgs * 6, se_sisdr_spec_loss_scratch_doubles(B, F, N));
+}
+
+extern "C" int se_head_linear_sisdr_f32(const float* feats, const uint16_t* W3, const float* bias, const float* linears, const float* stats,
+                                        int B, int F, int D, int N, int act, float* predicted, float* offset,
+                                        const float* linear_tar, const int64_t* lengths, int len_div, float eps, double* scratch,
+                                        float* loss_b, double* sums_out, float* loss_out, void* stream) {
+  SE_REQUIRE(feats && W3 && predicted && linear_tar && lengths && scratch && loss_b && sums_out && loss_out, "se_head_linear_sisdr_f32: null argument");
+  SE_REQUIRE(B > 0 && B <= 65535 && F >= 2 && D > 0 && N > 0 && N <= 256 && len_div >= 0, "se_head_linear_sisdr_f32: bad shape B=%d F=%d D=%d N=%d", B, F, D, N);
+  hipStream_t st = se::as_stream(stream);
+  if (act == SE_ACT_SIGMOID && head5_ok(linears, predicted, offset, linear_tar, F, D, N, act)) {
+    const int rc = launch_head5(feats, W3, bias, linears, stats, B * F, F, D, N, act, predicted, offset, linear_tar, lengths, len_div, scratch, st);
+    if (rc) return rc;
+    return se_sisdr_head_mean_f32(scratch, B, F, se::kHM, eps, loss_b, sums_out, loss_out, stream);
+  }
+  const int rc = se_head_linear_pre_f32(feats, W3, bias, linears, stats, B, F, D, N, act, predicted, offset, stream);
+  if (rc) return rc;
+  return se_sisdr_spec_loss_f32(predicted, linear_tar, lengths, len_div, B, F, N, eps, scratch, loss_b, sums_out, loss_out, stream);
 }

@@ -189,16 +189,26 @@ __global__ __launch_bounds__(256) void sisdr_spec_slab_kernel(const float* __res
     slab[((size_t)b * gridDim.x + blockIdx.x) * 3 + threadIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
 }
 
-// one workgroup: loss_b[b] from the slab rows of utterance b (per_b slots of 3 doubles; `first` / `count` select them: the head's fused form keeps
-// one slot pair per 128-row workgroup instead of per chunk), then out = {sum_b loss_b, B} and loss = their ratio
+// one workgroup: loss_b[b] from the slab, then out = {sum_b loss_b, B} and loss = their ratio.  per_b > 0: utterance b owns per_b slots of 3 doubles
+// (sisdr_spec_slab_kernel); per_b == 0: the mask head's fused form (head.hip: head5_kernel) -- every `tile`-row workgroup of the (B F, N) plane left
+// two slots, {first utterance it touches, second}, and utterance b collects its own from the workgroups its rows fall into
 __global__ __launch_bounds__(256) void sisdr_spec_mean_kernel(const double* __restrict__ slab, int per_b, int B, float eps, float* __restrict__ loss_b,
-                                                              double* __restrict__ out, float* __restrict__ loss) {
+                                                              double* __restrict__ out, float* __restrict__ loss, int F = 0, int tile = 1) {
   __shared__ double red[4];
   double acc = 0.0;
   for (int b = threadIdx.x; b < B; b += 256) {
     double S = 0.0, T2 = 0.0, Q = 0.0;
-    const double* r = slab + (size_t)b * per_b * 3;
-    for (int c = 0; c < per_b; ++c) { S += r[3 * c]; T2 += r[3 * c + 1]; Q += r[3 * c + 2]; }
+    if (per_b > 0) {
+      const double* r = slab + (size_t)b * per_b * 3;
+      for (int c = 0; c < per_b; ++c) { S += r[3 * c]; T2 += r[3 * c + 1]; Q += r[3 * c + 2]; }
+    } else {
+      const long long lo = (long long)b * F, hi = lo + F - 1;
+      for (long long wg = lo / tile; wg <= hi / tile; ++wg) {
+        const int u = b - (int)((wg * tile) / F);                  // 0: b is the first utterance of workgroup wg, 1: the second
+        const double* r = slab + ((size_t)wg * 2 + u) * 3;
+        S += r[0]; T2 += r[1]; Q += r[2];
+      }
+    }
     const double e = (double)eps;
     const double a = S / (T2 + e);
     const double ay2 = a * a * T2;
@@ -238,6 +248,13 @@ extern "C" int se_sisdr_spec_loss_f32(const float* predicted, const float* linea
   hipLaunchKernelGGL(se::sisdr_spec_slab_kernel, dim3(chunks, B), dim3(256), 0, st, predicted, linear_tar, lengths, len_div, F, N, scratch);
   SE_LAUNCH_CHECK();
   hipLaunchKernelGGL(se::sisdr_spec_mean_kernel, dim3(1), dim3(256), 0, st, scratch, chunks, B, eps, loss_b, sums_out, loss_out);
+  SE_LAUNCH_CHECK();
+  return SE_OK;
+}
+
+extern "C" int se_sisdr_head_mean_f32(const double* slab, int B, int F, int tile_rows, float eps, float* loss_b, double* sums_out, float* loss_out, void* stream) {
+  SE_REQUIRE(slab && loss_b && sums_out && loss_out && B > 0 && F >= tile_rows && tile_rows > 0, "se_sisdr_head_mean_f32: bad argument");
+  hipLaunchKernelGGL(se::sisdr_spec_mean_kernel, dim3(1), dim3(256), 0, se::as_stream(stream), slab, 0, B, eps, loss_b, sums_out, loss_out, F, tile_rows);
   SE_LAUNCH_CHECK();
   return SE_OK;
 }

@@ -177,6 +177,8 @@ class HeadEnhanceStep:
     wavs (B, C >= 2, T) -> features -> mask head -> mask (.) noisy power -> decode_wav [-> criterion].
     Returns (wav_pred, predicted, linear_tar, loss); loss is None without a criterion."""
 
+    fuse_criterion = True        # False: the criterion as its own launches behind the head (A/B)
+
     def __init__(self, preprocessor, head, criterion=None):
         self.pre, self.head, self.criterion = preprocessor, head, criterion
         if getattr(head, 'cmvn', False) and hasattr(head, 'eps'):
@@ -187,12 +189,17 @@ class HeadEnhanceStep:
     def __call__(self, wavs, lengths, max_len=None):
         from .objective import SISDR
         feats_up, feats_down, lin_inp, ph_inp, lin_tar, ph_tar = self.pre(wavs)
-        predicted, res = self.head(features=feats_down, linears=lin_inp)
+        hop = self.pre._win_args['hop_length']
+        if (self.fuse_criterion and isinstance(self.criterion, SISDR) and self.criterion.reduce_fn is None and hasattr(self.head, 'enhance_scored') and
+                not lin_tar.is_inference()):
+            # the criterion's sums come out of the head's own launch (the finished loss rides on `predicted`; objective.SISDR.forward below takes it)
+            predicted, res = self.head.enhance_scored(feats_down, lin_inp, lin_tar, lengths, hop, self.criterion.eps)
+        else:
+            predicted, res = self.head(features=feats_down, linears=lin_inp)
         wav_tar = wavs[:, self.pre.channel_tar, :]
         wav_pred = decode.decode_wav(self.pre, predicted, ph_inp, lengths, wav_tar, max_len=max_len)
         loss = None
         if self.criterion is not None:
-            hop = self.pre._win_args['hop_length']
             if isinstance(self.criterion, (L1, SISDR)):      # frame counts derived inside the kernel (runner.py:455): no element-wise launches in front
                 lens_kw = {'wav_lengths': lengths, 'hop': hop}
             else:

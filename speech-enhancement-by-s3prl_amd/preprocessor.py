@@ -336,11 +336,12 @@ class OnlinePreprocessor(nn.Module):
                                             int(bool(cmvn)), float(self.eps), _lib.ptr(out), _lib.ptr(ws), nbytes,
                                             _lib.ptr(xin), self.ENCODER_IN_PAD if side else 0, _lib.ptr(valid), _lib.stream()), 'se_features2_f32')
         else:
-            nbytes = lib.se_features3_workspace_bytes(B, D, delta) if cmvn else 0
-            ws = torch.empty(nbytes, device=raw.device, dtype=torch.uint8) if cmvn else None
             # LinearResidual's own CMVN (model.py:29-31) needs the column statistics of exactly these rows: the owner of the head says so
             # (head_stats_eps, pipeline.HeadEnhanceStep) and they ride on the returned tensor as `_se_colstats`
             hs_eps = None if (cmvn or encoder_side) else self.head_stats_eps
+            nbytes = (lib.se_features3_workspace_bytes(B, D, delta) if cmvn else
+                      lib.se_features3_colstats_workspace_bytes(B, D, F, delta) if hs_eps is not None else 0)
+            ws = torch.empty(nbytes, device=raw.device, dtype=torch.uint8) if nbytes else None
             colstats = torch.empty(B, Dout, 2, device=raw.device, dtype=torch.float32) if hs_eps is not None else None
             _lib.check(lib.se_features3_f32(_lib.ptr(raw), int(raw_time_major), B, D, F, int(bool(log)), int(delta), int(bool(cmvn)), float(self.eps),
                                             _lib.ptr(out), _lib.ptr(ws), nbytes, _lib.ptr(xin), self.ENCODER_IN_PAD if side else 0, _lib.ptr(valid),

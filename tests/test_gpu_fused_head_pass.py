@@ -31,7 +31,7 @@ def _features3(lib, L, raw, tm, log, delta, cmvn, eps, pad=0, colstats_eps=None)
     B, D, F = (raw.shape[0], raw.shape[2], raw.shape[1]) if tm else raw.shape
     Dout = D * (1 + delta)
     out = torch.empty(B, F, Dout, device=raw.device)
-    n = lib.se_features3_workspace_bytes(B, D, delta)
+    n = max(lib.se_features3_workspace_bytes(B, D, delta), lib.se_features3_colstats_workspace_bytes(B, D, F, delta))
     ws = torch.empty(n, device=raw.device, dtype=torch.uint8)
     xin = torch.zeros(B * F, pad, device=raw.device, dtype=torch.bfloat16) if pad else None
     valid = torch.empty(B, device=raw.device, dtype=torch.int32) if pad else None
@@ -96,8 +96,16 @@ def test_feature_launch_hands_the_head_its_column_statistics(gpu, B, D, F, delta
     assert torch.allclose(cst, ref, rtol=2e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize('B,F,D,N,cmvn', [(2, 1001, 120, 201, True), (3, 77, 201, 201, True), (1, 130, 40, 64, False)])
-def test_head_on_ready_made_split_and_statistics_is_bit_identical(gpu, B, F, D, N, cmvn):
+@pytest.mark.parametrize('B,F,D,N,cmvn,act', [
+    (2, 1001, 120, 201, True, 2),      # the branch-free kernel (201 bins, Sigmoid, F >= 128): pseudo_noise.yaml's features
+    (3, 1001, 201, 201, True, 2),      # vcb.yaml's linear features: D % 4 != 0, the last 16-B piece of a row is shifted back into the tensor
+    (5, 130, 120, 201, True, 2),       # every 128-row tile straddles two utterances
+    (2, 128, 13, 201, False, 1),       # ReLU, no CMVN, one K chunk
+    (1, 300, 36, 193, True, 2),        # 193 bins: the smallest width with seven column tiles; two K chunks + a partial third
+    (3, 77, 201, 201, True, 2),        # F < 128: the general kernel
+    (1, 130, 40, 64, False, 2),        # two column tiles: the general kernel
+])
+def test_head_on_ready_made_split_and_statistics_is_bit_identical(gpu, B, F, D, N, cmvn, act):
     from speech_enhancement_by_s3prl_amd import _lib as L
     lib = L.load()
     torch.manual_seed(B * F)
@@ -107,7 +115,7 @@ def test_head_on_ready_made_split_and_statistics_is_bit_identical(gpu, B, F, D, 
     n = lib.se_head_workspace_bytes(B, F, D, N)
     ws = torch.empty(n, device=gpu, dtype=torch.uint8)
     p0, o0 = torch.empty(B, F, N, device=gpu), torch.empty(B, F, N, device=gpu)
-    L.check(lib.se_head_linear_f32(L.ptr(feats), L.ptr(W), L.ptr(bias), L.ptr(lin), B, F, D, N, 2, int(cmvn), 1e-6, L.ptr(p0), L.ptr(o0), L.ptr(ws), n, L.stream()),
+    L.check(lib.se_head_linear_f32(L.ptr(feats), L.ptr(W), L.ptr(bias), L.ptr(lin), B, F, D, N, act, int(cmvn), 1e-6, L.ptr(p0), L.ptr(o0), L.ptr(ws), n, L.stream()),
             'se_head_linear_f32')
     w3 = torch.empty(lib.se_head_w3_bytes(N, D), device=gpu, dtype=torch.uint8)
     L.check(lib.se_head_split_weights_f32(L.ptr(W), N, D, L.ptr(w3), L.stream()), 'se_head_split_weights_f32')
@@ -116,9 +124,53 @@ def test_head_on_ready_made_split_and_statistics_is_bit_identical(gpu, B, F, D, 
         stats = torch.empty(B, D, 2, device=gpu)
         L.check(lib.se_head_colstats_f32(L.ptr(feats), B, F, D, 1e-6, L.ptr(stats), L.stream()), 'se_head_colstats_f32')
     p1, o1 = torch.empty(B, F, N, device=gpu), torch.empty(B, F, N, device=gpu)
-    L.check(lib.se_head_linear_pre_f32(L.ptr(feats), L.ptr(w3), L.ptr(bias), L.ptr(lin), L.ptr(stats), B, F, D, N, 2, L.ptr(p1), L.ptr(o1), L.stream()),
+    L.check(lib.se_head_linear_pre_f32(L.ptr(feats), L.ptr(w3), L.ptr(bias), L.ptr(lin), L.ptr(stats), B, F, D, N, act, L.ptr(p1), L.ptr(o1), L.stream()),
             'se_head_linear_pre_f32')
+    # same splits, same products in the same order, same activation instructions: the two kernels agree to the bit
     assert torch.equal(p1, p0) and torch.equal(o1, o0)
+    # mask only / product only (the lazy `offset` of evaluate())
+    p2 = torch.empty(B, F, N, device=gpu)
+    L.check(lib.se_head_linear_pre_f32(L.ptr(feats), L.ptr(w3), L.ptr(bias), None, L.ptr(stats), B, F, D, N, act, L.ptr(p2), None, L.stream()), 'se_head_linear_pre_f32')
+    assert torch.equal(p2, o0)
+
+
+@pytest.mark.parametrize('B,F,D,N', [(4, 1001, 120, 201), (5, 130, 120, 201), (3, 200, 201, 201), (2, 77, 120, 201)])
+def test_head_with_the_criterion_sums_taken_in_its_epilogue(gpu, B, F, D, N):
+    """se_head_linear_sisdr_f32 = se_head_linear_pre_f32 + se_sisdr_spec_loss_f32: ragged lengths (one utterance shorter than a tile, one empty
+    after the first frame, one full), tiles that straddle two utterances; (2, 77, ...) takes the un-fused route inside."""
+    from speech_enhancement_by_s3prl_amd import _lib as L
+    lib = L.load()
+    torch.manual_seed(B + F)
+    feats = (torch.randn(B, F, D) * 2).to(gpu)
+    lin, tar = (torch.rand(B, F, N) * 5).to(gpu), (torch.rand(B, F, N) * 5).to(gpu)
+    W, bias = (torch.randn(N, D) * 0.1).to(gpu), torch.randn(N).to(gpu)
+    frames = torch.tensor([F, 1, max(F // 3, 1), F - 1, 100][:B], dtype=torch.int64)
+    wav_len = ((frames - 1) * 160 + 31).to(gpu)
+    w3 = torch.empty(lib.se_head_w3_bytes(N, D), device=gpu, dtype=torch.uint8)
+    L.check(lib.se_head_split_weights_f32(L.ptr(W), N, D, L.ptr(w3), L.stream()), 'se_head_split_weights_f32')
+    stats = torch.empty(B, D, 2, device=gpu)
+    L.check(lib.se_head_colstats_f32(L.ptr(feats), B, F, D, 1e-6, L.ptr(stats), L.stream()), 'se_head_colstats_f32')
+    p0 = torch.empty(B, F, N, device=gpu)
+    L.check(lib.se_head_linear_pre_f32(L.ptr(feats), L.ptr(w3), L.ptr(bias), L.ptr(lin), L.ptr(stats), B, F, D, N, 2, L.ptr(p0), None, L.stream()), 'pre')
+    sc0 = torch.empty(lib.se_sisdr_spec_loss_scratch_doubles(B, F, N), device=gpu, dtype=torch.float64)
+    lb0, s0, l0 = torch.empty(B, device=gpu), torch.empty(2, device=gpu, dtype=torch.float64), torch.empty((), device=gpu)
+    L.check(lib.se_sisdr_spec_loss_f32(L.ptr(p0), L.ptr(tar), L.ptr(wav_len), 160, B, F, N, 1e-10, L.ptr(sc0), L.ptr(lb0), L.ptr(s0), L.ptr(l0), L.stream()), 'loss')
+    p1 = torch.empty(B, F, N, device=gpu)
+    sc1 = torch.empty(lib.se_head_sisdr_scratch_doubles(B, F, N), device=gpu, dtype=torch.float64)
+    lb1, s1, l1 = torch.empty(B, device=gpu), torch.empty(2, device=gpu, dtype=torch.float64), torch.empty((), device=gpu)
+    L.check(lib.se_head_linear_sisdr_f32(L.ptr(feats), L.ptr(w3), L.ptr(bias), L.ptr(lin), L.ptr(stats), B, F, D, N, 2, L.ptr(p1), None, L.ptr(tar), L.ptr(wav_len),
+                                         160, 1e-10, L.ptr(sc1), L.ptr(lb1), L.ptr(s1), L.ptr(l1), L.stream()), 'fused')
+    assert torch.equal(p1, p0)
+    # the fused form sums a pass's 28 elements per lane in fp32 with hardware square roots: 1e-6 relative on the sums
+    assert torch.allclose(lb1, lb0, rtol=1e-5, atol=1e-4)
+    assert abs(l1.item() - l0.item()) <= 1e-5 * abs(l0.item()) + 1e-5 and s1[1].item() == B
+    # and against the definition (objective.py:81-100) in fp64
+    src, ref = p0.double().clamp(min=0).sqrt(), tar.double().clamp(min=0).sqrt()
+    m = (torch.arange(F, device=gpu)[None, :] < frames.to(gpu)[:, None]).double()[:, :, None]
+    src, ref = (src * m).flatten(1), (ref * m).flatten(1)
+    a = (src * ref).sum(1, keepdim=True) / ((ref * ref).sum(1, keepdim=True) + 1e-10)
+    want = -10 * torch.log10((a * ref).pow(2).sum(1) / ((a * ref - src).pow(2).sum(1) + 1e-10) + 1e-10)
+    assert torch.allclose(lb1.double(), want, rtol=1e-5, atol=1e-4)
 
 
 def test_sisdr_inference_criterion_golden_and_equal_to_the_autograd_form(gpu, golden):
