@@ -176,7 +176,8 @@ class LinearResidual(nn.Module):
 
     def enhance_scored(self, features, linears, linear_tar, lengths, len_div, eps):
         """forward() for evaluate() when objective.SISDR(eps) scores the result next: same (predicted, {'offset': lazy}) -- see _forward_lazy"""
-        if torch.is_grad_enabled() or not features.is_cuda or not getattr(self, 'lazy_offset', True):
+        # the hand-over to the criterion is tied to `predicted`'s version counter: tensors made under torch.inference_mode() have none -> the plain call
+        if torch.is_grad_enabled() or torch.is_inference_mode_enabled() or not features.is_cuda or not getattr(self, 'lazy_offset', True):
             return self.forward(features, linears)
         return self._forward_lazy(features, linears, sisdr=(linear_tar, lengths, len_div, eps))
 
