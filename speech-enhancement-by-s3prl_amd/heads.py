@@ -109,16 +109,18 @@ class LinearResidual(nn.Module):
 
     def _w3(self, dev):
         """the three-term bf16 split of the weights (se_head_split_weights_f32), rebuilt when the parameter changed (in-place update, new storage, device)"""
+        import weakref
         w = self.linear.weight
         key = (w.data_ptr(), w._version, str(dev))
         c = getattr(self, '_w3_cache', None)
-        if c is None or c[0] != key:
+        # the entry belongs to one Parameter OBJECT (a new parameter may reuse a freed one's address with the same version count)
+        if c is None or c[0] != key or c[2]() is not w:
             lib = _lib.load()
             N, D = w.shape
             wf = w.detach().contiguous().float()
             w3 = torch.empty(int(lib.se_head_w3_bytes(N, D)), device=dev, dtype=torch.uint8)
             _lib.check(lib.se_head_split_weights_f32(_lib.ptr(wf), N, D, _lib.ptr(w3), _lib.stream()), 'se_head_split_weights_f32')
-            c = self._w3_cache = (key, w3)
+            c = self._w3_cache = (key, w3, weakref.ref(w))
         return c[1]
 
     def _forward_lazy(self, features, linears, sisdr=None):
