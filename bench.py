@@ -91,8 +91,8 @@ def cpu_baseline(batch, layers, seconds_budget=25.0):
 
 
 # committed counter passes (tools/collect_profiles.sh), one file per workload: bench.py cannot run counter passes on itself
-PMC_FILES = {'enhance': 'r05_pmc_fetch_write.json', 'finetune': 'r05_pmc_fetch_write_finetune.json',
-             'head:mel120': 'r05_pmc_fetch_write_head_mel120.json', 'head:linear201': 'r05_pmc_fetch_write_head_linear201.json'}
+PMC_FILES = {'enhance': 'r05c_pmc_fetch_write.json', 'finetune': 'r05c_finetune_pmc_fetch_write.json',
+             'head:mel120': 'r05c_head_mel120_pmc_fetch_write.json', 'head:linear201': 'r05c_head_linear201_pmc_fetch_write.json'}
 
 
 # every kernel the prof family 'gemm_bf16' times (csrc/gemm*.hip): the traffic figure is the launch-weighted mean over the same launches
@@ -572,10 +572,10 @@ def head_pass_bytes(head_feat):
     T, F, K = 160000, 1001, 201
     D = 120 if head_feat == 'mel120' else 201
     stft = 2 * (4 * T + 2 * 4 * F * K)                       # both channels, power + phase each (2 249 608 B per utterance-channel)
-    feats = (4 * F * 40 + 4 * F * D * 3) if head_feat == 'mel120' else 0
-    head = 4 * F * (D + 2 * K + K)                           # features + noisy power in, predicted + offset out
+    feats = (4 * F * 40 + 4 * F * D) if head_feat == 'mel120' else 0      # round 5: one pass, mel plane in, time-major rows out (was in + 3 x out)
+    head = 4 * F * (D + 2 * K + K)                           # features + noisy power + clean power (the criterion's sums ride in the epilogue) in, predicted out
     istft = 2 * 4 * F * K + 4 * T + 4 * T                    # + the reference wav read by the level normalisation
-    crit = 2 * 4 * F * K                                     # SISDR criterion reads predicted + clean power
+    crit = 0                                                 # round 5: no pass of its own (was predicted + clean power: 2 x 4 F K)
     return {'sum_of_kernels': stft + feats + head + istft + crit, 'fused_bound': 2 * 4 * T,
             'parts': {'stft_2ch': stft, 'features': feats, 'head': head, 'istft_dbnorm': istft, 'criterion': crit}}
 
