@@ -223,3 +223,40 @@ def test_finetune_step_dispatch_switches_agree():
     b = _t.tensor([v for n in sorted(off['samples']) for v in off['samples'][n]], dtype=_t.float64)
     cos = float(_t.dot(a, b) / (a.norm() * b.norm()))
     assert cos > 0.99, cos
+
+
+def test_scored_head_pass_at_vcb_batch_mel_features(gpu):
+    """configs[0] / [3] with pseudo_noise.yaml's features (mel / log / delta-2, 120 dims) and the SISDR criterion at B = 256: the round-5 route (one-pass
+    feature launch handing over its column statistics, branch-free head taking the criterion's sums) against (a) the criterion recomputed from the
+    returned planes by its own launches, (b) the same utterances in a batch of 3 (every stage is per utterance; the loss is a mean over utterances),
+    (c) the defining property of the statistics: the head's CMVN input has zero mean and unit unbiased std per (utterance, column)"""
+    from speech_enhancement_by_s3prl_amd import pipeline, synth
+    from speech_enhancement_by_s3prl_amd.heads import LinearResidual
+    from speech_enhancement_by_s3prl_amd.objective import SISDR, sisdr_loss_inference
+    pre = pipeline.build_preprocessor(pipeline.make_config(), gpu, upstream='baseline')
+    torch.manual_seed(1)
+    head = LinearResidual(input_size=120, output_size=201, cmvn=True).to(gpu)
+    step = pipeline.HeadEnhanceStep(pre, head, criterion=SISDR())
+    lengths, wavs = synth.fast_batch(256, 160000, seed=13, device=gpu)
+    wavs = wavs[:, :2].contiguous()
+    lengths = lengths.clone()
+    lengths[7], lengths[130] = 90000, 12345
+    wavs[7, :, 90000:] = 0.0
+    wavs[130, :, 12345:] = 0.0
+    wav_all, pred_all, tar_all, loss = step(wavs, lengths, max_len=160000)
+    assert getattr(pred_all, '_se_sisdr', None) is not None            # the criterion's sums came out of the head's launch
+    # (a)
+    l2, lb = sisdr_loss_inference(pred_all, tar_all, lengths, 160, 1e-10)
+    bounded('scored_head_pass fused vs own-launch criterion', abs(loss.item() - l2.item()) / abs(l2.item()), 1e-5)
+    # (b)
+    idx = [7, 130, 255]
+    w3, p3, t3, l3 = step(wavs[idx].contiguous(), lengths[idx].contiguous(), max_len=160000)
+    bounded('scored_head_pass predicted, batch of 3 vs 256', _relmax(p3, pred_all[idx]), 2e-5)
+    bounded('scored_head_pass waveform, batch of 3 vs 256', _relmax(w3, wav_all[idx]), 2e-5)
+    bounded('scored_head_pass loss of 3 = mean of their loss_b', abs(l3.item() - lb[idx].double().mean().item()) / abs(l3.item()), 1e-5)
+    # (c)
+    feats = pre(wavs[:8].contiguous())[1]
+    cst = feats._se_colstats[0]
+    z = (feats.double() - cst[..., 0].double()[:, None, :]) * cst[..., 1].double()[:, None, :]
+    assert z.mean(dim=1).abs().max().item() < 1e-4
+    assert (z.std(dim=1, unbiased=True) - 1.0).abs().max().item() < 1e-3
