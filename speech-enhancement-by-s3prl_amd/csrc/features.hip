@@ -199,7 +199,18 @@ __global__ __launch_bounds__(256) void feat_stats_kernel(const float* __restrict
 //            level j - 1 EVALUATED AT the clamped frame (compute_deltas pads the sequence it differentiates, level by level: the value left of
 //            frame 0 is delta_j[0], not a delta of padded inputs)
 //   emit   : as feat_emit_kernel (rows of the tile are one contiguous span of `out`; odd LDS pitch: conflict-free column walks), same side outputs
-constexpr int kTileT = 32;
+#ifndef SE_FEAT_TILE
+#define SE_FEAT_TILE 32
+#endif
+constexpr int kTileT = SE_FEAT_TILE;      // frames per workgroup (a multiple of 32: the valid-frame count walks 32 frames per 256 threads)
+// developer A/B (-DSE_FEAT_FASTMATH, results differ in the last ulp): hardware log2 x ln 2 and a multiplication by 0.1f in place of logf and the IEEE / 10
+#ifdef SE_FEAT_FASTMATH
+#define SE_FEAT_LOG(x_) __logf(x_)
+#define SE_FEAT_DIV10(x_) ((x_) * 0.1f)
+#else
+#define SE_FEAT_LOG(x_) logf(x_)
+#define SE_FEAT_DIV10(x_) ((x_) / 10.f)
+#endif
 
 __global__ __launch_bounds__(256) void feat_tile_kernel(const float* __restrict__ raw, int raw_time_major, int D, int F, int apply_log, int delta,
                                                         int cmvn, float eps, const float* __restrict__ stats, float* __restrict__ out,
@@ -216,7 +227,7 @@ __global__ __launch_bounds__(256) void feat_tile_kernel(const float* __restrict_
       const int p = it / D, d = it - p * D;
       const int u = min(max(t0 - H + p, 0), F - 1);
       float v = raw[((size_t)b * F + u) * D + d];
-      if (apply_log) v = logf(v + eps);
+      if (apply_log) v = SE_FEAT_LOG(v + eps);
       x[d * P + p] = v;
     }
   } else {
@@ -224,7 +235,7 @@ __global__ __launch_bounds__(256) void feat_tile_kernel(const float* __restrict_
       const int d = it / W, p = it - d * W;
       const int u = min(max(t0 - H + p, 0), F - 1);
       float v = raw[((size_t)b * D + d) * F + u];
-      if (apply_log) v = logf(v + eps);
+      if (apply_log) v = SE_FEAT_LOG(v + eps);
       x[d * P + p] = v;
     }
   }
@@ -239,7 +250,7 @@ __global__ __launch_bounds__(256) void feat_tile_kernel(const float* __restrict_
       const int pc = min(max(t0 - H + p, 0), F - 1) - (t0 - H);      // the position of the clamped frame
       const float* s = src + d * P + pc;
       const float m2 = s[-2], m1 = s[-1], p1 = s[1], p2 = s[2];
-      dst[d * P + p] = (-2.f * m2 - m1 + p1 + 2.f * p2) / 10.f;
+      dst[d * P + p] = SE_FEAT_DIV10(-2.f * m2 - m1 + p1 + 2.f * p2);
     }
     __syncthreads();
   }
@@ -312,16 +323,19 @@ __global__ __launch_bounds__(256) void feat_tile_kernel(const float* __restrict_
   }
   if (valid_count) {
     // 8 threads per frame, shuffle-reduced; one integer atomic per workgroup (as feat_emit_kernel, same summation order)
-    const int tl = tid >> 3, part = tid & 7;
-    float sum = 0.f;
-    if (tl < nt)
-      for (int dd = part; dd < Dout; dd += 8) sum += xt[dd * P + tl];
-    sum += __shfl_xor(sum, 1);
-    sum += __shfl_xor(sum, 2);
-    sum += __shfl_xor(sum, 4);
-    const unsigned long long m = __ballot(part == 0 && tl < nt && sum != 0.f);
+    const int part = tid & 7;
+    int cnt = 0;
+    for (int tl = tid >> 3; tl < kTileT; tl += 32) {
+      float sum = 0.f;
+      if (tl < nt)
+        for (int dd = part; dd < Dout; dd += 8) sum += xt[dd * P + tl];
+      sum += __shfl_xor(sum, 1);
+      sum += __shfl_xor(sum, 2);
+      sum += __shfl_xor(sum, 4);
+      cnt += __popcll(__ballot(part == 0 && tl < nt && sum != 0.f));
+    }
     __shared__ int cnts[4];
-    if ((tid & 63) == 0) cnts[tid >> 6] = __popcll(m);
+    if ((tid & 63) == 0) cnts[tid >> 6] = cnt;
     __syncthreads();
     if (tid == 0) atomicAdd(&valid_count[b], cnts[0] + cnts[1] + cnts[2] + cnts[3]);
   }
